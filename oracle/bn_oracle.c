@@ -1,0 +1,653 @@
+/*
+ * TEST INFRASTRUCTURE - CPU oracle for the BN254 pairing hot path.
+ *
+ * A plain-C restatement, limb for limb, of the algorithm the reference crate
+ * zcash-hackworks/bn v0.4.3 executes for `pairing(G1, G2) -> Gt` and `G * Fr`.
+ * It is the checker for the HIP path and the timed "reference CPU path" stand-in
+ * (bench.py cpu_baseline, kind "port"); it is never linked, imported or called by
+ * the product library (bn_amd/).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.
+ *
+ * Parity pin: every known-answer test the reference holds for this path
+ * (tests/golden/reference_kats.json, extracted from src/fields/mod.rs:67-201 and
+ * src/groups/mod.rs:522-796) is reproduced bit-for-bit by this file
+ * (tests/test_oracle_kats.py).  The reference itself cannot be built here
+ * (Rust; no rustc/cargo in the image), so there is no oracle/_ref.
+ *
+ * What "reference-faithful" means here: the same operation schedule (36 938 Fq
+ * Montgomery multiplications per pairing), the same SOS Montgomery multiply built from
+ * 32-bit half-word MACs, the same binary-EEA inversion, the same MSB-first bit loops.
+ * -DBNO_NATIVE128 swaps the half-word MAC for a 64x64->128 multiply (a faster CPU
+ * port, same results) so both can be timed.
+ *
+ * Memory layouts equal the reference's #[repr(C)] types:
+ *   Fq/Fr  u64[4] little-endian limbs, Montgomery image a*2^256 mod m, always < m
+ *   Fq2 (c0,c1) | Fq6 (c0,c1,c2) | Fq12 (c0,c1) | G1 (x,y,z) | G2 (x,y,z over Fq2)
+ */
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include <pthread.h>
+
+typedef uint64_t u64;
+typedef struct { u64 l[4]; } u256;
+typedef u256 fq;                 /* Montgomery form */
+typedef struct { fq c0, c1; } fq2;
+typedef struct { fq2 c0, c1, c2; } fq6;
+typedef struct { fq6 c0, c1; } fq12;
+typedef struct { fq x, y, z; } g1;
+typedef struct { fq2 x, y, z; } g2;
+typedef struct { fq2 x, y; } g2aff;
+typedef struct { fq x, y; } g1aff;
+typedef struct { fq2 ell_0, ell_vw, ell_vv; } ellc;
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* all numeric constants (field moduli, Montgomery constants, xi, Frobenius and twist coefficients, generators,
+ * loop counts: fp.rs:161-177, fq2.rs:10-22, fq6.rs:5-40, fq12.rs:7-24, groups/mod.rs:349-402,441-470) are DERIVED
+ * from u by oracle/gen_consts.py and checked against the reference literals in tests/test_oracle_kats.py */
+#include "bn_oracle_consts.h"
+
+/* ---------------------------------------------------------------- U256 (src/arith.rs:161-503) */
+static inline int u256_cmp(const u256 *a, const u256 *b) {          /* arith.rs:161-174 */
+    for (int i = 3; i >= 0; --i) {
+        if (a->l[i] < b->l[i]) return -1;
+        if (a->l[i] > b->l[i]) return 1;
+    }
+    return 0;
+}
+static inline int u256_is_zero(const u256 *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int u256_eq(const u256 *a, const u256 *b) { return u256_cmp(a, b) == 0; }
+static inline int u256_is_one(const u256 *a) { return a->l[0] == 1 && (a->l[1] | a->l[2] | a->l[3]) == 0; }
+
+#define HI32(v) ((v) >> 32)
+#define LO32(v) ((v) & 0xFFFFFFFFULL)
+
+static inline u64 adc64(u64 a, u64 b, u64 *carry) {                 /* arith.rs:397-406 */
+    u64 t0 = LO32(a) + LO32(b) + *carry;
+    u64 t1 = HI32(a) + HI32(b) + HI32(t0);
+    *carry = HI32(t1);
+    return (LO32(t1) << 32) | LO32(t0);
+}
+static inline u64 sbb64(u64 a, u64 b, u64 *borrow) {                /* arith.rs:421-431 */
+    u64 t0 = (1ULL << 32) + LO32(a) - LO32(b) - *borrow;
+    u64 t1 = (1ULL << 32) + HI32(a) - HI32(b) - (HI32(t0) == 0);
+    *borrow = (HI32(t1) == 0);
+    return (LO32(t1) << 32) | LO32(t0);
+}
+static inline void add_nocarry(u256 *a, const u256 *b) {            /* arith.rs:408-417 */
+    u64 c = 0;
+    for (int i = 0; i < 4; ++i) a->l[i] = adc64(a->l[i], b->l[i], &c);
+}
+static inline void sub_noborrow(u256 *a, const u256 *b) {           /* arith.rs:419-439 */
+    u64 br = 0;
+    for (int i = 0; i < 4; ++i) a->l[i] = sbb64(a->l[i], b->l[i], &br);
+}
+static inline u64 mac_with_carry(u64 a, u64 b, u64 c, u64 *carry) { /* arith.rs:443-458 */
+#ifdef BNO_NATIVE128
+    unsigned __int128 t = (unsigned __int128)b * c + a + *carry;
+    *carry = (u64)(t >> 64);
+    return (u64)t;
+#else
+    u64 bh = HI32(b), bl = LO32(b), ch = HI32(c), cl = LO32(c);
+    u64 x = bl * cl + LO32(a) + LO32(*carry);
+    u64 y = bl * ch;
+    u64 z = bh * cl;
+    u64 r = HI32(x) + LO32(y) + LO32(z) + HI32(a) + HI32(*carry);
+    *carry = bh * ch + HI32(r) + HI32(y) + HI32(z);
+    return (LO32(r) << 32) | LO32(x);
+#endif
+}
+/* acc[0..nacc) += b[0..4) * c            (arith.rs:441-478) */
+static inline void mac_digit(u64 *acc, int nacc, const u64 *b, u64 c) {
+    if (c == 0) return;
+    u64 carry = 0;
+    for (int i = 0; i < nacc; ++i) {
+        if (i < 4) acc[i] = mac_with_carry(acc[i], b[i], c, &carry);
+        else if (carry != 0) acc[i] = mac_with_carry(acc[i], 0, c, &carry);
+        else break;
+    }
+}
+static inline void mul_reduce(u256 *self, const u256 *by, const u256 *m, u64 inv) {  /* arith.rs:481-503 */
+    u64 res[8] = {0};
+    for (int i = 0; i < 4; ++i) mac_digit(res + i, 8 - i, by->l, self->l[i]);
+    for (int i = 0; i < 4; ++i) {
+        u64 k = inv * res[i];
+        mac_digit(res + i, 8 - i, m->l, k);
+    }
+    memcpy(self->l, res + 4, 32);
+}
+static inline void u256_add(u256 *a, const u256 *b, const u256 *m) {   /* arith.rs:238-244 */
+    add_nocarry(a, b);
+    if (u256_cmp(a, m) >= 0) sub_noborrow(a, m);
+}
+static inline void u256_sub(u256 *a, const u256 *b, const u256 *m) {   /* arith.rs:247-253 */
+    if (u256_cmp(a, b) < 0) add_nocarry(a, m);
+    sub_noborrow(a, b);
+}
+static inline void u256_mul(u256 *a, const u256 *b, const u256 *m, u64 inv) {  /* arith.rs:257-263 */
+    mul_reduce(a, b, m, inv);
+    if (u256_cmp(a, m) >= 0) sub_noborrow(a, m);
+}
+static inline void u256_neg(u256 *a, const u256 *m) {                   /* arith.rs:266-273 */
+    if (!u256_is_zero(a)) { u256 t = *m; sub_noborrow(&t, a); *a = t; }
+}
+static inline void div2(u256 *a) {                                      /* arith.rs:359-372 */
+    a->l[0] = (a->l[0] >> 1) | (a->l[1] << 63);
+    a->l[1] = (a->l[1] >> 1) | (a->l[2] << 63);
+    a->l[2] = (a->l[2] >> 1) | (a->l[3] << 63);
+    a->l[3] >>= 1;
+}
+static void u256_invert(u256 *self, const u256 *m) {                    /* arith.rs:281-327 (GKPP Alg. 16) */
+    u256 u = *self, v = *m, b = {{1, 0, 0, 0}}, c = {{0, 0, 0, 0}};
+    while (!u256_is_one(&u) && !u256_is_one(&v)) {
+        while ((u.l[0] & 1) == 0) {
+            div2(&u);
+            if ((b.l[0] & 1) == 0) div2(&b); else { add_nocarry(&b, m); div2(&b); }
+        }
+        while ((v.l[0] & 1) == 0) {
+            div2(&v);
+            if ((c.l[0] & 1) == 0) div2(&c); else { add_nocarry(&c, m); div2(&c); }
+        }
+        if (u256_cmp(&u, &v) >= 0) { sub_noborrow(&u, &v); u256_sub(&b, &c, m); }
+        else { sub_noborrow(&v, &u); u256_sub(&c, &b, m); }
+    }
+    *self = u256_is_one(&u) ? b : c;
+}
+static inline int u256_bit(const u256 *a, int n) { return (int)((a->l[n >> 6] >> (n & 63)) & 1); }
+
+/* ---------------------------------------------------------------- Fq (src/fields/fp.rs:9-159,170-177) */
+static inline fq fq_add(fq a, fq b) { u256_add(&a, &b, &FQ_MOD); return a; }
+static inline fq fq_sub(fq a, fq b) { u256_sub(&a, &b, &FQ_MOD); return a; }
+static inline fq fq_mul(fq a, fq b) { u256_mul(&a, &b, &FQ_MOD, FQ_INV); return a; }
+static inline fq fq_neg(fq a) { u256_neg(&a, &FQ_MOD); return a; }
+static inline fq fq_sqr(fq a) { return fq_mul(a, a); }               /* fields/mod.rs:32-34 default */
+static inline fq fq_zero(void) { fq z = {{0, 0, 0, 0}}; return z; }
+static inline int fq_is_zero(fq a) { return u256_is_zero(&a); }
+static inline int fq_eq(fq a, fq b) { return u256_eq(&a, &b); }
+static fq fq_inverse(fq a) {                                         /* fp.rs:103-112 (caller checks zero) */
+    u256_invert(&a, &FQ_MOD);
+    u256_mul(&a, &FQ_R3, &FQ_MOD, FQ_INV);
+    return a;
+}
+static inline u256 fr_to_raw(u256 a) { u256 one = {{1, 0, 0, 0}}; u256_mul(&a, &one, &FR_MOD, FR_INV); return a; }  /* fp.rs:15-22 */
+
+/* ---------------------------------------------------------------- Fq2 (src/fields/fq2.rs) */
+static inline fq2 fq2_add(fq2 a, fq2 b) { fq2 r = {fq_add(a.c0, b.c0), fq_add(a.c1, b.c1)}; return r; }
+static inline fq2 fq2_sub(fq2 a, fq2 b) { fq2 r = {fq_sub(a.c0, b.c0), fq_sub(a.c1, b.c1)}; return r; }
+static inline fq2 fq2_neg(fq2 a) { fq2 r = {fq_neg(a.c0), fq_neg(a.c1)}; return r; }
+static inline fq2 fq2_zero(void) { fq2 r; memset(&r, 0, sizeof r); return r; }
+static inline fq2 fq2_one(void) { fq2 r = {FQ_ONE, {{0, 0, 0, 0}}}; return r; }
+static inline int fq2_is_zero(fq2 a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
+static inline int fq2_eq(fq2 a, fq2 b) { return fq_eq(a.c0, b.c0) && fq_eq(a.c1, b.c1); }
+static fq2 fq2_mul(fq2 a, fq2 b) {                                  /* fq2.rs:139-155 */
+    fq aa = fq_mul(a.c0, b.c0), bb = fq_mul(a.c1, b.c1);
+    fq2 r;
+    r.c0 = fq_add(fq_mul(bb, FQ_NONRES), aa);
+    r.c1 = fq_sub(fq_sub(fq_mul(fq_add(a.c0, a.c1), fq_add(b.c0, b.c1)), aa), bb);
+    return r;
+}
+static fq2 fq2_sqr(fq2 a) {                                         /* fq2.rs:112-123 */
+    fq ab = fq_mul(a.c0, a.c1);
+    fq2 r;
+    r.c0 = fq_sub(fq_sub(fq_mul(fq_add(fq_mul(a.c1, FQ_NONRES), a.c0), fq_add(a.c0, a.c1)), ab), fq_mul(ab, FQ_NONRES));
+    r.c1 = fq_add(ab, ab);
+    return r;
+}
+static inline fq2 fq2_scale(fq2 a, fq k) { fq2 r = {fq_mul(a.c0, k), fq_mul(a.c1, k)}; return r; }   /* fq2.rs:63-68 */
+static inline fq2 fq2_mul_xi(fq2 a) { return fq2_mul(a, XI); }                                        /* fq2.rs:70-72 */
+static inline fq2 fq2_frob(fq2 a, int p) {                                                            /* fq2.rs:74-83 */
+    if (p % 2 == 0) return a;
+    fq2 r = {a.c0, fq_mul(a.c1, FQ_NONRES)};
+    return r;
+}
+static fq2 fq2_inverse(fq2 a) {                                     /* fq2.rs:125-136 (caller checks zero) */
+    fq t = fq_inverse(fq_sub(fq_sqr(a.c0), fq_mul(fq_sqr(a.c1), FQ_NONRES)));
+    fq2 r = {fq_mul(a.c0, t), fq_neg(fq_mul(a.c1, t))};
+    return r;
+}
+
+/* ---------------------------------------------------------------- Fq6 (src/fields/fq6.rs) */
+static inline fq6 fq6_add(fq6 a, fq6 b) { fq6 r = {fq2_add(a.c0, b.c0), fq2_add(a.c1, b.c1), fq2_add(a.c2, b.c2)}; return r; }
+static inline fq6 fq6_sub(fq6 a, fq6 b) { fq6 r = {fq2_sub(a.c0, b.c0), fq2_sub(a.c1, b.c1), fq2_sub(a.c2, b.c2)}; return r; }
+static inline fq6 fq6_neg(fq6 a) { fq6 r = {fq2_neg(a.c0), fq2_neg(a.c1), fq2_neg(a.c2)}; return r; }
+static inline fq6 fq6_zero(void) { fq6 r; memset(&r, 0, sizeof r); return r; }
+static inline fq6 fq6_one(void) { fq6 r = fq6_zero(); r.c0 = fq2_one(); return r; }
+static inline fq6 fq6_mul_by_nonresidue(fq6 a) { fq6 r = {fq2_mul_xi(a.c2), a.c0, a.c1}; return r; }   /* fq6.rs:59-65 */
+static inline fq6 fq6_scale(fq6 a, fq2 k) { fq6 r = {fq2_mul(a.c0, k), fq2_mul(a.c1, k), fq2_mul(a.c2, k)}; return r; }
+static fq6 fq6_mul(fq6 a, fq6 b) {                                   /* fq6.rs:144-158 */
+    fq2 aa = fq2_mul(a.c0, b.c0), bb = fq2_mul(a.c1, b.c1), cc = fq2_mul(a.c2, b.c2);
+    fq6 r;
+    r.c0 = fq2_add(fq2_mul_xi(fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c1, a.c2), fq2_add(b.c1, b.c2)), bb), cc)), aa);
+    r.c1 = fq2_add(fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c0, a.c1), fq2_add(b.c0, b.c1)), aa), bb), fq2_mul_xi(cc));
+    r.c2 = fq2_sub(fq2_add(fq2_sub(fq2_mul(fq2_add(a.c0, a.c2), fq2_add(b.c0, b.c2)), aa), bb), cc);
+    return r;
+}
+static fq6 fq6_sqr(fq6 a) {                                          /* fq6.rs:113-127 */
+    fq2 s0 = fq2_sqr(a.c0), ab = fq2_mul(a.c0, a.c1), s1 = fq2_add(ab, ab);
+    fq2 s2 = fq2_sqr(fq2_add(fq2_sub(a.c0, a.c1), a.c2));
+    fq2 bc = fq2_mul(a.c1, a.c2), s3 = fq2_add(bc, bc), s4 = fq2_sqr(a.c2);
+    fq6 r;
+    r.c0 = fq2_add(s0, fq2_mul_xi(s3));
+    r.c1 = fq2_add(s1, fq2_mul_xi(s4));
+    r.c2 = fq2_sub(fq2_sub(fq2_add(fq2_add(s1, s2), s3), s0), s4);
+    return r;
+}
+static fq6 fq6_frob(fq6 a, int p) {                                  /* fq6.rs:75-81 */
+    fq6 r = {fq2_frob(a.c0, p), fq2_mul(fq2_frob(a.c1, p), FROB6_C1[p % 6]), fq2_mul(fq2_frob(a.c2, p), FROB6_C2[p % 6])};
+    return r;
+}
+static fq6 fq6_inverse(fq6 a) {                                      /* fq6.rs:129-141 */
+    fq2 c0 = fq2_sub(fq2_sqr(a.c0), fq2_mul(a.c1, fq2_mul_xi(a.c2)));
+    fq2 c1 = fq2_sub(fq2_mul_xi(fq2_sqr(a.c2)), fq2_mul(a.c0, a.c1));
+    fq2 c2 = fq2_sub(fq2_sqr(a.c1), fq2_mul(a.c0, a.c2));
+    fq2 t = fq2_inverse(fq2_add(fq2_mul_xi(fq2_add(fq2_mul(a.c2, c1), fq2_mul(a.c1, c2))), fq2_mul(a.c0, c0)));
+    fq6 r = {fq2_mul(t, c0), fq2_mul(t, c1), fq2_mul(t, c2)};
+    return r;
+}
+
+/* ---------------------------------------------------------------- Fq12 (src/fields/fq12.rs) */
+static inline fq12 fq12_one(void) { fq12 r = {fq6_one(), fq6_zero()}; return r; }
+static inline fq12 fq12_add(fq12 a, fq12 b) { fq12 r = {fq6_add(a.c0, b.c0), fq6_add(a.c1, b.c1)}; return r; }
+static inline fq12 fq12_sub(fq12 a, fq12 b) { fq12 r = {fq6_sub(a.c0, b.c0), fq6_sub(a.c1, b.c1)}; return r; }
+static inline fq12 fq12_neg(fq12 a) { fq12 r = {fq6_neg(a.c0), fq6_neg(a.c1)}; return r; }
+static fq12 fq12_mul(fq12 a, fq12 b) {                                /* fq12.rs:295-307 */
+    fq6 aa = fq6_mul(a.c0, b.c0), bb = fq6_mul(a.c1, b.c1);
+    fq12 r;
+    r.c0 = fq6_add(fq6_mul_by_nonresidue(bb), aa);
+    r.c1 = fq6_sub(fq6_sub(fq6_mul(fq6_add(a.c0, a.c1), fq6_add(b.c0, b.c1)), aa), bb);
+    return r;
+}
+static fq12 fq12_sqr(fq12 a) {                                        /* fq12.rs:275-282 */
+    fq6 ab = fq6_mul(a.c0, a.c1);
+    fq12 r;
+    r.c0 = fq6_sub(fq6_sub(fq6_mul(fq6_add(fq6_mul_by_nonresidue(a.c1), a.c0), fq6_add(a.c0, a.c1)), ab), fq6_mul_by_nonresidue(ab));
+    r.c1 = fq6_add(ab, ab);
+    return r;
+}
+static fq12 fq12_inverse(fq12 a) {                                    /* fq12.rs:284-292 */
+    fq6 t = fq6_inverse(fq6_sub(fq6_sqr(a.c0), fq6_mul_by_nonresidue(fq6_sqr(a.c1))));
+    fq12 r = {fq6_mul(a.c0, t), fq6_neg(fq6_mul(a.c1, t))};
+    return r;
+}
+static inline fq12 fq12_unitary_inverse(fq12 a) { fq12 r = {a.c0, fq6_neg(a.c1)}; return r; }   /* fq12.rs:103-105 */
+static fq12 fq12_frob(fq12 a, int p) {                                /* fq12.rs:90-95 */
+    fq12 r = {fq6_frob(a.c0, p), fq6_scale(fq6_frob(a.c1, p), FROB12_C1[p % 12])};
+    return r;
+}
+static fq12 fq12_mul_by_024(fq12 f, fq2 ell_0, fq2 ell_vw, fq2 ell_vv) {   /* fq12.rs:107-176, same op order */
+    fq2 z0 = f.c0.c0, z1 = f.c0.c1, z2 = f.c0.c2, z3 = f.c1.c0, z4 = f.c1.c1, z5 = f.c1.c2;
+    fq2 x0 = ell_0, x2 = ell_vv, x4 = ell_vw;
+    fq2 d0 = fq2_mul(z0, x0), d2 = fq2_mul(z2, x2), d4 = fq2_mul(z4, x4);
+    fq2 t2 = fq2_add(z0, z4), t1 = fq2_add(z0, z2), s0 = fq2_add(fq2_add(z1, z3), z5);
+    fq2 s1 = fq2_mul(z1, x2);
+    fq2 t3 = fq2_add(s1, d4);
+    fq2 t4 = fq2_add(fq2_mul_xi(t3), d0);
+    z0 = t4;
+    t3 = fq2_mul(z5, x4); s1 = fq2_add(s1, t3); t3 = fq2_add(t3, d2);
+    t4 = fq2_mul_xi(t3);
+    t3 = fq2_mul(z1, x0); s1 = fq2_add(s1, t3); t4 = fq2_add(t4, t3);
+    z1 = t4;
+    fq2 t0 = fq2_add(x0, x2);
+    t3 = fq2_sub(fq2_sub(fq2_mul(t1, t0), d0), d2);
+    t4 = fq2_mul(z3, x4); s1 = fq2_add(s1, t4); t3 = fq2_add(t3, t4);
+    t0 = fq2_add(z2, z4);
+    z2 = t3;
+    t1 = fq2_add(x2, x4);
+    t3 = fq2_sub(fq2_sub(fq2_mul(t0, t1), d2), d4);
+    t4 = fq2_mul_xi(t3);
+    t3 = fq2_mul(z3, x0); s1 = fq2_add(s1, t3); t4 = fq2_add(t4, t3);
+    z3 = t4;
+    t3 = fq2_mul(z5, x2); s1 = fq2_add(s1, t3);
+    t4 = fq2_mul_xi(t3);
+    t0 = fq2_add(x0, x4);
+    t3 = fq2_sub(fq2_sub(fq2_mul(t2, t0), d0), d4);
+    t4 = fq2_add(t4, t3);
+    z4 = t4;
+    t0 = fq2_add(fq2_add(x0, x2), x4);
+    t3 = fq2_sub(fq2_mul(s0, t0), s1);
+    z5 = t3;
+    fq12 r = {{z0, z1, z2}, {z3, z4, z5}};
+    return r;
+}
+static inline void cyc_pair(fq2 a, fq2 b, fq2 *t_even, fq2 *t_odd) { /* fq12.rs:186-196 */
+    fq2 tmp = fq2_mul(a, b);
+    *t_even = fq2_sub(fq2_sub(fq2_mul(fq2_add(a, b), fq2_add(fq2_mul_xi(b), a)), tmp), fq2_mul_xi(tmp));
+    *t_odd = fq2_add(tmp, tmp);
+}
+static fq12 fq12_cyclotomic_squared(fq12 a) {                         /* fq12.rs:178-227 */
+    fq2 z0 = a.c0.c0, z4 = a.c0.c1, z3 = a.c0.c2, z2 = a.c1.c0, z1 = a.c1.c1, z5 = a.c1.c2;
+    fq2 t0, t1, t2, t3, t4, t5, tmp;
+    cyc_pair(z0, z1, &t0, &t1); cyc_pair(z2, z3, &t2, &t3); cyc_pair(z4, z5, &t4, &t5);
+    z0 = fq2_sub(t0, z0); z0 = fq2_add(z0, z0); z0 = fq2_add(z0, t0);
+    z1 = fq2_add(t1, z1); z1 = fq2_add(z1, z1); z1 = fq2_add(z1, t1);
+    tmp = fq2_mul_xi(t5);
+    z2 = fq2_add(tmp, z2); z2 = fq2_add(z2, z2); z2 = fq2_add(z2, tmp);
+    z3 = fq2_sub(t4, z3); z3 = fq2_add(z3, z3); z3 = fq2_add(z3, t4);
+    z4 = fq2_sub(t2, z4); z4 = fq2_add(z4, z4); z4 = fq2_add(z4, t2);
+    z5 = fq2_add(t3, z5); z5 = fq2_add(z5, z5); z5 = fq2_add(z5, t3);
+    fq12 r = {{z0, z4, z3}, {z2, z1, z5}};
+    return r;
+}
+static fq12 fq12_cyclotomic_pow(fq12 a, const u256 *by) {             /* fq12.rs:229-246 */
+    fq12 res = fq12_one();
+    int found = 0;
+    for (int n = 255; n >= 0; --n) {
+        if (found) res = fq12_cyclotomic_squared(res);
+        if (u256_bit(by, n)) { found = 1; res = fq12_mul(a, res); }
+    }
+    return res;
+}
+static fq12 fq12_exp_by_neg_z(fq12 a) { return fq12_unitary_inverse(fq12_cyclotomic_pow(a, &BN_U)); }  /* fq12.rs:97-101 */
+static fq12 fq12_pow(fq12 a, const u256 *by) {                        /* fields/mod.rs:35-46 */
+    fq12 res = fq12_one();
+    for (int n = 255; n >= 0; --n) {
+        res = fq12_sqr(res);
+        if (u256_bit(by, n)) res = fq12_mul(a, res);
+    }
+    return res;
+}
+static fq12 final_exp_first_chunk(fq12 f) {                           /* fq12.rs:41-52 */
+    fq12 b = fq12_inverse(f), a = fq12_unitary_inverse(f);
+    fq12 c = fq12_mul(a, b), d = fq12_frob(c, 2);
+    return fq12_mul(d, c);
+}
+static fq12 final_exp_last_chunk(fq12 s) {                            /* fq12.rs:54-84 */
+    fq12 a = fq12_exp_by_neg_z(s), b = fq12_cyclotomic_squared(a), c = fq12_cyclotomic_squared(b), d = fq12_mul(c, b);
+    fq12 e = fq12_exp_by_neg_z(d), f = fq12_cyclotomic_squared(e), g = fq12_exp_by_neg_z(f);
+    fq12 h = fq12_unitary_inverse(d), i = fq12_unitary_inverse(g);
+    fq12 j = fq12_mul(i, e), k = fq12_mul(j, h), l = fq12_mul(k, b), m = fq12_mul(k, e), n = fq12_mul(s, m);
+    fq12 o = fq12_frob(l, 1), p = fq12_mul(o, n);
+    fq12 q = fq12_frob(k, 2), r = fq12_mul(q, p);
+    fq12 ss = fq12_unitary_inverse(s), t = fq12_mul(ss, l), u = fq12_frob(t, 3);
+    return fq12_mul(u, r);
+}
+static fq12 fq12_final_exponentiation(fq12 f) { return final_exp_last_chunk(final_exp_first_chunk(f)); }  /* fq12.rs:86-88 */
+
+/* ---------------------------------------------------------------- groups (src/groups/mod.rs:113-347), one body per base field */
+#define DEFINE_GROUP(G, F, AFF, F_ADD, F_SUB, F_MUL, F_SQR, F_NEG, F_INV, F_ISZERO, F_EQ, F_ZERO, F_ONE)               \
+static G G##_zero(void) { G r = {F_ZERO, F_ONE, F_ZERO}; return r; }                 /* :208-214 */                     \
+static int G##_is_zero(G p) { return F_ISZERO(p.z); }                                                                   \
+static G G##_double(G p) {                                                           /* :228-247 */                     \
+    F a = F_SQR(p.x), b = F_SQR(p.y), c = F_SQR(b);                                                                     \
+    F d = F_SUB(F_SUB(F_SQR(F_ADD(p.x, b)), a), c); d = F_ADD(d, d);                                                    \
+    F e = F_ADD(F_ADD(a, a), a), f = F_SQR(e);                                                                          \
+    F x3 = F_SUB(f, F_ADD(d, d));                                                                                       \
+    F c8 = F_ADD(c, c); c8 = F_ADD(c8, c8); c8 = F_ADD(c8, c8);                                                         \
+    F yz = F_MUL(p.y, p.z);                                                                                             \
+    G r = {x3, F_SUB(F_MUL(e, F_SUB(d, x3)), c8), F_ADD(yz, yz)};                                                       \
+    return r;                                                                                                           \
+}                                                                                                                       \
+static G G##_add(G p, G q) {                                                         /* :275-311 */                     \
+    if (G##_is_zero(p)) return q;                                                                                       \
+    if (G##_is_zero(q)) return p;                                                                                       \
+    F z1s = F_SQR(p.z), z2s = F_SQR(q.z);                                                                               \
+    F u1 = F_MUL(p.x, z2s), u2 = F_MUL(q.x, z1s);                                                                       \
+    F z1c = F_MUL(p.z, z1s), z2c = F_MUL(q.z, z2s);                                                                     \
+    F s1 = F_MUL(p.y, z2c), s2 = F_MUL(q.y, z1c);                                                                       \
+    if (F_EQ(u1, u2) && F_EQ(s1, s2)) return G##_double(p);                                                             \
+    F h = F_SUB(u2, u1), sd = F_SUB(s2, s1);                                                                            \
+    F i = F_SQR(F_ADD(h, h)), j = F_MUL(h, i), r_ = F_ADD(sd, sd), v = F_MUL(u1, i), s1j = F_MUL(s1, j);                \
+    F x3 = F_SUB(F_SUB(F_SQR(r_), j), F_ADD(v, v));                                                                     \
+    G r = {x3, F_SUB(F_MUL(r_, F_SUB(v, x3)), F_ADD(s1j, s1j)),                                                         \
+           F_MUL(F_SUB(F_SUB(F_SQR(F_ADD(p.z, q.z)), z1s), z2s), h)};                                                   \
+    return r;                                                                                                           \
+}                                                                                                                       \
+static G G##_neg(G p) { if (!G##_is_zero(p)) p.y = F_NEG(p.y); return p; }           /* :313-327 */                     \
+static G G##_mul(G p, u256 fr_mont) {                                                /* :250-270 */                     \
+    u256 k = fr_to_raw(fr_mont);                                                                                        \
+    G res = G##_zero(); int found = 0;                                                                                  \
+    for (int n = 255; n >= 0; --n) {                                                                                    \
+        if (found) res = G##_double(res);                                                                               \
+        if (u256_bit(&k, n)) { found = 1; res = G##_add(res, p); }                                                      \
+    }                                                                                                                   \
+    return res;                                                                                                         \
+}                                                                                                                       \
+static int G##_to_affine(G p, AFF *out) {                                            /* :113-130 */                     \
+    if (F_ISZERO(p.z)) return 0;                                                                                        \
+    if (F_EQ(p.z, F_ONE)) { out->x = p.x; out->y = p.y; return 1; }                                                     \
+    F zi = F_INV(p.z), zi2 = F_SQR(zi);                                                                                 \
+    out->x = F_MUL(p.x, zi2); out->y = F_MUL(p.y, F_MUL(zi2, zi));                                                      \
+    return 1;                                                                                                           \
+}                                                                                                                       \
+static G G##_normalize(G p) {                                                        /* lib.rs:88-95 */                 \
+    AFF a; if (!G##_to_affine(p, &a)) return p;                                                                         \
+    G r = {a.x, a.y, F_ONE}; return r;                                                                                  \
+}                                                                                                                       \
+static int G##_eq(G p, G q) {                                                        /* :83-109 */                      \
+    if (G##_is_zero(p)) return G##_is_zero(q);                                                                          \
+    if (G##_is_zero(q)) return 0;                                                                                       \
+    F z1s = F_SQR(p.z), z2s = F_SQR(q.z);                                                                               \
+    if (!F_EQ(F_MUL(p.x, z2s), F_MUL(q.x, z1s))) return 0;                                                              \
+    return F_EQ(F_MUL(p.y, F_MUL(q.z, z2s)), F_MUL(q.y, F_MUL(p.z, z1s)));                                              \
+}
+
+#define FQ_ZERO_V fq_zero()
+#define FQ_ONE_V FQ_ONE
+DEFINE_GROUP(g1, fq, g1aff, fq_add, fq_sub, fq_mul, fq_sqr, fq_neg, fq_inverse, fq_is_zero, fq_eq, FQ_ZERO_V, FQ_ONE_V)
+#define FQ2_ZERO_V fq2_zero()
+#define FQ2_ONE_V fq2_one()
+DEFINE_GROUP(g2, fq2, g2aff, fq2_add, fq2_sub, fq2_mul, fq2_sqr, fq2_neg, fq2_inverse, fq2_is_zero, fq2_eq, FQ2_ZERO_V, FQ2_ONE_V)
+
+/* ---------------------------------------------------------------- pairing (src/groups/mod.rs:472-635, 764-771) */
+static ellc doubling_step(g2 *r) {                                    /* :612-634 */
+    fq2 a = fq2_scale(fq2_mul(r->x, r->y), TWO_INV);
+    fq2 b = fq2_sqr(r->y), c = fq2_sqr(r->z);
+    fq2 d = fq2_add(fq2_add(c, c), c);
+    fq2 e = fq2_mul(G2_COEFF_B, d);
+    fq2 f = fq2_add(fq2_add(e, e), e);
+    fq2 g = fq2_scale(fq2_add(b, f), TWO_INV);
+    fq2 h = fq2_sub(fq2_sqr(fq2_add(r->y, r->z)), fq2_add(b, c));
+    fq2 i = fq2_sub(e, b);
+    fq2 j = fq2_sqr(r->x);
+    fq2 e_sq = fq2_sqr(e);
+    r->x = fq2_mul(a, fq2_sub(b, f));
+    r->y = fq2_sub(fq2_sqr(g), fq2_add(fq2_add(e_sq, e_sq), e_sq));
+    r->z = fq2_mul(b, h);
+    ellc out = {fq2_mul(XI, i), fq2_neg(h), fq2_add(fq2_add(j, j), j)};
+    return out;
+}
+static ellc addition_step(g2 *r, const g2aff *base) {                 /* :592-610 */
+    fq2 d = fq2_sub(r->x, fq2_mul(r->z, base->x));
+    fq2 e = fq2_sub(r->y, fq2_mul(r->z, base->y));
+    fq2 f = fq2_sqr(d), g = fq2_sqr(e);
+    fq2 h = fq2_mul(d, f), i = fq2_mul(r->x, f);
+    fq2 j = fq2_sub(fq2_add(fq2_mul(r->z, g), h), fq2_add(i, i));
+    r->x = fq2_mul(d, j);
+    r->y = fq2_sub(fq2_mul(e, fq2_sub(i, j)), fq2_mul(h, r->y));
+    r->z = fq2_mul(r->z, h);
+    ellc out = {fq2_mul(XI, fq2_sub(fq2_mul(e, base->x), fq2_mul(d, base->y))), d, fq2_neg(e)};
+    return out;
+}
+static g2aff mul_by_q(const g2aff *a) {                               /* :550-555 */
+    g2aff r = {fq2_mul(TWIST_MUL_BY_Q_X, fq2_frob(a->x, 1)), fq2_mul(TWIST_MUL_BY_Q_Y, fq2_frob(a->y, 1))};
+    return r;
+}
+#define NCOEFF 102
+static int precompute(const g2aff *q, ellc *coeffs) {                 /* :557-588 */
+    g2 r = {q->x, q->y, fq2_one()};
+    int n = 0, found = 0;
+    for (int b = 255; b >= 0; --b) {
+        int bit = u256_bit(&ATE_LOOP_COUNT, b);
+        if (!found) { found = bit; continue; }
+        coeffs[n++] = doubling_step(&r);
+        if (bit) coeffs[n++] = addition_step(&r, q);
+    }
+    g2aff q1 = mul_by_q(q), q2 = mul_by_q(&q1);
+    q2.y = fq2_neg(q2.y);
+    coeffs[n++] = addition_step(&r, &q1);
+    coeffs[n++] = addition_step(&r, &q2);
+    return n;
+}
+static fq12 miller_loop(const ellc *coeffs, const g1aff *p) {         /* :486-519 */
+    fq12 f = fq12_one();
+    int idx = 0, found = 0;
+    for (int b = 255; b >= 0; --b) {
+        int bit = u256_bit(&ATE_LOOP_COUNT, b);
+        if (!found) { found = bit; continue; }
+        const ellc *c = &coeffs[idx++];
+        f = fq12_mul_by_024(fq12_sqr(f), c->ell_0, fq2_scale(c->ell_vw, p->y), fq2_scale(c->ell_vv, p->x));
+        if (bit) {
+            c = &coeffs[idx++];
+            f = fq12_mul_by_024(f, c->ell_0, fq2_scale(c->ell_vw, p->y), fq2_scale(c->ell_vv, p->x));
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        const ellc *c = &coeffs[idx++];
+        f = fq12_mul_by_024(f, c->ell_0, fq2_scale(c->ell_vw, p->y), fq2_scale(c->ell_vv, p->x));
+    }
+    return f;
+}
+static fq12 pairing(const g1 *p, const g2 *q) {                       /* :764-771 */
+    g1aff pa; g2aff qa;
+    if (!g1_to_affine(*p, &pa) || !g2_to_affine(*q, &qa)) return fq12_one();
+    ellc coeffs[NCOEFF];
+    precompute(&qa, coeffs);
+    return fq12_final_exponentiation(miller_loop(coeffs, &pa));
+}
+
+/* ================================================================ exported C surface (used through ctypes) */
+EXPORT int bno_native128(void) {
+#ifdef BNO_NATIVE128
+    return 1;
+#else
+    return 0;
+#endif
+}
+/* field: which = 0 -> Fq, 1 -> Fr */
+static const u256 *modof(int w) { return w ? &FR_MOD : &FQ_MOD; }
+static u64 invof(int w) { return w ? FR_INV : FQ_INV; }
+EXPORT int bno_fp_from_raw(int w, const u64 *raw, u64 *out) {         /* fp.rs:62-70 ; 0 on raw >= modulus */
+    u256 a; memcpy(&a, raw, 32);
+    if (u256_cmp(&a, modof(w)) >= 0) return 0;
+    u256_mul(&a, w ? &FR_R2 : &FQ_R2, modof(w), invof(w));
+    memcpy(out, &a, 32); return 1;
+}
+EXPORT void bno_fp_to_raw(int w, const u64 *mont, u64 *out) {         /* fp.rs:15-22 */
+    u256 a, one = {{1, 0, 0, 0}}; memcpy(&a, mont, 32);
+    u256_mul(&a, &one, modof(w), invof(w)); memcpy(out, &a, 32);
+}
+EXPORT void bno_fp_add(int w, const u64 *a, const u64 *b, u64 *o) { u256 x, y; memcpy(&x, a, 32); memcpy(&y, b, 32); u256_add(&x, &y, modof(w)); memcpy(o, &x, 32); }
+EXPORT void bno_fp_sub(int w, const u64 *a, const u64 *b, u64 *o) { u256 x, y; memcpy(&x, a, 32); memcpy(&y, b, 32); u256_sub(&x, &y, modof(w)); memcpy(o, &x, 32); }
+EXPORT void bno_fp_mul(int w, const u64 *a, const u64 *b, u64 *o) { u256 x, y; memcpy(&x, a, 32); memcpy(&y, b, 32); u256_mul(&x, &y, modof(w), invof(w)); memcpy(o, &x, 32); }
+EXPORT void bno_fp_neg(int w, const u64 *a, u64 *o) { u256 x; memcpy(&x, a, 32); u256_neg(&x, modof(w)); memcpy(o, &x, 32); }
+EXPORT int bno_fp_inverse(int w, const u64 *a, u64 *o) {              /* fp.rs:103-112 ; 0 = None */
+    u256 x; memcpy(&x, a, 32);
+    if (u256_is_zero(&x)) return 0;
+    u256_invert(&x, modof(w)); u256_mul(&x, w ? &FR_R3 : &FQ_R3, modof(w), invof(w));
+    memcpy(o, &x, 32); return 1;
+}
+EXPORT int bno_fp_from_decimal(int w, const char *s, u64 *out) {      /* fp.rs:39-59 ; 0 = None */
+    u256 ints[11], acc = {{0, 0, 0, 0}}, one = w ? FR_ONE : FQ_ONE;
+    for (int i = 0; i < 11; ++i) { ints[i] = acc; u256_add(&acc, &one, modof(w)); }
+    u256 res = {{0, 0, 0, 0}};
+    for (; *s; ++s) {
+        if (*s < '0' || *s > '9') return 0;
+        u256_mul(&res, &ints[10], modof(w), invof(w));
+        u256_add(&res, &ints[*s - '0'], modof(w));
+    }
+    memcpy(out, &res, 32); return 1;
+}
+#define LD(T, v, p) T v; memcpy(&v, p, sizeof(T))
+#define ST(p, v) memcpy(p, &v, sizeof(v))
+EXPORT void bno_fq2_mul(const u64 *a, const u64 *b, u64 *o) { LD(fq2, x, a); LD(fq2, y, b); fq2 r = fq2_mul(x, y); ST(o, r); }
+EXPORT void bno_fq2_sqr(const u64 *a, u64 *o) { LD(fq2, x, a); fq2 r = fq2_sqr(x); ST(o, r); }
+EXPORT void bno_fq2_inverse(const u64 *a, u64 *o) { LD(fq2, x, a); fq2 r = fq2_inverse(x); ST(o, r); }
+EXPORT void bno_fq2_mul_xi(const u64 *a, u64 *o) { LD(fq2, x, a); fq2 r = fq2_mul_xi(x); ST(o, r); }
+EXPORT void bno_fq6_mul(const u64 *a, const u64 *b, u64 *o) { LD(fq6, x, a); LD(fq6, y, b); fq6 r = fq6_mul(x, y); ST(o, r); }
+EXPORT void bno_fq6_sqr(const u64 *a, u64 *o) { LD(fq6, x, a); fq6 r = fq6_sqr(x); ST(o, r); }
+EXPORT void bno_fq6_inverse(const u64 *a, u64 *o) { LD(fq6, x, a); fq6 r = fq6_inverse(x); ST(o, r); }
+EXPORT void bno_fq12_mul(const u64 *a, const u64 *b, u64 *o) { LD(fq12, x, a); LD(fq12, y, b); fq12 r = fq12_mul(x, y); ST(o, r); }
+EXPORT void bno_fq12_sqr(const u64 *a, u64 *o) { LD(fq12, x, a); fq12 r = fq12_sqr(x); ST(o, r); }
+EXPORT void bno_fq12_add(const u64 *a, const u64 *b, u64 *o) { LD(fq12, x, a); LD(fq12, y, b); fq12 r = fq12_add(x, y); ST(o, r); }
+EXPORT void bno_fq12_sub(const u64 *a, const u64 *b, u64 *o) { LD(fq12, x, a); LD(fq12, y, b); fq12 r = fq12_sub(x, y); ST(o, r); }
+EXPORT void bno_fq12_neg(const u64 *a, u64 *o) { LD(fq12, x, a); fq12 r = fq12_neg(x); ST(o, r); }
+EXPORT void bno_fq12_inverse(const u64 *a, u64 *o) { LD(fq12, x, a); fq12 r = fq12_inverse(x); ST(o, r); }
+EXPORT void bno_fq12_unitary_inverse(const u64 *a, u64 *o) { LD(fq12, x, a); fq12 r = fq12_unitary_inverse(x); ST(o, r); }
+EXPORT void bno_fq12_frobenius_map(const u64 *a, int p, u64 *o) { LD(fq12, x, a); fq12 r = fq12_frob(x, p); ST(o, r); }
+EXPORT void bno_fq12_cyclotomic_squared(const u64 *a, u64 *o) { LD(fq12, x, a); fq12 r = fq12_cyclotomic_squared(x); ST(o, r); }
+EXPORT void bno_fq12_exp_by_neg_z(const u64 *a, u64 *o) { LD(fq12, x, a); fq12 r = fq12_exp_by_neg_z(x); ST(o, r); }
+EXPORT void bno_fq12_mul_by_024(const u64 *f, const u64 *l0, const u64 *lvw, const u64 *lvv, u64 *o) {
+    LD(fq12, x, f); LD(fq2, a, l0); LD(fq2, b, lvw); LD(fq2, c, lvv); fq12 r = fq12_mul_by_024(x, a, b, c); ST(o, r);
+}
+EXPORT void bno_fq12_final_exponentiation(const u64 *a, u64 *o) { LD(fq12, x, a); fq12 r = fq12_final_exponentiation(x); ST(o, r); }
+EXPORT void bno_fq12_final_exp_first_chunk(const u64 *a, u64 *o) { LD(fq12, x, a); fq12 r = final_exp_first_chunk(x); ST(o, r); }
+EXPORT void bno_gt_pow(const u64 *a, const u64 *fr_mont, u64 *o) {    /* lib.rs:171 */
+    LD(fq12, x, a); LD(u256, k, fr_mont); u256 raw = fr_to_raw(k); fq12 r = fq12_pow(x, &raw); ST(o, r);
+}
+EXPORT void bno_fq12_one(u64 *o) { fq12 r = fq12_one(); ST(o, r); }
+
+EXPORT void bno_g1_one(u64 *o) { ST(o, G1_GEN); }
+EXPORT void bno_g2_one(u64 *o) { ST(o, G2_GEN); }
+EXPORT void bno_g1_zero(u64 *o) { g1 r = g1_zero(); ST(o, r); }
+EXPORT void bno_g2_zero(u64 *o) { g2 r = g2_zero(); ST(o, r); }
+EXPORT void bno_g1_add(const u64 *a, const u64 *b, u64 *o) { LD(g1, x, a); LD(g1, y, b); g1 r = g1_add(x, y); ST(o, r); }
+EXPORT void bno_g2_add(const u64 *a, const u64 *b, u64 *o) { LD(g2, x, a); LD(g2, y, b); g2 r = g2_add(x, y); ST(o, r); }
+EXPORT void bno_g1_double(const u64 *a, u64 *o) { LD(g1, x, a); g1 r = g1_double(x); ST(o, r); }
+EXPORT void bno_g2_double(const u64 *a, u64 *o) { LD(g2, x, a); g2 r = g2_double(x); ST(o, r); }
+EXPORT void bno_g1_neg(const u64 *a, u64 *o) { LD(g1, x, a); g1 r = g1_neg(x); ST(o, r); }
+EXPORT void bno_g2_neg(const u64 *a, u64 *o) { LD(g2, x, a); g2 r = g2_neg(x); ST(o, r); }
+EXPORT void bno_g1_mul(const u64 *a, const u64 *fr, u64 *o) { LD(g1, x, a); LD(u256, k, fr); g1 r = g1_mul(x, k); ST(o, r); }
+EXPORT void bno_g2_mul(const u64 *a, const u64 *fr, u64 *o) { LD(g2, x, a); LD(u256, k, fr); g2 r = g2_mul(x, k); ST(o, r); }
+EXPORT void bno_g1_normalize(const u64 *a, u64 *o) { LD(g1, x, a); g1 r = g1_normalize(x); ST(o, r); }
+EXPORT void bno_g2_normalize(const u64 *a, u64 *o) { LD(g2, x, a); g2 r = g2_normalize(x); ST(o, r); }
+EXPORT int bno_g1_eq(const u64 *a, const u64 *b) { LD(g1, x, a); LD(g1, y, b); return g1_eq(x, y); }
+EXPORT int bno_g2_eq(const u64 *a, const u64 *b) { LD(g2, x, a); LD(g2, y, b); return g2_eq(x, y); }
+EXPORT int bno_g1_to_affine(const u64 *a, u64 *o) { LD(g1, x, a); g1aff r; if (!g1_to_affine(x, &r)) return 0; ST(o, r); return 1; }
+EXPORT int bno_g2_to_affine(const u64 *a, u64 *o) { LD(g2, x, a); g2aff r; if (!g2_to_affine(x, &r)) return 0; ST(o, r); return 1; }
+
+/* q_affine: Fq2 x, Fq2 y (16 u64) -> 102 x (ell_0, ell_vw, ell_vv) (102*24 u64); returns the count */
+EXPORT int bno_g2_precompute(const u64 *q_affine, u64 *coeffs_out) {
+    LD(g2aff, q, q_affine); ellc c[NCOEFF]; int n = precompute(&q, c); memcpy(coeffs_out, c, sizeof c); return n;
+}
+EXPORT void bno_miller_loop(const u64 *coeffs, const u64 *p_affine, u64 *o) {
+    ellc c[NCOEFF]; memcpy(c, coeffs, sizeof c); LD(g1aff, p, p_affine); fq12 r = miller_loop(c, &p); ST(o, r);
+}
+/* un-exponentiated Miller value of pairing(p,q); infinity -> one (used by the product-path checks) */
+EXPORT void bno_miller_only(const u64 *p, const u64 *q, u64 *o) {
+    LD(g1, x, p); LD(g2, y, q); g1aff pa; g2aff qa; fq12 r;
+    if (!g1_to_affine(x, &pa) || !g2_to_affine(y, &qa)) r = fq12_one();
+    else { ellc c[NCOEFF]; precompute(&qa, c); r = miller_loop(c, &pa); }
+    ST(o, r);
+}
+EXPORT void bno_pairing(const u64 *p, const u64 *q, u64 *o) { LD(g1, x, p); LD(g2, y, q); fq12 r = pairing(&x, &y); ST(o, r); }
+
+/* ---- batch drivers (pthread; independent units) */
+typedef struct { int kind; const u64 *a, *b; u64 *o; size_t lo, hi; } job;
+static void *worker(void *arg) {
+    job *j = (job *)arg;
+    for (size_t i = j->lo; i < j->hi; ++i) {
+        if (j->kind == 0) bno_pairing(j->a + 12 * i, j->b + 24 * i, j->o + 48 * i);
+        else if (j->kind == 1) { LD(g1, x, j->a + 12 * i); LD(u256, k, j->b + 4 * i); g1 r = g1_normalize(g1_mul(x, k)); ST(j->o + 12 * i, r); }
+        else if (j->kind == 2) { LD(g2, x, j->a + 24 * i); LD(u256, k, j->b + 4 * i); g2 r = g2_normalize(g2_mul(x, k)); ST(j->o + 24 * i, r); }
+        else if (j->kind == 3) { LD(g1, x, j->a + 12 * i); LD(u256, k, j->b + 4 * i); g1 r = g1_mul(x, k); ST(j->o + 12 * i, r); }
+        else if (j->kind == 4) { LD(g2, x, j->a + 24 * i); LD(u256, k, j->b + 4 * i); g2 r = g2_mul(x, k); ST(j->o + 24 * i, r); }
+    }
+    return 0;
+}
+static void run_jobs(int kind, const u64 *a, const u64 *b, u64 *o, size_t n, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    job *jb = (job *)malloc(sizeof(job) * nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        job j = {kind, a, b, o, n * t / nthreads, n * (t + 1) / nthreads};
+        jb[t] = j;
+        if (nthreads == 1) worker(&jb[t]); else pthread_create(&th[t], 0, worker, &jb[t]);
+    }
+    if (nthreads > 1) for (int t = 0; t < nthreads; ++t) pthread_join(th[t], 0);
+    free(th); free(jb);
+}
+EXPORT void bno_pairing_batch(const u64 *p, const u64 *q, u64 *out, size_t n, int nthreads) { run_jobs(0, p, q, out, n, nthreads); }
+/* out[i] = normalize(p[i] * k[i])  (affine image, the parity definition for scalar muls) */
+EXPORT void bno_g1_mul_batch(const u64 *p, const u64 *k, u64 *out, size_t n, int nthreads) { run_jobs(1, p, k, out, n, nthreads); }
+EXPORT void bno_g2_mul_batch(const u64 *p, const u64 *k, u64 *out, size_t n, int nthreads) { run_jobs(2, p, k, out, n, nthreads); }
+/* raw Jacobian result of the reference's double-and-add (what G::random produces) */
+EXPORT void bno_g1_mul_batch_jacobian(const u64 *p, const u64 *k, u64 *out, size_t n, int nthreads) { run_jobs(3, p, k, out, n, nthreads); }
+EXPORT void bno_g2_mul_batch_jacobian(const u64 *p, const u64 *k, u64 *out, size_t n, int nthreads) { run_jobs(4, p, k, out, n, nthreads); }
+/* fold(Gt::one(), acc * pairing(p,q))  (shootout/main.rs:11-16) */
+EXPORT void bno_pairing_product(const u64 *p, const u64 *q, size_t n, u64 *out) {
+    fq12 acc = fq12_one();
+    for (size_t i = 0; i < n; ++i) { LD(g1, x, p + 12 * i); LD(g2, y, q + 24 * i); acc = fq12_mul(acc, pairing(&x, &y)); }
+    ST(out, acc);
+}

@@ -1,0 +1,140 @@
+"""Pins the CPU oracle (oracle/bn_oracle.c + oracle/bn_model.py) to every known-answer test the reference holds
+for the pairing path.  Vectors: tests/golden/reference_kats.json (made by make_kats.py)."""
+import numpy as np
+import pytest
+
+import bn_model as M
+from bn_oracle import FQ, FR
+
+I = lambda l: [int(x) for x in l]
+
+
+def test_str_minus_one(oracle, kats):                         # fields/mod.rs:67-71
+    k = kats["test_str"]
+    for w, key, one in ((FR, "minus_one_fr", M.R_ORD), (FQ, "minus_one_fq", M.Q)):
+        m1 = oracle.fp_neg(w, oracle.fp_from_int(w, 1))
+        assert np.array_equal(m1, oracle.fp_from_decimal(w, k[key]))
+        assert oracle.fp_to_int(w, m1) == int(k[key]) == one - 1
+    assert oracle.fp_from_decimal(FQ, "12x") is None
+
+
+def test_fq12_test_vector(oracle, kats):                      # fields/mod.rs:83-169
+    k = kats["fq12_test_vector"]
+    start = oracle.fq12_from_ints(k["start"]); nxt = start.copy()
+    for _ in range(100):
+        nxt = oracle.fq12_mul(nxt, start)
+    cpy = nxt.copy()
+    for _ in range(10):
+        nxt = oracle.fq12_sqr(nxt)
+    for _ in range(10):
+        nxt = oracle.fq12_neg(oracle.fq12_sub(oracle.fq12_add(nxt, start), cpy))
+    nxt = oracle.fq12_sqr(nxt)
+    assert oracle.fq12_to_ints(nxt) == I(k["finally"])
+
+
+def test_cyclotomic_exp(oracle, kats):                        # fields/mod.rs:171-201
+    k = kats["test_cyclotomic_exp"]
+    e = oracle.fq12_exp_by_neg_z(oracle.fq12_from_ints(k["orig"]))
+    assert oracle.fq12_to_ints(e) == I(k["expected"])
+
+
+@pytest.fixture(scope="module")
+def kat_points(oracle, kats):
+    k1 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k1"])
+    k2 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k2"])
+    return oracle.g1_mul(oracle.g1_one(), k1), oracle.g2_mul(oracle.g2_one(), k2)
+
+
+def test_prepared_g2(oracle, kats, kat_points):               # groups/mod.rs:637-762
+    k = kats["test_prepared_g2"]
+    assert k["k2"] == kats["test_miller_loop"]["k2"]
+    qa = oracle.g2_to_affine(kat_points[1])
+    assert [oracle.fp_to_int(FQ, qa[4 * i:4 * i + 4]) for i in range(4)] == I(k["q_x"]) + I(k["q_y"])
+    co = oracle.g2_precompute(qa)
+    assert co.shape[0] == 102 == len(k["coeffs"])
+    for got, exp in zip(co, k["coeffs"]):
+        for slot, name in enumerate(("ell_0", "ell_vw", "ell_vv")):
+            assert [oracle.fp_to_int(FQ, got[slot][4 * i:4 * i + 4]) for i in range(2)] == I(exp[name])
+
+
+def test_miller_loop(oracle, kats, kat_points):               # groups/mod.rs:522-547
+    pa = oracle.g1_to_affine(kat_points[0]); qa = oracle.g2_to_affine(kat_points[1])
+    f = oracle.miller_loop(oracle.g2_precompute(qa), pa)
+    assert oracle.fq12_to_ints(f) == I(kats["test_miller_loop"]["expected"])
+    assert np.array_equal(f, oracle.miller_only(*kat_points))
+
+
+def test_reduced_pairing(oracle, kats, kat_points):           # groups/mod.rs:773-796
+    gt = oracle.pairing(*kat_points)
+    assert oracle.fq12_to_ints(gt) == I(kats["test_reduced_pairing"]["expected"])
+    # SURVEY section 4 fingerprint of the Montgomery image of c0.c0.c0
+    assert sum(int(x) << (64 * i) for i, x in enumerate(gt[:4])) == 0x014e727beeb7c2bac118b2739cd7f11252d72437f8386b954905a354b64680e4
+    assert np.array_equal(oracle.fq12_final_exponentiation(oracle.miller_only(*kat_points)), gt)
+
+
+def test_native128_variant_identical(kats, kat_points):
+    import bn_oracle
+    o2 = bn_oracle.Oracle(native128=True)
+    assert o2.native128
+    assert o2.fq12_to_ints(o2.pairing(*kat_points)) == I(kats["test_reduced_pairing"]["expected"])
+
+
+# ---------------------------------------------------------------- derived constants == reference literals
+def _m(v):
+    return M.to_mont_limbs(v)
+
+
+def test_constants_match_reference_literals(ref_consts):
+    c = ref_consts
+    for name, mod in (("Fq", M.Q), ("Fr", M.R_ORD)):
+        f = c[name]
+        raw = lambda v: [(v >> (64 * i)) & (2**64 - 1) for i in range(4)]
+        assert f["modulus"] == raw(mod)
+        assert f["rsquared"] == raw(M.MONT_R**2 % mod) and f["rcubed"] == raw(M.MONT_R**3 % mod)
+        assert f["one"] == raw(M.MONT_R % mod) and f["inv"] == (-pow(mod, -1, 2**64)) % 2**64
+    assert c["fq_non_residue"] == _m(M.Q - 1)
+    assert c["fq2_nonresidue"] == [_m(9), _m(1)]
+    for key, tab in (("fq6_frobenius_coeffs_c1", M.FROB6_C1), ("fq6_frobenius_coeffs_c2", M.FROB6_C2),
+                     ("fq12_frobenius_coeffs_c1", M.FROB12_C1)):
+        assert tab[0] == (1, 0)
+        for p in (1, 2, 3):
+            lit = c[key][str(p)]
+            assert lit[0] == _m(tab[p][0])
+            if len(lit) == 2:
+                assert lit[1] == _m(tab[p][1])
+            else:
+                assert tab[p][1] == 0                      # written as Fq::zero() in the reference
+    assert c["g1_one_y"] == _m(2) and c["g1_coeff_b"] == _m(3)
+    gx, gy, _ = M.G2_ONE
+    assert c["g2_one_xy"] == [_m(gx[0]), _m(gx[1]), _m(gy[0]), _m(gy[1])]
+    assert c["g2_coeff_b"] == [_m(M.G2_B[0]), _m(M.G2_B[1])]
+    assert c["two_inv"] == _m(M.TWO_INV)
+    assert c["ate_loop_count"] == [M.ATE_LOOP_COUNT & (2**64 - 1), M.ATE_LOOP_COUNT >> 64, 0, 0]
+    assert c["twist_mul_by_q_x"] == [_m(M.TWIST_MUL_BY_Q_X[0]), _m(M.TWIST_MUL_BY_Q_X[1])]
+    assert c["twist_mul_by_q_y"] == [_m(M.TWIST_MUL_BY_Q_Y[0]), _m(M.TWIST_MUL_BY_Q_Y[1])]
+    assert c["exp_by_neg_z_u"] == [M.U, 0, 0, 0]
+    # the G2 generator is on the twist and has order r
+    y2 = M.f2_sqr(gy); x3b = M.f2_add(M.f2_mul(M.f2_sqr(gx), gx), M.G2_B)
+    assert y2 == x3b
+    assert M.g_is_zero(M.FQ2_OPS, M.g_mul(M.FQ2_OPS, M.G2_ONE, M.R_ORD))
+
+
+# ---------------------------------------------------------------- big-int model == limb oracle
+def test_model_matches_limb_oracle(oracle, kats):
+    k = kats["fq12_test_vector"]
+    a = M.f12_unflat(I(k["start"])); b = M.f12_unflat(I(k["finally"]))
+    A = oracle.fq12_from_ints(k["start"]); B = oracle.fq12_from_ints(k["finally"])
+    chk = lambda got, want: oracle.fq12_to_ints(got) == M.f12_flat(want)
+    assert chk(oracle.fq12_mul(A, B), M.f12_mul(a, b))
+    assert chk(oracle.fq12_inverse(A), M.f12_inv(a))
+    for p in (1, 2, 3):
+        assert chk(oracle.fq12_frobenius_map(A, p), M.f12_frob(a, p))
+    assert chk(oracle.fq12_cyclotomic_squared(A), M.f12_cyclotomic_squared(a))
+    assert chk(oracle.fq12_final_exponentiation(A), M.final_exponentiation(a))
+    rng = np.random.default_rng(7)
+    for _ in range(3):
+        s1 = int.from_bytes(rng.bytes(32), "little") % M.R_ORD; s2 = int.from_bytes(rng.bytes(32), "little") % M.R_ORD
+        P = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, s1))
+        Qp = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_int(FR, s2))
+        want = M.pairing(M.g_mul(M.FQ_OPS, M.G1_ONE, s1), M.g_mul(M.FQ2_OPS, M.G2_ONE, s2))
+        assert chk(oracle.pairing(P, Qp), want)
