@@ -1,0 +1,359 @@
+// Base-field arithmetic of the HIP pairing engine: Fq elements as 9 x 29-bit limbs ("Fe"), Montgomery radix 2^261.
+//
+// Replaces, for the GPU, src/arith.rs:183-503 + src/fields/fp.rs:9-182 of the reference (U256 / Fq with 4 x u64 limbs,
+// radix 2^256, every value canonical).  Why a different number system (measured, profiles/r01_ubench_valu_rates.txt):
+//   * v_mad_u64_u32 is the best multiplier gfx950 has (0.44-0.46 G wave-instr/s/SIMD), and it adds a 64-bit addend for
+//     free, but every carry-writing add (v_add_co/v_addc) runs at half the plain-add rate.  With 29-bit limbs a whole
+//     column of 18 partial products accumulates in one 64-bit register with NO carry handling at all.
+//   * 9 x 29 = 261 bits leaves q/2^261 ~ 1/169 of head-room, so sums, differences and even products of unreduced values
+//     stay representable: additions are 9 plain v_add_u32, reduction mod q happens only where the bounds demand it.
+//
+// Representation invariants (tracked and ENFORCED at run time in the host simulation build, -DBN_BOUNDS; the control flow
+// of the engine is data independent, so one simulated run exercises every bound):
+//   limb bound  lb : l[i] <= lb * (2^29 - 1)  for i < 8      (lb = 1: "normalized")
+//   value bound vb : value < vb * q                            (the top limb l[8] holds everything above 2^232)
+// Montgomery products return (lb, vb) = (1, 2).  Values are only made canonical (< q) when they leave the engine
+// (fe_to_u32x8), where they are converted back to the reference's radix-2^256 image, so the bytes at the C ABI are
+// exactly the reference's.
+#pragma once
+#include <stdint.h>
+
+#if defined(BN_HOSTSIM)
+#define BN_FN inline
+#define BN_NOINLINE __attribute__((noinline))
+#define BN254_CONSTANT constexpr
+#else
+#include <hip/hip_runtime.h>
+#define BN_FN __device__ __forceinline__
+#define BN_NOINLINE __device__ __noinline__
+#define BN254_CONSTANT __device__ constexpr
+#endif
+#include "bn254_constants.hpp"
+
+#if defined(BN_BOUNDS)
+#include <cstdio>
+#include <cstdlib>
+#define BN_REQUIRE(cond, what)                                                                              \
+    do {                                                                                                    \
+        if (!(cond)) {                                                                                      \
+            std::fprintf(stderr, "BN_BOUNDS violation: %s  [%s]  at %s:%d\n", what, #cond, __FILE__, __LINE__); \
+            std::abort();                                                                                   \
+        }                                                                                                   \
+    } while (0)
+#define BN_SETB(x, LBV, VBV) ((x).lb = (LBV), (x).vb = (VBV))
+#define BN_IFB(...) __VA_ARGS__
+#else
+#define BN_REQUIRE(cond, what) ((void)0)
+#define BN_SETB(x, LBV, VBV) ((void)0)
+#define BN_IFB(...)
+#endif
+
+namespace bn254 {
+
+constexpr uint32_t MASK29 = 0x1fffffffu;
+
+struct Fe {
+    uint32_t l[9];
+#if defined(BN_BOUNDS)
+    uint32_t lb = 1, vb = 1;
+#endif
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// constants as Fe
+template <class T>
+BN_FN Fe fe_const(const T &tab) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = tab[i];
+    BN_SETB(r, 1, 1);
+    return r;
+}
+BN_FN Fe fe_zero() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = 0;
+    BN_SETB(r, 1, 1);
+    return r;
+}
+BN_FN Fe fe_one() { return fe_const(k::ONE); }
+
+// K*q written with every low limb raised by LB*(2^29-1)-ish so that  a + Bias - b  never borrows when b has limb bound LB
+// and value < (K-1)*q.   Sum of the limbs (weighted) is exactly K*q.
+template <int LB, int K>
+struct Bias {
+    uint32_t c[9];
+    constexpr Bias() : c{} {
+        uint64_t carry = 0;
+        uint32_t n[9] = {};
+        for (int i = 0; i < 9; ++i) {
+            uint64_t t = (uint64_t)k::Q[i] * (uint64_t)K + carry;
+            if (i < 8) { n[i] = (uint32_t)(t & MASK29); carry = t >> 29; } else { n[i] = (uint32_t)t; }
+        }
+        c[0] = n[0] + ((uint32_t)LB << 29);
+        for (int i = 1; i < 8; ++i) c[i] = n[i] + ((uint32_t)LB << 29) - (uint32_t)LB;
+        c[8] = n[8] - (uint32_t)LB;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lazy additive ops (arith.rs:238-253,266-273 do these with a conditional correction per call; here: none)
+BN_FN Fe fe_add(const Fe &a, const Fe &b) {
+    BN_REQUIRE(a.lb + b.lb <= 8, "fe_add limb overflow");
+    BN_REQUIRE(a.vb + b.vb <= 1024, "fe_add value overflow");
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+    BN_SETB(r, a.lb + b.lb, a.vb + b.vb);
+    return r;
+}
+BN_FN Fe fe_dbl(const Fe &a) { return fe_add(a, a); }
+
+// a - b (mod q) as a + K*q - b, b must satisfy lb <= LB and vb <= K-1
+template <int LB, int K>
+BN_FN Fe fe_sub(const Fe &a, const Fe &b) {
+    BN_REQUIRE(b.lb <= (uint32_t)LB, "fe_sub: subtrahend limbs exceed the bias");
+    BN_REQUIRE(b.vb + 1 <= (uint32_t)K, "fe_sub: subtrahend value exceeds the bias");
+    BN_REQUIRE(a.lb + LB + 1 <= 8, "fe_sub limb overflow");
+    BN_REQUIRE(a.vb + K <= 1024, "fe_sub value overflow");
+    constexpr Bias<LB, K> B{};
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + B.c[i] - b.l[i];
+    BN_SETB(r, a.lb + LB + 1, a.vb + K);
+    return r;
+}
+template <int LB, int K>
+BN_FN Fe fe_neg(const Fe &b) {
+    BN_REQUIRE(b.lb <= (uint32_t)LB, "fe_neg: limbs exceed the bias");
+    BN_REQUIRE(b.vb + 1 <= (uint32_t)K, "fe_neg: value exceeds the bias");
+    constexpr Bias<LB, K> B{};
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = B.c[i] - b.l[i];
+    BN_SETB(r, LB + 1, K);
+    return r;
+}
+
+// carry propagation only: limbs back to 29 bits, value unchanged
+BN_FN Fe fe_norm(const Fe &a) {
+    Fe r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t t = a.l[i] + c;      // a.l[i] <= 8*(2^29-1), c < 2^4: no overflow
+        r.l[i] = t & MASK29;
+        c = t >> 29;
+    }
+    r.l[8] = a.l[8] + c;
+    BN_SETB(r, 1, a.vb);
+    return r;
+}
+
+// quotient estimate in fe_reduce: k = floor(top * FE_MU / 2^53), FE_MU = floor(2^285/q), top ~ value >> 232
+// value reduction: returns the same residue with normalized limbs and value < 2q.   Accepts any lb <= 8, vb <= 1000.
+// `scale` multiplies the input by a small constant first (1, 9, ...): reduce(scale * a).
+template <int SCALE = 1>
+BN_FN Fe fe_reduce(const Fe &a) {
+    BN_REQUIRE(a.lb <= 8, "fe_reduce lb");
+    BN_REQUIRE((uint64_t)a.vb * SCALE <= 1000, "fe_reduce vb");
+    // top ~ floor(SCALE*value / 2^232), never above it (carries still parked in lower limbs are ignored: at most ~8*SCALE)
+    uint32_t top = (uint32_t)SCALE * (a.l[8] + (a.l[7] >> 29));
+    uint32_t kq = (uint32_t)(((uint64_t)top * k::FE_MU) >> 53);     // k <= floor(SCALE*value/q), k >= that - 1
+    Fe r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int64_t t = carry + (int64_t)((uint64_t)a.l[i] * (uint32_t)SCALE) - (int64_t)((uint64_t)kq * k::Q[i]);
+        if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
+    }
+    BN_SETB(r, 1, 2);
+    return r;
+}
+
+// reduce(C1*x + C2*y + C3*z) for small signed integer constants (0 disables a term): one signed 64-bit carry chain that
+// forms the linear combination, subtracts floor-ish(value/q)*q and renormalizes.  This is how every "sum of products"
+// of the tower (Karatsuba recombination, multiplication by xi = 9+i) gets back to standard form; the reference spends a
+// conditional add/subtract per Fq add instead (arith.rs:238-253).  Result: normalized limbs, value < 3q.
+template <int C1, int C2, int C3>
+BN_FN Fe fe_lc3(const Fe &x, const Fe &y, const Fe &z) {
+    constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3;
+    BN_REQUIRE((C1 == 0 || x.lb <= 8) && (C2 == 0 || y.lb <= 8) && (C3 == 0 || z.lb <= 8), "fe_lc3 lb");
+    BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb <= 1000, "fe_lc3 vb");
+    // signed estimate of floor(value / 2^232) that never exceeds the truth: positive terms use a low estimate of their
+    // top (carries parked in lower limbs ignored), negative terms a high one (+9)
+    auto top = [](const Fe &f, bool hi) -> int64_t { return (int64_t)f.l[8] + (int64_t)(f.l[7] >> 29) + (hi ? 9 : 0); };
+    int64_t te = -600;   // safety margin covering the truncation of FE_MU24 (|te| < 2^32 -> < 2^9 units)
+    if (C1 != 0) te += (int64_t)C1 * top(x, C1 < 0);
+    if (C2 != 0) te += (int64_t)C2 * top(y, C2 < 0);
+    if (C3 != 0) te += (int64_t)C3 * top(z, C3 < 0);
+    int64_t kq = (te * (int64_t)k::FE_MU24) >> 45;          // floor; kq <= floor(value/q), kq >= value/q - 2
+    Fe r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int64_t t = carry - kq * (int64_t)k::Q[i];
+        if (C1 != 0) t += (int64_t)C1 * (int64_t)x.l[i];
+        if (C2 != 0) t += (int64_t)C2 * (int64_t)y.l[i];
+        if (C3 != 0) t += (int64_t)C3 * (int64_t)z.l[i];
+        if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
+    }
+    BN_SETB(r, 1, 3);
+    return r;
+}
+BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any lazy value -> standard form (1,3)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Montgomery multiplication, product scanning with interleaved reduction (replaces arith.rs:481-503 mul_reduce +
+// :257-263).  One 64-bit accumulator per column, 81 + 81 v_mad_u64_u32, no carry instructions.
+// Column bound: 9*(la*lb) * 2^58 + 9 * 2^58 + carry < 2^64  <=>  la*lb <= 6.
+// Value: result < (A*B/169.3 + 1) q, so A*B <= 169 gives < 2q.
+BN_FN Fe fe_mul(const Fe &a, const Fe &b) {
+    BN_REQUIRE(a.lb * b.lb <= 6, "fe_mul column overflow");
+    BN_REQUIRE(a.vb * b.vb <= 169, "fe_mul value bound");
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fe r;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+#pragma unroll
+        for (int i = 0; i <= c; ++i) acc += (uint64_t)a.l[i] * b.l[c - i];
+#pragma unroll
+        for (int i = 0; i < c; ++i) acc += (uint64_t)m[i] * k::Q[c - i];
+        m[c] = ((uint32_t)acc * k::QINV) & MASK29;
+        acc += (uint64_t)m[c] * k::Q[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int c = 9; c < 17; ++c) {
+#pragma unroll
+        for (int i = c - 8; i <= 8; ++i) acc += (uint64_t)a.l[i] * b.l[c - i];
+#pragma unroll
+        for (int i = c - 8; i <= 8; ++i) acc += (uint64_t)m[i] * k::Q[c - i];
+        r.l[c - 9] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    BN_SETB(r, 1, 2);
+    return r;
+}
+BN_FN Fe fe_sqr(const Fe &a) { return fe_mul(a, a); }
+
+// (a*u + c*v) / R with ONE reduction: 162 + 81 mads.   Column bound: la*lu + lc*lv <= 6; value: A*U + C*V <= 169.
+BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
+    BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 6, "fe_mul2 column overflow");
+    BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 169, "fe_mul2 value bound");
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fe r;
+#pragma unroll
+    for (int col = 0; col < 9; ++col) {
+#pragma unroll
+        for (int i = 0; i <= col; ++i) {
+            acc += (uint64_t)a.l[i] * u.l[col - i];
+            acc += (uint64_t)c.l[i] * v.l[col - i];
+        }
+#pragma unroll
+        for (int i = 0; i < col; ++i) acc += (uint64_t)m[i] * k::Q[col - i];
+        m[col] = ((uint32_t)acc * k::QINV) & MASK29;
+        acc += (uint64_t)m[col] * k::Q[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int col = 9; col < 17; ++col) {
+#pragma unroll
+        for (int i = col - 8; i <= 8; ++i) {
+            acc += (uint64_t)a.l[i] * u.l[col - i];
+            acc += (uint64_t)c.l[i] * v.l[col - i];
+        }
+#pragma unroll
+        for (int i = col - 8; i <= 8; ++i) acc += (uint64_t)m[i] * k::Q[col - i];
+        r.l[col - 9] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    BN_SETB(r, 1, 2);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// boundary conversions: the C ABI speaks the reference's format (8 x u32 = [u64;4] little endian, a*2^256 mod q, < q)
+BN_FN Fe fe_unpack_u32x8(const uint32_t *w) {     // raw 256-bit integer -> 29-bit limbs (no Montgomery change)
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)w[wi] | (wi + 1 < 8 ? ((uint64_t)w[wi + 1] << 32) : 0);
+        r.l[i] = (uint32_t)(two >> sh) & (i < 8 ? MASK29 : 0xffffffffu);
+    }
+    BN_SETB(r, 1, 1);
+    return r;
+}
+BN_FN void fe_pack_u32x8(const Fe &a, uint32_t *w) {   // normalized limbs, value < 2^256 -> 8 words
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int bit = 32 * j, li = bit / 29, sh = bit - 29 * li;      // word j starts inside limb li at offset sh
+        uint64_t v = (uint64_t)a.l[li] >> sh;
+        int have = 29 - sh;
+        if (li + 1 < 9) v |= (uint64_t)a.l[li + 1] << have;
+        if (have + 29 < 32 && li + 2 < 9) v |= (uint64_t)a.l[li + 2] << (have + 29);
+        w[j] = (uint32_t)v;
+    }
+}
+// reference image (canonical, radix 2^256) -> internal (radix 2^261), result (1,2)
+BN_FN Fe fe_from_u32x8(const uint32_t *w) { return fe_mul(fe_unpack_u32x8(w), fe_const(k::C_IN)); }
+
+// exact canonical value of a (1,2) element: conditional subtraction of q
+BN_FN Fe fe_canonical(const Fe &t) {
+    BN_REQUIRE(t.lb == 1 && t.vb <= 2, "fe_canonical expects a Montgomery product");
+    Fe d;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int32_t s = (int32_t)t.l[i] - (int32_t)k::Q[i] + borrow;      // |s| < 2^30
+        if (i < 8) { d.l[i] = (uint32_t)s & MASK29; borrow = s >> 29; } else { d.l[i] = (uint32_t)s; borrow = s >> 31; }
+    }
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = borrow ? t.l[i] : d.l[i];
+    BN_SETB(r, 1, 1);
+    return r;
+}
+// internal -> reference image, exact (this is where "bit-exact vs the reference" is decided)
+BN_FN void fe_to_u32x8(const Fe &a, uint32_t *w) {
+    Fe t = fe_canonical(fe_mul(a, fe_const(k::C_OUT)));
+    fe_pack_u32x8(t, w);
+}
+// a == 0 (mod q) for any lazy a with lb*1 <= 6, vb <= 169
+BN_FN bool fe_is_zero(const Fe &a) {
+    Fe t = fe_canonical(fe_mul(a, fe_const(k::RAW_ONE)));
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o |= t.l[i];
+    return o == 0;
+}
+// per-lane select without divergence
+BN_FN Fe fe_select(bool take_b, const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = take_b ? b.l[i] : a.l[i];
+    BN_IFB(r.lb = a.lb > b.lb ? a.lb : b.lb; r.vb = a.vb > b.vb ? a.vb : b.vb;)
+    return r;
+}
+
+// a^(q-2) (Fermat).  Uniform across lanes; replaces the data-dependent binary EEA of arith.rs:281-327 + fp.rs:103-112.
+// The inverse is unique mod q, so after canonicalisation the bytes equal the reference's.  inverse(0) = 0.
+BN_FN Fe fe_inverse(const Fe &a_in) {
+    Fe a = a_in;
+    BN_REQUIRE(a.lb <= 2 && a.vb <= 8, "fe_inverse input");
+    Fe r = fe_one();
+    // left-to-right square-and-multiply over the 254 bits of q-2; loop not unrolled (keeps the code small)
+#pragma unroll 1
+    for (int i = 253; i >= 0; --i) {
+        r = fe_sqr(r);
+        if ((k::Q_MINUS_2[i >> 6] >> (i & 63)) & 1) r = fe_mul(r, a);     // exponent bits are wave-uniform: scalar branch
+    }
+    return r;
+}
+
+}  // namespace bn254

@@ -1,0 +1,185 @@
+// Fq6 = Fq2[v]/(v^3 - xi) and Fq12 = Fq6[w]/(w^2 - v) for the HIP pairing engine, generic over the Fq2 lane mapping
+// (Fq2A / Fq2B, fq2.hpp).  Formulas follow the reference op for op where the reference fixes the VALUE
+// (src/fields/fq6.rs, src/fields/fq12.rs); any rearrangement below is value-preserving and the results are compared
+// bit for bit with the oracle (tests/test_hostsim.py on CPU, tests/test_gpu_parity.py on the GPU).
+//
+// Every function takes and returns components in standard form S (normalized limbs, value < 3q) - see fq2.hpp.  Lazy
+// intermediates (plain limb-wise sums/differences) are folded back by the fused f2_lc3 / f2_lc_xi reductions.
+#pragma once
+#include "fq2.hpp"
+
+namespace bn254 {
+
+template <class F2> struct Fq6 { F2 c0, c1, c2; };
+template <class F2> struct Fq12 { Fq6<F2> c0, c1; };
+
+#define F2P ((const F2 *)nullptr)
+
+// ------------------------------------------------------------------------------------------------------------- Fq6
+template <class F2> BN_FN Fq6<F2> f6_zero() { return {f2_zero(F2P), f2_zero(F2P), f2_zero(F2P)}; }
+template <class F2> BN_FN Fq6<F2> f6_one() { return {f2_one(F2P), f2_zero(F2P), f2_zero(F2P)}; }
+// reduce(C1*x + C2*y + C3*z) componentwise
+template <int C1, int C2, int C3, class F2>
+BN_FN Fq6<F2> f6_lc3(const Fq6<F2> &x, const Fq6<F2> &y, const Fq6<F2> &z) {
+    return {f2_lc3<C1, C2, C3>(x.c0, y.c0, z.c0), f2_lc3<C1, C2, C3>(x.c1, y.c1, z.c1), f2_lc3<C1, C2, C3>(x.c2, y.c2, z.c2)};
+}
+template <class F2> BN_FN Fq6<F2> f6_add(const Fq6<F2> &a, const Fq6<F2> &b) { return f6_lc3<1, 1, 0>(a, b, b); }
+template <class F2> BN_FN Fq6<F2> f6_sub(const Fq6<F2> &a, const Fq6<F2> &b) { return f6_lc3<1, -1, 0>(a, b, b); }
+template <class F2> BN_FN Fq6<F2> f6_neg(const Fq6<F2> &a) { return f6_lc3<-1, 0, 0>(a, a, a); }
+// v * x   (fq6.rs:59-65)
+template <class F2> BN_FN Fq6<F2> f6_mul_by_v(const Fq6<F2> &a) { return {f2_mul_xi(a.c2), a.c0, a.c1}; }
+
+// fq6.rs:144-158: 6 Fq2 products (Karatsuba), the two xi-multiplications folded into the final reductions
+template <class F2>
+BN_FN Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
+    F2 aa = f2_mul(a.c0, b.c0), bb = f2_mul(a.c1, b.c1), cc = f2_mul(a.c2, b.c2);
+    F2 t0 = f2_mul(f2_add(a.c1, a.c2), f2_norm(f2_add(b.c1, b.c2)));
+    F2 t1 = f2_mul(f2_add(a.c0, a.c1), f2_norm(f2_add(b.c0, b.c1)));
+    F2 t2 = f2_mul(f2_add(a.c0, a.c2), f2_norm(f2_add(b.c0, b.c2)));
+    F2 x0 = f2_sub<1, 4>(f2_sub<1, 4>(t0, bb), cc);            // a1 b2 + a2 b1, lazy
+    F2 y1 = f2_sub<1, 4>(f2_sub<1, 4>(t1, aa), bb);            // a0 b1 + a1 b0, lazy
+    Fq6<F2> r;
+    r.c0 = f2_lc_xi<1, 1>(x0, aa);
+    r.c1 = f2_lc_xi<1, 1>(cc, y1);
+    r.c2 = f2_lc3<1, -1, -1>(f2_add(t2, bb), aa, cc);
+    return r;
+}
+// fq6.rs:113-127 (CH-SQR2)
+template <class F2>
+BN_FN Fq6<F2> f6_sqr(const Fq6<F2> &a) {
+    F2 s0 = f2_sqr(a.c0), ab = f2_mul(a.c0, a.c1);
+    F2 s2 = f2_sqr(f2_lc3<1, -1, 1>(a.c0, a.c1, a.c2));
+    F2 bc = f2_mul(a.c1, a.c2), s4 = f2_sqr(a.c2);
+    F2 s1 = f2_dbl(ab), s3 = f2_dbl(bc);
+    Fq6<F2> r;
+    r.c0 = f2_lc_xi<1, 1>(s3, s0);
+    r.c1 = f2_lc_xi<1, 1>(s4, s1);
+    r.c2 = f2_lc3<1, -1, -1>(f2_add(f2_add(s1, s2), s3), s0, s4);
+    return r;
+}
+template <class F2> BN_FN Fq6<F2> f6_scale(const Fq6<F2> &a, const F2 &by) { return {f2_mul(a.c0, by), f2_mul(a.c1, by), f2_mul(a.c2, by)}; }
+// fq6.rs:75-81, P in {1,2,3}
+template <int P, class F2>
+BN_FN Fq6<F2> f6_frobenius(const Fq6<F2> &a) {
+    if constexpr (P % 2 == 0) {
+        return {a.c0, f2_mul_const(a.c1, k::FROB6_C1[P]), f2_mul_const(a.c2, k::FROB6_C2[P])};
+    } else {
+        return {f2_conj(a.c0), f2_mul_const(f2_conj_lazy(a.c1), k::FROB6_C1[P]), f2_mul_const(f2_conj_lazy(a.c2), k::FROB6_C2[P])};
+    }
+}
+// fq6.rs:129-141
+template <class F2>
+BN_FN Fq6<F2> f6_inverse(const Fq6<F2> &a) {
+    F2 c0 = f2_lc3<1, -1, 0>(f2_sqr(a.c0), f2_mul(a.c1, f2_mul_xi(a.c2)), a.c0);
+    F2 c1 = f2_lc_xi<1, -1>(f2_sqr(a.c2), f2_mul(a.c0, a.c1));
+    F2 c2 = f2_lc3<1, -1, 0>(f2_sqr(a.c1), f2_mul(a.c0, a.c2), a.c0);
+    F2 n = f2_lc_xi<1, 1>(f2_add(f2_mul(a.c2, c1), f2_mul(a.c1, c2)), f2_mul(a.c0, c0));
+    F2 t = f2_inverse(n);
+    return {f2_mul(t, c0), f2_mul(t, c1), f2_mul(t, c2)};
+}
+
+// ------------------------------------------------------------------------------------------------------------- Fq12
+template <class F2> BN_FN Fq12<F2> f12_one() { return {f6_one<F2>(), f6_zero<F2>()}; }
+// fq12.rs:295-307
+template <class F2>
+BN_FN Fq12<F2> f12_mul(const Fq12<F2> &a, const Fq12<F2> &b) {
+    Fq6<F2> aa = f6_mul(a.c0, b.c0), bb = f6_mul(a.c1, b.c1);
+    Fq6<F2> t = f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1));
+    Fq12<F2> r;
+    r.c0.c0 = f2_lc_xi<1, 1>(bb.c2, aa.c0);                  // aa + v*bb
+    r.c0.c1 = f2_lc3<1, 1, 0>(aa.c1, bb.c0, bb.c0);
+    r.c0.c2 = f2_lc3<1, 1, 0>(aa.c2, bb.c1, bb.c1);
+    r.c1 = f6_lc3<1, -1, -1>(t, aa, bb);
+    return r;
+}
+// fq12.rs:275-282 (complex squaring over Fq6)
+template <class F2>
+BN_FN Fq12<F2> f12_sqr(const Fq12<F2> &a) {
+    Fq6<F2> ab = f6_mul(a.c0, a.c1);
+    Fq6<F2> u;                                                // v*c1 + c0
+    u.c0 = f2_lc_xi<1, 1>(a.c1.c2, a.c0.c0);
+    u.c1 = f2_lc3<1, 1, 0>(a.c1.c0, a.c0.c1, a.c0.c1);
+    u.c2 = f2_lc3<1, 1, 0>(a.c1.c1, a.c0.c2, a.c0.c2);
+    Fq6<F2> t = f6_mul(u, f6_add(a.c0, a.c1));
+    Fq12<F2> r;
+    r.c0.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_sub<1, 4>(t.c0, ab.c0));      // t - ab - v*ab
+    r.c0.c1 = f2_lc3<1, -1, -1>(t.c1, ab.c1, ab.c0);
+    r.c0.c2 = f2_lc3<1, -1, -1>(t.c2, ab.c2, ab.c1);
+    r.c1 = f6_lc3<2, 0, 0>(ab, ab, ab);
+    return r;
+}
+// fq12.rs:103-105
+template <class F2> BN_FN Fq12<F2> f12_conj(const Fq12<F2> &a) { return {a.c0, f6_neg(a.c1)}; }
+// fq12.rs:284-292
+template <class F2>
+BN_FN Fq12<F2> f12_inverse(const Fq12<F2> &a) {
+    Fq6<F2> s1 = f6_sqr(a.c1);
+    Fq6<F2> s0 = f6_sqr(a.c0);
+    Fq6<F2> d;                                                // c0^2 - v*c1^2
+    d.c0 = f2_lc_xi<-1, 1>(s1.c2, s0.c0);
+    d.c1 = f2_lc3<1, -1, 0>(s0.c1, s1.c0, s1.c0);
+    d.c2 = f2_lc3<1, -1, 0>(s0.c2, s1.c1, s1.c1);
+    Fq6<F2> t = f6_inverse(d);
+    return {f6_mul(a.c0, t), f6_neg(f6_mul(a.c1, t))};
+}
+// fq12.rs:90-95, P in {1,2,3}
+template <int P, class F2>
+BN_FN Fq12<F2> f12_frobenius(const Fq12<F2> &a) {
+    Fq6<F2> c1 = f6_frobenius<P>(a.c1);
+    F2 g = f2_const(F2P, k::FROB12_C1[P]);
+    return {f6_frobenius<P>(a.c0), f6_scale(c1, g)};
+}
+
+// fq12.rs:107-176: f * (x0 + x2 v^2 + x4 v w), 13 Fq2 products; (ell_0, ell_vw, ell_vv) -> (x0, x4, x2) as in the reference
+template <class F2>
+BN_FN Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &ell_vw, const F2 &ell_vv) {
+    const F2 &z0 = f.c0.c0, &z1 = f.c0.c1, &z2 = f.c0.c2, &z3 = f.c1.c0, &z4 = f.c1.c1, &z5 = f.c1.c2;
+    const F2 &x0 = ell_0, &x2 = ell_vv, &x4 = ell_vw;
+    F2 d0 = f2_mul(z0, x0), d2 = f2_mul(z2, x2), d4 = f2_mul(z4, x4);
+    F2 z1x2 = f2_mul(z1, x2), z5x4 = f2_mul(z5, x4), z1x0 = f2_mul(z1, x0);
+    F2 z3x4 = f2_mul(z3, x4), z3x0 = f2_mul(z3, x0), z5x2 = f2_mul(z5, x2);
+    F2 x02 = f2_norm(f2_add(x0, x2)), x24 = f2_norm(f2_add(x2, x4)), x04 = f2_norm(f2_add(x0, x4));
+    F2 m02 = f2_mul(f2_add(z0, z2), x02);                   // (z0+z2)(x0+x2)
+    F2 m24 = f2_mul(f2_add(z2, z4), x24);                   // (z2+z4)(x2+x4)
+    F2 m04 = f2_mul(f2_add(z0, z4), x04);                   // (z0+z4)(x0+x4)
+    F2 s0 = f2_lc3<1, 1, 1>(z1, z3, z5), xs = f2_lc3<1, 1, 1>(x0, x2, x4);
+    F2 ms = f2_mul(s0, xs);
+    F2 s1 = f2_add(f2_add(f2_add(z1x2, z5x4), f2_add(z1x0, z3x4)), f2_add(z3x0, z5x2));      // lazy, lb 6
+    Fq12<F2> r;
+    r.c0.c0 = f2_lc_xi<1, 1>(f2_add(z1x2, d4), d0);
+    r.c0.c1 = f2_lc_xi<1, 1>(f2_add(z5x4, d2), z1x0);
+    r.c0.c2 = f2_lc3<1, -1, -1>(f2_add(m02, z3x4), d0, d2);
+    r.c1.c0 = f2_lc_xi<1, 1>(f2_sub<1, 4>(f2_sub<1, 4>(m24, d2), d4), z3x0);
+    r.c1.c1 = f2_lc_xi<1, 1>(z5x2, f2_sub<1, 4>(f2_sub<1, 4>(m04, d0), d4));
+    r.c1.c2 = f2_lc3<1, -1, 0>(ms, s1, s1);
+    return r;
+}
+
+// fq12.rs:178-227 (Granger-Scott squaring; equals f*f only on the cyclotomic subgroup - the KAT of fields/mod.rs:171-201
+// feeds it an element OFF the subgroup, so the formula itself is part of the contract)
+template <class F2>
+BN_FN void f4_sq(const F2 &a, const F2 &b, F2 &t_even, F2 &tmp_out) {       // (a + b s)^2, s^2 = xi: even = a^2 + xi b^2, tmp = a b
+    F2 tmp = f2_mul(a, b);
+    F2 m = f2_mul(f2_add(a, b), f2_lc_xi<1, 1>(b, a));
+    t_even = f2_lc_xi<-1, 1>(tmp, f2_sub<1, 4>(m, tmp));
+    tmp_out = tmp;
+}
+template <class F2>
+BN_FN Fq12<F2> f12_cyclotomic_sqr(const Fq12<F2> &f) {
+    const F2 &z0 = f.c0.c0, &z4 = f.c0.c1, &z3 = f.c0.c2, &z2 = f.c1.c0, &z1 = f.c1.c1, &z5 = f.c1.c2;
+    F2 t0, t2, t4, p01, p23, p45;                            // t1 = 2 p01, t3 = 2 p23, t5 = 2 p45
+    f4_sq(z0, z1, t0, p01);
+    f4_sq(z2, z3, t2, p23);
+    f4_sq(z4, z5, t4, p45);
+    Fq12<F2> r;
+    r.c0.c0 = f2_lc3<3, -2, 0>(t0, z0, z0);                   // 2(t0 - z0) + t0
+    r.c1.c1 = f2_lc3<6, 2, 0>(p01, z1, z1);                   // 2(t1 + z1) + t1
+    r.c1.c0 = f2_lc_xi<6, 2>(p45, z2);                        // 2(xi t5 + z2) + xi t5
+    r.c0.c2 = f2_lc3<3, -2, 0>(t4, z3, z3);
+    r.c0.c1 = f2_lc3<3, -2, 0>(t2, z4, z4);
+    r.c1.c2 = f2_lc3<6, 2, 0>(p23, z5, z5);
+    return r;
+}
+
+#undef F2P
+}  // namespace bn254

@@ -1,0 +1,74 @@
+// TEST INFRASTRUCTURE - host simulation of the DEVICE headers (bn_amd/csrc/*.hpp) compiled with g++ for the CPU.
+// Purpose: (1) bit-exact comparison of the engine's arithmetic with the oracle where there is no GPU, and
+// (2) -DBN_BOUNDS: run-time enforcement of every limb/value bound of the lazy 9x29-bit number system (the engine's control
+// flow is data independent, so one simulated pairing exercises every bound check).
+// This library is never loaded by the product (bn_amd/); it is not a CPU fallback.
+#define BN_HOSTSIM 1
+#include "../../bn_amd/csrc/io.hpp"
+#include <cstring>
+
+using namespace bn254;
+#define EXPORT extern "C" __attribute__((visibility("default")))
+typedef Fq2A F2;
+
+EXPORT int hs_bounds_enabled() {
+#ifdef BN_BOUNDS
+    return 1;
+#else
+    return 0;
+#endif
+}
+// out = a*b, a+b, a-b in the reference image (canonical Montgomery radix 2^256), through the engine's lazy arithmetic
+EXPORT void hs_fe_mul(const uint32_t *a, const uint32_t *b, uint32_t *o) { fe_to_u32x8(fe_mul(fe_from_u32x8(a), fe_from_u32x8(b)), o); }
+EXPORT void hs_fe_add(const uint32_t *a, const uint32_t *b, uint32_t *o) { fe_to_u32x8(fe_add(fe_from_u32x8(a), fe_from_u32x8(b)), o); }
+EXPORT void hs_fe_sub(const uint32_t *a, const uint32_t *b, uint32_t *o) { fe_to_u32x8(fe_sub<1, 3>(fe_from_u32x8(a), fe_from_u32x8(b)), o); }
+EXPORT void hs_fe_roundtrip(const uint32_t *a, uint32_t *o) { fe_to_u32x8(fe_from_u32x8(a), o); }
+EXPORT void hs_fe_inverse(const uint32_t *a, uint32_t *o) { fe_to_u32x8(fe_inverse(fe_from_u32x8(a)), o); }
+EXPORT int hs_fe_is_zero(const uint32_t *a) { return fe_is_zero(fe_from_u32x8(a)); }
+// a stress of the lazy forms: ((a+b)+(a+b)) - b - b + 9a ... reduced through lc3, compared with the oracle's canonical ops
+EXPORT void hs_fe_lazy_mix(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *o) {
+    Fe x = fe_from_u32x8(a), y = fe_from_u32x8(b), z = fe_from_u32x8(c);
+    Fe s = fe_add(fe_add(x, y), fe_add(x, y));                    // 2x + 2y  (4,8)
+    Fe d = fe_sub<1, 3>(fe_sub<1, 3>(s, y), z);                   // 2x + y - z (8, 14)
+    Fe r = fe_lc3<9, -1, 3>(d, x, z);                             // 18x + 9y - 9z - x + 3z = 17x + 9y - 6z
+    Fe n = fe_norm(fe_add(r, fe_reduce<9>(y)));                   // + 9y
+    fe_to_u32x8(fe_mul(n, fe_one()), o);                          // = 17x + 18y - 6z
+}
+EXPORT void hs_fe_mul2(const uint32_t *a, const uint32_t *u, const uint32_t *c, const uint32_t *v, uint32_t *o) {
+    fe_to_u32x8(fe_mul2(fe_from_u32x8(a), fe_from_u32x8(u), fe_from_u32x8(c), fe_from_u32x8(v)), o);
+}
+
+EXPORT void hs_fq2_mul(const uint32_t *a, const uint32_t *b, uint32_t *o) { f2_store(f2_mul(f2_load((F2 *)0, a), f2_load((F2 *)0, b)), o); }
+EXPORT void hs_fq2_sqr(const uint32_t *a, uint32_t *o) { f2_store(f2_sqr(f2_load((F2 *)0, a)), o); }
+EXPORT void hs_fq2_mul_xi(const uint32_t *a, uint32_t *o) { f2_store(f2_mul_xi(f2_load((F2 *)0, a)), o); }
+EXPORT void hs_fq2_inverse(const uint32_t *a, uint32_t *o) { f2_store(f2_inverse(f2_load((F2 *)0, a)), o); }
+
+EXPORT void hs_fq12_mul(const uint32_t *a, const uint32_t *b, uint32_t *o) { f12_store(f12_mul(f12_load<F2>(a), f12_load<F2>(b)), o); }
+EXPORT void hs_fq12_sqr(const uint32_t *a, uint32_t *o) { f12_store(f12_sqr(f12_load<F2>(a)), o); }
+EXPORT void hs_fq12_inverse(const uint32_t *a, uint32_t *o) { f12_store(f12_inverse(f12_load<F2>(a)), o); }
+EXPORT void hs_fq12_conj(const uint32_t *a, uint32_t *o) { f12_store(f12_conj(f12_load<F2>(a)), o); }
+EXPORT void hs_fq12_cyclotomic_sqr(const uint32_t *a, uint32_t *o) { f12_store(f12_cyclotomic_sqr(f12_load<F2>(a)), o); }
+EXPORT void hs_fq12_exp_by_neg_z(const uint32_t *a, uint32_t *o) { f12_store(exp_by_neg_z(f12_load<F2>(a)), o); }
+EXPORT void hs_fq12_frobenius(const uint32_t *a, int p, uint32_t *o) {
+    Fq12<F2> f = f12_load<F2>(a);
+    f12_store(p == 1 ? f12_frobenius<1>(f) : p == 2 ? f12_frobenius<2>(f) : f12_frobenius<3>(f), o);
+}
+EXPORT void hs_fq12_mul_by_024(const uint32_t *a, const uint32_t *l0, const uint32_t *lvw, const uint32_t *lvv, uint32_t *o) {
+    f12_store(f12_mul_by_024(f12_load<F2>(a), f2_load((F2 *)0, l0), f2_load((F2 *)0, lvw), f2_load((F2 *)0, lvv)), o);
+}
+EXPORT void hs_final_exponentiation(const uint32_t *a, uint32_t *o) { f12_store(final_exponentiation(f12_load<F2>(a)), o); }
+
+// full pairing of Jacobian inputs in the reference layout (groups/mod.rs:764-771): infinity -> one
+EXPORT void hs_miller(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
+    G1Aff<Fe> p = g1_to_affine(fe_from_u32x8(g1), fe_from_u32x8(g1 + 8), fe_from_u32x8(g1 + 16));
+    G2Aff<F2> q = g2_to_affine(f2_load((F2 *)0, g2), f2_load((F2 *)0, g2 + 16), f2_load((F2 *)0, g2 + 32));
+    f12_store(miller_loop(p, q), o);
+}
+EXPORT void hs_pairing(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
+    bool inf = words_all_zero(g1 + 16, 8) || words_all_zero(g2 + 32, 16);
+    G1Aff<Fe> p = g1_to_affine(fe_from_u32x8(g1), fe_from_u32x8(g1 + 8), fe_from_u32x8(g1 + 16));
+    G2Aff<F2> q = g2_to_affine(f2_load((F2 *)0, g2), f2_load((F2 *)0, g2 + 16), f2_load((F2 *)0, g2 + 32));
+    Fq12<F2> f = final_exponentiation(miller_loop(p, q));
+    if (inf) f = f12_one<F2>();
+    f12_store(f, o);
+}

@@ -1,0 +1,112 @@
+"""CPU-side proof of the DEVICE arithmetic: bn_amd/csrc/*.hpp compiled with g++ (tests/hostsim/hostsim.cpp, -DBN_BOUNDS
+so every limb/value bound of the lazy 9x29-bit number system is enforced at run time) and compared bit for bit with the
+oracle.  Not a fallback: the product never loads this library."""
+import numpy as np
+import pytest
+
+import bn_model as M
+import hostsim_lib
+from bn_oracle import FQ, FR
+
+
+@pytest.fixture(scope="module")
+def hs():
+    return hostsim_lib.HostSim(bounds=True)
+
+
+def _rfq(oracle, rng):
+    return oracle.fp_from_int(FQ, int.from_bytes(rng.bytes(40), "little") % M.Q)
+
+
+def _rf(oracle, rng, n):
+    return np.concatenate([_rfq(oracle, rng) for _ in range(n)])
+
+
+EDGE = [0, 1, 2, M.Q - 1, M.Q - 2, (M.Q - 1) // 2, (1 << 253), (1 << 29) - 1, 1 << 232, M.MONT_R % M.Q]
+
+
+def test_fe_ops_match_oracle(oracle, hs):
+    rng = np.random.default_rng(11)
+    vals = [oracle.fp_from_int(FQ, v) for v in EDGE] + [_rfq(oracle, rng) for _ in range(60)]
+    for i, a in enumerate(vals):
+        assert np.array_equal(hs.call("hs_fe_roundtrip", a, out_words=8), a)
+        for b in vals[::7] + vals[:len(EDGE)]:
+            assert np.array_equal(hs.call("hs_fe_mul", a, b, out_words=8), oracle.fp_mul(FQ, a, b))
+            assert np.array_equal(hs.call("hs_fe_add", a, b, out_words=8), oracle.fp_add(FQ, a, b))
+            assert np.array_equal(hs.call("hs_fe_sub", a, b, out_words=8), oracle.fp_sub(FQ, a, b))
+        assert bool(hs.lib.hs_fe_is_zero(a.ctypes.data_as(hostsim_lib._U32P))) == (i == 0)
+
+
+def test_fe_lazy_forms(oracle, hs):
+    rng = np.random.default_rng(12)
+    pool = [oracle.fp_from_int(FQ, v) for v in EDGE] + [_rfq(oracle, rng) for _ in range(40)]
+    for _ in range(400):
+        a, b, c, d = (pool[i] for i in rng.integers(0, len(pool), 4))
+        ai, bi, ci = (oracle.fp_to_int(FQ, x) for x in (a, b, c))
+        want = oracle.fp_from_int(FQ, (17 * ai + 18 * bi - 6 * ci) % M.Q)
+        assert np.array_equal(hs.call("hs_fe_lazy_mix", a, b, c, out_words=8), want)
+        want = oracle.fp_add(FQ, oracle.fp_mul(FQ, a, b), oracle.fp_mul(FQ, c, d))
+        assert np.array_equal(hs.call("hs_fe_mul2", a, b, c, d, out_words=8), want)
+
+
+def test_fe_inverse(oracle, hs):
+    rng = np.random.default_rng(13)
+    for a in [oracle.fp_from_int(FQ, v) for v in (1, 2, M.Q - 1, 12345)] + [_rfq(oracle, rng) for _ in range(4)]:
+        assert np.array_equal(hs.call("hs_fe_inverse", a, out_words=8), oracle.fp_inverse(FQ, a))
+    z = oracle.fp_from_int(FQ, 0)
+    assert np.array_equal(hs.call("hs_fe_inverse", z, out_words=8), z)       # engine convention: inverse(0) = 0
+
+
+def test_fq2(oracle, hs):
+    rng = np.random.default_rng(14)
+    for _ in range(25):
+        a, b = _rf(oracle, rng, 2), _rf(oracle, rng, 2)
+        assert np.array_equal(hs.call("hs_fq2_mul", a, b, out_words=16), oracle.fq2_mul(a, b))
+        assert np.array_equal(hs.call("hs_fq2_sqr", a, out_words=16), oracle.fq2_sqr(a))
+        assert np.array_equal(hs.call("hs_fq2_mul_xi", a, out_words=16), oracle.fq2_mul_xi(a))
+        assert np.array_equal(hs.call("hs_fq2_inverse", a, out_words=16), oracle.fq2_inverse(a))
+
+
+def test_fq12_ops(oracle, hs, kats):
+    rng = np.random.default_rng(15)
+    elems = [oracle.fq12_from_ints(kats["fq12_test_vector"]["start"]), oracle.fq12_from_ints(kats["test_cyclotomic_exp"]["orig"]),
+             oracle.fq12_one()] + [_rf(oracle, rng, 12) for _ in range(4)]
+    for a in elems:
+        b = elems[int(rng.integers(0, len(elems)))]
+        assert np.array_equal(hs.call("hs_fq12_mul", a, b, out_words=96), oracle.fq12_mul(a, b))
+        assert np.array_equal(hs.call("hs_fq12_sqr", a, out_words=96), oracle.fq12_sqr(a))
+        assert np.array_equal(hs.call("hs_fq12_conj", a, out_words=96), oracle.fq12_unitary_inverse(a))
+        assert np.array_equal(hs.call("hs_fq12_cyclotomic_sqr", a, out_words=96), oracle.fq12_cyclotomic_squared(a))
+        assert np.array_equal(hs.call("hs_fq12_inverse", a, out_words=96), oracle.fq12_inverse(a))
+        for p in (1, 2, 3):
+            assert np.array_equal(hs.call("hs_fq12_frobenius", a, p, out_words=96), oracle.fq12_frobenius_map(a, p))
+        l = _rf(oracle, rng, 6)
+        assert np.array_equal(hs.call("hs_fq12_mul_by_024", a, l[:8], l[8:16], l[16:], out_words=96),
+                              oracle.fq12_mul_by_024(a, l[:8], l[8:16], l[16:]))
+
+
+def test_kats_through_engine(oracle, hs, kats):
+    """the reference's own known answers, computed by the engine's code (fields/mod.rs:171-201, groups/mod.rs:522-547,773-796)"""
+    I = lambda l: [int(x) for x in l]
+    e = hs.call("hs_fq12_exp_by_neg_z", oracle.fq12_from_ints(kats["test_cyclotomic_exp"]["orig"]), out_words=96)
+    assert oracle.fq12_to_ints(e) == I(kats["test_cyclotomic_exp"]["expected"])
+    k1 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k1"]); k2 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k2"])
+    P = oracle.g1_mul(oracle.g1_one(), k1); Q = oracle.g2_mul(oracle.g2_one(), k2)
+    assert oracle.fq12_to_ints(hs.call("hs_miller", P, Q, out_words=96)) == I(kats["test_miller_loop"]["expected"])
+    assert oracle.fq12_to_ints(hs.call("hs_pairing", P, Q, out_words=96)) == I(kats["test_reduced_pairing"]["expected"])
+
+
+def test_pairing_random_and_edges(oracle, hs):
+    rng = np.random.default_rng(16)
+    scal = [1, 2, M.R_ORD - 1, 3, (1 << 253) % M.R_ORD] + [int.from_bytes(rng.bytes(40), "little") % M.R_ORD for _ in range(6)]
+    for i in range(len(scal)):
+        P = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, scal[i]))
+        Q = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_int(FR, scal[-1 - i]))
+        got = hs.call("hs_pairing", P, Q, out_words=96)
+        assert np.array_equal(got, oracle.pairing(P, Q))
+    # z == 1 inputs (the reference's shortcut, groups/mod.rs:116-120) and infinity (-> one, :766)
+    got = hs.call("hs_pairing", oracle.g1_one(), oracle.g2_one(), out_words=96)
+    assert np.array_equal(got, oracle.pairing(oracle.g1_one(), oracle.g2_one()))
+    one = oracle.fq12_one()
+    assert np.array_equal(hs.call("hs_pairing", oracle.g1_zero(), oracle.g2_one(), out_words=96), one)
+    assert np.array_equal(hs.call("hs_pairing", oracle.g1_one(), oracle.g2_zero(), out_words=96), one)
