@@ -1,0 +1,80 @@
+"""ctypes binding of libbn254_hip.so (include/bn254_hip.h).  Fails loudly when the HIP library or a GPU is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+import pathlib
+import subprocess
+
+HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = HERE / "libbn254_hip.so"
+SRC = HERE / "csrc" / "bn254_hip.hip"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+_VP = C.c_void_p
+_SZ = C.c_size_t
+
+SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
+    "bn254_device_count": [],
+    "bn254_ctx_create": [C.c_int, C.POINTER(_VP)],
+    "bn254_ctx_destroy": [_VP],
+    "bn254_error_string": [C.c_int],
+    "bn254_ctx_set_mapping": [_VP, C.c_int],
+    "bn254_pairing_batch": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_pairing_product": [_VP, _VP, _VP, _SZ, _VP],
+    "bn254_g1_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_g2_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_pairing_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
+    "bn254_miller_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
+    "bn254_final_exp_batch_dev": [_VP, _VP, _VP, _SZ, _VP],
+    "bn254_gt_product_dev": [_VP, _VP, _SZ, _VP, _VP],
+    "bn254_miller_product_dev": [_VP, _VP, _VP, _SZ, _VP, _VP],
+    "bn254_g1_mul_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
+    "bn254_g2_mul_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
+    "bn254_g1_mul_jacobian_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
+    "bn254_g2_mul_jacobian_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
+    "bn254_profile_enable": [_VP, C.c_int],
+    "bn254_profile_reset": [_VP],
+    "bn254_kernel_stats": [_VP, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
+}
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU; the .so is kept in-tree so it travels to the GPU box."""
+    deps = [SRC] + sorted((HERE / "csrc").glob("*.hpp")) + [HERE.parent / "include" / "bn254_hip.h"]
+    if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           str(SRC), "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950).  bn_amd has no CPU fallback.")
+        l = C.CDLL(str(LIB_PATH))
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)            # AttributeError if the library does not export a declared symbol
+            fn.argtypes = args
+            fn.restype = C.c_int
+        l.bn254_error_string.restype = C.c_char_p
+        l.bn254_ctx_destroy.restype = None
+        _lib = l
+    return _lib
+
+
+class Bn254Error(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise Bn254Error(f"bn254_hip error {rc}: {lib().bn254_error_string(rc).decode()}")

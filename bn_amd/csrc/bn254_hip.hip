@@ -1,0 +1,397 @@
+// MI355X (gfx950) kernels and the C ABI of the batched BN254 pairing engine (include/bn254_hip.h).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC bn254_hip.hip -o libbn254_hip.so
+//
+// Kernels (one wave = 64 lanes, no cross-lane traffic in mapping A, DPP lane-pair exchange in mapping B):
+//   bn254_miller_*      G1/G2 Jacobian -> affine (Fermat inversions) -> fused Miller loop -> Fq12 (infinity -> one)
+//   bn254_final_exp_*   Fq12 -> Gt
+//   bn254_gt_product    Fq12 product tree (multi-pairing)
+//   bn254_g1_mul / bn254_g2_mul   G * Fr by the reference's double-and-add chain, optionally normalized
+// All global-memory traffic is the algorithmic input/output (672 B per pairing) plus, in mapping A, private-memory
+// (scratch) traffic for the Fq12-sized temporaries; see DESIGN.md for the measured numbers.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bn254_hip.h"
+#include "curve.hpp"
+#include "io.hpp"
+
+using namespace bn254;
+
+// ======================================================================================================== kernels
+namespace {
+
+constexpr int BLOCK = 64;
+
+template <class F2>
+__device__ __forceinline__ void miller_body(const uint32_t *__restrict__ g1, const uint32_t *__restrict__ g2, uint32_t *__restrict__ f_out) {
+    uint32_t w1[24], w2[48];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) w1[i] = g1[i];
+#pragma unroll
+    for (int i = 0; i < 48; ++i) w2[i] = g2[i];
+    bool inf = words_all_zero(w1 + 16, 8) || words_all_zero(w2 + 32, 16);        // groups/mod.rs:766
+    G1Aff<Fe> p = g1_to_affine(fe_from_u32x8(w1), fe_from_u32x8(w1 + 8), fe_from_u32x8(w1 + 16));
+    G2Aff<F2> q = g2_to_affine(f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32));
+    Fq12<F2> f = miller_loop(p, q);
+    uint32_t o[96];
+    f12_store(f, o);
+    // Gt::one() in the reference image: c0.c0.c0 = R mod q, everything else 0
+    uint32_t one[8];
+    fe_to_u32x8(fe_one(), one);
+#pragma unroll
+    for (int i = 0; i < 96; ++i) f_out[i] = inf ? (i < 8 ? one[i] : 0u) : o[i];
+}
+
+__global__ void __launch_bounds__(BLOCK) bn254_miller_A(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    miller_body<Fq2A>(g1 + 24u * idx, g2 + 48u * idx, f_out + 96u * idx);
+}
+
+__global__ void __launch_bounds__(BLOCK) bn254_final_exp_A(const uint32_t *f_in, uint32_t *out, uint32_t n) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    uint32_t w[96];
+#pragma unroll
+    for (int i = 0; i < 96; ++i) w[i] = f_in[96u * idx + i];
+    Fq12<Fq2A> f = final_exponentiation(f12_load<Fq2A>(w));
+    f12_store(f, w);
+#pragma unroll
+    for (int i = 0; i < 96; ++i) out[96u * idx + i] = w[i];
+}
+
+// out[t] = product of in[t*chunk .. min(n,(t+1)*chunk))   (one Fq12 chain per lane; 3 levels reduce 2^18 values)
+__global__ void __launch_bounds__(BLOCK) bn254_gt_product_A(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t chunk) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint64_t lo = (uint64_t)t * chunk;
+    if (lo >= n) return;
+    uint64_t hi = lo + chunk < n ? lo + chunk : n;
+    uint32_t w[96];
+#pragma unroll
+    for (int i = 0; i < 96; ++i) w[i] = in[96u * lo + i];
+    Fq12<Fq2A> acc = f12_load<Fq2A>(w);
+    for (uint64_t j = lo + 1; j < hi; ++j) {
+#pragma unroll
+        for (int i = 0; i < 96; ++i) w[i] = in[96u * j + i];
+        acc = f12_mul(acc, f12_load<Fq2A>(w));
+    }
+    f12_store(acc, w);
+#pragma unroll
+    for (int i = 0; i < 96; ++i) out[96u * t + i] = w[i];
+}
+
+template <class F, int W, class LD, class ST>
+__device__ __forceinline__ void mul_body(const uint32_t *pt, const uint32_t *km, uint32_t *out, int normalize, LD ld, ST st) {
+    uint32_t kw[8], raw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kw[i] = km[i];
+    fr_from_mont(kw, raw);
+    uint32_t w[3 * W];
+#pragma unroll
+    for (int i = 0; i < 3 * W; ++i) w[i] = pt[i];
+    Jac<F> p = {ld(w), ld(w + W), ld(w + 2 * W)};
+    Jac<F> r = scalar_mul_reference_chain<F>(p, raw);
+    if (normalize) r = jac_normalize<F>(r);
+    st(r.x, w); st(r.y, w + W); st(r.z, w + 2 * W);
+#pragma unroll
+    for (int i = 0; i < 3 * W; ++i) out[i] = w[i];
+}
+__global__ void __launch_bounds__(BLOCK) bn254_g1_mul_k(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    mul_body<FqField, 8>(p + 24u * idx, k + 8u * idx, out + 24u * idx, normalize,
+                         [](const uint32_t *w) { return fe_from_u32x8(w); }, [](const Fe &a, uint32_t *w) { fe_to_u32x8(a, w); });
+}
+__global__ void __launch_bounds__(BLOCK) bn254_g2_mul_k(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    mul_body<Fq2Field<Fq2A>, 16>(p + 48u * idx, k + 8u * idx, out + 48u * idx, normalize,
+                                 [](const uint32_t *w) { return f2_load((const Fq2A *)nullptr, w); }, [](const Fq2A &a, uint32_t *w) { f2_store(a, w); });
+}
+
+}  // namespace
+
+// ======================================================================================================== host side
+struct bn254_ctx {
+    int device = 0;
+    int mapping = 0;
+    hipStream_t stream = nullptr;       // used by the host-buffer entry points
+    void *ws = nullptr;                 // workspace (Miller values, product-tree levels)
+    size_t ws_bytes = 0;
+    bool profile = false;
+    struct Rec { std::string name; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                         \
+    do {                                      \
+        hipError_t e__ = (expr);              \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+std::mutex g_default_mu;
+bn254_ctx *g_default = nullptr;
+
+int get_ctx(bn254_ctx *&ctx) {
+    if (ctx) return BN254_OK;
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return BN254_E_NO_DEVICE;
+        int rc = bn254_ctx_create(dev, &g_default);
+        if (rc) return rc;
+    }
+    ctx = g_default;
+    return BN254_OK;
+}
+int ensure_ws(bn254_ctx *c, size_t bytes) {
+    if (c->ws_bytes >= bytes) return BN254_OK;
+    if (c->ws) { HIP_TRY(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+    if (hipMalloc(&c->ws, bytes) != hipSuccess) return BN254_E_ALLOC;
+    c->ws_bytes = bytes;
+    return BN254_OK;
+}
+struct Scope {      // brackets one kernel launch with events when profiling is on
+    bn254_ctx *c; hipStream_t s; bool on; hipEvent_t a, b; const char *name;
+    Scope(bn254_ctx *c_, hipStream_t s_, const char *n) : c(c_), s(s_), on(c_->profile), name(n) {
+        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    }
+    ~Scope() {
+        if (on) { hipEventRecord(b, s); c->recs.push_back({name, a, b}); }
+    }
+};
+inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+int launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s) {
+    Scope sc(c, s, "miller");
+    hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
+    return (int)hipGetLastError();
+}
+int launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s) {
+    Scope sc(c, s, "final_exp");
+    hipLaunchKernelGGL(bn254_final_exp_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
+    return (int)hipGetLastError();
+}
+// reduces n Fq12 values at `in` to one at `out` using ping-pong space `tmp` (>= 2 * ceil(n/64) * 384 B)
+int launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s) {
+    const uint32_t chunk = 64;
+    const uint32_t *src = (const uint32_t *)in;
+    size_t level_cap = (n + chunk - 1) / chunk;
+    uint32_t *bufA = (uint32_t *)tmp, *bufB = (uint32_t *)tmp + 96 * level_cap;
+    bool useA = true;
+    while (true) {
+        size_t m = (n + chunk - 1) / chunk;
+        uint32_t *dst = (m == 1) ? (uint32_t *)out : (useA ? bufA : bufB);
+        {
+            Scope sc(c, s, "gt_product");
+            hipLaunchKernelGGL(bn254_gt_product_A, dim3(grid_for(m)), dim3(BLOCK), 0, s, src, dst, (uint32_t)n, chunk);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        if (m == 1) break;
+        src = dst; n = m; useA = !useA;
+    }
+    return BN254_OK;
+}
+size_t product_tmp_bytes(size_t n) { return 2 * ((n + 63) / 64) * 384 + 384; }
+
+}  // namespace
+
+extern "C" {
+
+int bn254_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int bn254_ctx_create(int device, bn254_ctx **out) {
+    if (!out) return BN254_E_BAD_ARG;
+    int n = bn254_device_count();
+    if (n <= 0 || device < 0 || device >= n) return BN254_E_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    bn254_ctx *c = new bn254_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return (int)e; }
+    *out = c;
+    return BN254_OK;
+}
+void bn254_ctx_destroy(bn254_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    for (auto &r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (c->ws) hipFree(c->ws);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+const char *bn254_error_string(int code) {
+    switch (code) {
+        case BN254_OK: return "ok";
+        case BN254_E_NO_DEVICE: return "no usable HIP device (this engine has no CPU fallback)";
+        case BN254_E_BAD_ARG: return "bad argument";
+        case BN254_E_ALLOC: return "device allocation failed";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping) {
+    if (!ctx || (mapping != 0 && mapping != 1)) return BN254_E_BAD_ARG;
+    ctx->mapping = mapping;
+    return BN254_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- device-resident API
+int bn254_miller_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_f, size_t n, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_p || !d_q || !d_f || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return launch_miller(ctx, d_p, d_q, d_f, n, (hipStream_t)stream);
+}
+int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size_t n, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_f || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return launch_final_exp(ctx, d_f, d_out, n, (hipStream_t)stream);
+}
+int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_out, size_t n, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_p || !d_q || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // the Miller values are written to d_out and exponentiated in place (same 384-byte slots)
+    rc = launch_miller(ctx, d_p, d_q, d_out, n, (hipStream_t)stream); if (rc) return rc;
+    return launch_final_exp(ctx, d_out, d_out, n, (hipStream_t)stream);
+}
+int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (!d_out || (n && !d_in) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) {       // empty product = one
+        bn_gt one; memset(&one, 0, sizeof one);
+        one.c[0] = 0xd35d438dc58f0d9dull; one.c[1] = 0x0a78eb28f5c70b3dull; one.c[2] = 0x666ea36f7879462cull; one.c[3] = 0x0e0a77c19a07df2full;
+        HIP_TRY(hipMemcpyAsync(d_out, &one, sizeof one, hipMemcpyHostToDevice, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        return BN254_OK;
+    }
+    rc = ensure_ws(ctx, product_tmp_bytes(n)); if (rc) return rc;
+    return launch_product(ctx, d_in, n, d_out, ctx->ws, (hipStream_t)stream);
+}
+int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (!d_partial || (n && (!d_p || !d_q)) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    if (n == 0) return bn254_gt_product_dev(ctx, nullptr, 0, d_partial, stream);
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t fbytes = n * 384;
+    rc = ensure_ws(ctx, fbytes + product_tmp_bytes(n)); if (rc) return rc;
+    rc = launch_miller(ctx, d_p, d_q, ctx->ws, n, (hipStream_t)stream); if (rc) return rc;
+    return launch_product(ctx, ctx->ws, n, d_partial, (char *)ctx->ws + fbytes, (hipStream_t)stream);
+}
+static int mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream, int normalize) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_p || !d_k || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Scope sc(ctx, (hipStream_t)stream, g == 1 ? "g1_mul" : "g2_mul");
+    if (g == 1)
+        hipLaunchKernelGGL(bn254_g1_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
+    else
+        hipLaunchKernelGGL(bn254_g2_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
+    return (int)hipGetLastError();
+}
+int bn254_g1_mul_batch_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 1, p, k, o, n, s, 1); }
+int bn254_g2_mul_batch_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 2, p, k, o, n, s, 1); }
+int bn254_g1_mul_jacobian_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 1, p, k, o, n, s, 0); }
+int bn254_g2_mul_jacobian_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 2, p, k, o, n, s, 0); }
+
+// ---------------------------------------------------------------------------------------------- host-buffer API
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? BN254_OK : BN254_E_ALLOC; }
+};
+}
+int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!p || !q || !out) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf dp, dq, dout;
+    if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
+    HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
+    rc = bn254_pairing_batch_dev(ctx, dp.p, dq.p, dout.p, n, ctx->stream); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (!out || (n && (!p || !q))) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf dp, dq, dpart;
+    if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dpart.alloc(sizeof(bn_gt)))) return rc;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
+    }
+    // FE is a homomorphism: FE(prod miller_i) = prod FE(miller_i); one final exponentiation for the whole product
+    rc = bn254_miller_product_dev(ctx, dp.p, dq.p, n, dpart.p, ctx->stream); if (rc) return rc;
+    rc = bn254_final_exp_batch_dev(ctx, dpart.p, dpart.p, 1, ctx->stream); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dpart.p, sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+static int mul_host(bn254_ctx *ctx, int g, const void *p, const bn_fr *k, void *out, size_t n) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!p || !k || !out) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
+    DevBuf dp, dk, dout;
+    if ((rc = dp.alloc(n * ps)) || (rc = dk.alloc(n * sizeof(bn_fr))) || (rc = dout.alloc(n * ps))) return rc;
+    HIP_TRY(hipMemcpyAsync(dp.p, p, n * ps, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dk.p, k, n * sizeof(bn_fr), hipMemcpyHostToDevice, ctx->stream));
+    rc = mul_dev(ctx, g, dp.p, dk.p, dout.p, n, ctx->stream, 1); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n * ps, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n) { return mul_host(ctx, 1, p, k, out, n); }
+int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n) { return mul_host(ctx, 2, p, k, out, n); }
+
+// ---------------------------------------------------------------------------------------------- measurement
+int bn254_profile_enable(bn254_ctx *ctx, int on) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    ctx->profile = on != 0;
+    return BN254_OK;
+}
+int bn254_profile_reset(bn254_ctx *ctx) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    ctx->recs.clear();
+    return BN254_OK;
+}
+int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (!kernel || !total_ms || !launches) return BN254_E_BAD_ARG;
+    double tot = 0; uint64_t cnt = 0;
+    for (auto &r : ctx->recs) {
+        if (r.name != kernel) continue;
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms; ++cnt;
+    }
+    *total_ms = tot; *launches = cnt;
+    return BN254_OK;
+}
+
+}  // extern "C"

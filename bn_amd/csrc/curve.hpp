@@ -1,0 +1,149 @@
+// Jacobian group arithmetic on G1 (over Fq) and G2 (over Fq2) and scalar multiplication by an Fr, for the HIP engine.
+// Reference: src/groups/mod.rs - double :228-247 (dbl-2009-l, a = 0), add :275-311 (add-2007-bl with the zero / equal-point
+// branches), Mul<Fr> :250-270 (MSB-first double-and-add on the scalar taken OUT of Montgomery form, fields/fp.rs:15-22),
+// to_affine :113-130, normalize lib.rs:88-95.
+//
+// Two products:
+//   * scalar_mul_reference_chain: executes exactly the reference's operation sequence, so the (non-canonical) Jacobian
+//     coordinates it returns are the very limbs `G::random` / `G * Fr` produce in the reference.  Used to build benchmark
+//     inputs with z != 1 on the device.
+//   * the caller may normalize (x/z^2, y/z^3, 1) - the parity definition for `g*_mul_batch`.
+#pragma once
+#include "pairing.hpp"
+
+namespace bn254 {
+
+// ---- field adaptors: the same generic point code runs over Fe (G1) and over an Fq2 mapping (G2) -------------------------
+struct FqField {
+    using T = Fe;
+    static BN_FN T mul(const T &a, const T &b) { return fe_mul(a, b); }
+    static BN_FN T sqr(const T &a) { return fe_sqr(a); }
+    template <int C1, int C2, int C3> static BN_FN T lc3(const T &x, const T &y, const T &z) { return fe_lc3<C1, C2, C3>(x, y, z); }
+    static BN_FN T zero() { return fe_zero(); }
+    static BN_FN T one() { return fe_one(); }
+    static BN_FN T select(bool b, const T &x, const T &y) { return fe_select(b, x, y); }
+    static BN_FN bool is_zero(const T &a) { return fe_is_zero(a); }
+    static BN_FN T inverse(const T &a) { return fe_inverse(a); }
+};
+template <class F2>
+struct Fq2Field {
+    using T = F2;
+    static BN_FN T mul(const T &a, const T &b) { return f2_mul(a, b); }
+    static BN_FN T sqr(const T &a) { return f2_sqr(a); }
+    template <int C1, int C2, int C3> static BN_FN T lc3(const T &x, const T &y, const T &z) { return f2_lc3<C1, C2, C3>(x, y, z); }
+    static BN_FN T zero() { return f2_zero((const F2 *)nullptr); }
+    static BN_FN T one() { return f2_one((const F2 *)nullptr); }
+    static BN_FN T select(bool b, const T &x, const T &y) { return f2_select(b, x, y); }
+    static BN_FN bool is_zero(const T &a) { return f2_is_zero(a); }
+    static BN_FN T inverse(const T &a) { return f2_inverse(a); }
+};
+
+template <class F> struct Jac { typename F::T x, y, z; };
+
+// groups/mod.rs:228-247
+template <class F>
+BN_COARSE Jac<F> jac_double(const Jac<F> &p) {
+    using T = typename F::T;
+    T a = F::sqr(p.x), b = F::sqr(p.y), c = F::sqr(b);
+    T t = F::sqr(F::template lc3<1, 1, 0>(p.x, b, b));
+    T d = F::template lc3<2, -2, -2>(t, a, c);
+    T e = F::template lc3<3, 0, 0>(a, a, a);
+    T f = F::sqr(e);
+    Jac<F> r;
+    r.x = F::template lc3<1, -2, 0>(f, d, d);
+    r.y = F::template lc3<1, -8, 0>(F::mul(e, F::template lc3<1, -1, 0>(d, r.x, d)), c, c);
+    r.z = F::template lc3<2, 0, 0>(F::mul(p.y, p.z), p.y, p.y);
+    return r;
+}
+// groups/mod.rs:275-311, all branches (zero operands, equal points) as per-lane selects; the doubling for equal points is a
+// divergent branch that no lane takes for valid prime-order inputs and scalars < r
+template <class F>
+BN_COARSE Jac<F> jac_add(const Jac<F> &p, const Jac<F> &q) {
+    using T = typename F::T;
+    bool pz = F::is_zero(p.z), qz = F::is_zero(q.z);
+    T z1s = F::sqr(p.z), z2s = F::sqr(q.z);
+    T u1 = F::mul(p.x, z2s), u2 = F::mul(q.x, z1s);
+    T s1 = F::mul(p.y, F::mul(q.z, z2s)), s2 = F::mul(q.y, F::mul(p.z, z1s));
+    T h = F::template lc3<1, -1, 0>(u2, u1, u1), sd = F::template lc3<1, -1, 0>(s2, s1, s1);
+    bool same = F::is_zero(h) && F::is_zero(sd) && !pz && !qz;
+    T i = F::sqr(F::template lc3<2, 0, 0>(h, h, h));
+    T j = F::mul(h, i);
+    T rr = F::template lc3<2, 0, 0>(sd, sd, sd);
+    T v = F::mul(u1, i);
+    Jac<F> r;
+    r.x = F::template lc3<1, -1, -2>(F::sqr(rr), j, v);
+    r.y = F::template lc3<1, -2, 0>(F::mul(rr, F::template lc3<1, -1, 0>(v, r.x, v)), F::mul(s1, j), j);
+    r.z = F::mul(F::template lc3<1, -1, -1>(F::sqr(F::template lc3<1, 1, 0>(p.z, q.z, q.z)), z1s, z2s), h);
+    if (same) {                                    // groups/mod.rs:291-292
+        Jac<F> d = jac_double(p);
+        r.x = F::select(same, r.x, d.x); r.y = F::select(same, r.y, d.y); r.z = F::select(same, r.z, d.z);
+    }
+    r.x = F::select(qz, r.x, p.x); r.y = F::select(qz, r.y, p.y); r.z = F::select(qz, r.z, p.z);     // :280-282
+    r.x = F::select(pz, r.x, q.x); r.y = F::select(pz, r.y, q.y); r.z = F::select(pz, r.z, q.z);     // :276-278
+    return r;
+}
+
+// Fr out of Montgomery form (fields/fp.rs:15-22: multiply by 1): 8 x u32 words, word-serial Montgomery reduction mod r
+BN_FN void fr_from_mont(const uint32_t *km, uint32_t *raw) {
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = km[i];
+    t[8] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t m = t[0] * k::FR_INV32;
+        uint64_t c = ((uint64_t)m * k::FR_MOD32[0] + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            uint64_t x = (uint64_t)m * k::FR_MOD32[j] + t[j] + c;
+            t[j - 1] = (uint32_t)x;
+            c = x >> 32;
+        }
+        uint64_t x = (uint64_t)t[8] + c;
+        t[7] = (uint32_t)x;
+        t[8] = (uint32_t)(x >> 32);
+    }
+    // t < 2r; one conditional subtraction
+    uint32_t d[8];
+    int64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int64_t s = (int64_t)t[i] - (int64_t)k::FR_MOD32[i] + br;
+        d[i] = (uint32_t)s;
+        br = s >> 32;
+    }
+    bool ge = (t[8] != 0) || (br == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) raw[i] = ge ? d[i] : t[i];
+}
+
+// groups/mod.rs:250-270: res = 0; for bits MSB->LSB { if found { res = 2 res }; if bit { found = true; res = res + p } }.
+// Per-lane scalars differ, so `found`/`bit` are per-lane predicates applied by selects; the op sequence each lane's result
+// went through is exactly the reference's.
+template <class F>
+BN_FN Jac<F> scalar_mul_reference_chain(const Jac<F> &p, const uint32_t *k_raw) {
+    Jac<F> res = {F::zero(), F::one(), F::zero()};           // groups/mod.rs:208-214
+    bool found = false;
+#pragma unroll 1
+    for (int i = 255; i >= 0; --i) {
+        Jac<F> d = jac_double(res);
+        res.x = F::select(found, res.x, d.x); res.y = F::select(found, res.y, d.y); res.z = F::select(found, res.z, d.z);
+        bool bit = (k_raw[i >> 5] >> (i & 31)) & 1;
+        Jac<F> s = jac_add(res, p);
+        res.x = F::select(bit, res.x, s.x); res.y = F::select(bit, res.y, s.y); res.z = F::select(bit, res.z, s.z);
+        found = found || bit;
+    }
+    return res;
+}
+// lib.rs:88-95 (normalize): (x/z^2, y/z^3, 1), infinity unchanged
+template <class F>
+BN_FN Jac<F> jac_normalize(const Jac<F> &p) {
+    using T = typename F::T;
+    bool inf = F::is_zero(p.z);
+    T zi = F::inverse(p.z), zi2 = F::sqr(zi);
+    Jac<F> r = {F::mul(p.x, zi2), F::mul(p.y, F::mul(zi2, zi)), F::one()};
+    r.x = F::select(inf, r.x, p.x); r.y = F::select(inf, r.y, p.y); r.z = F::select(inf, r.z, p.z);
+    return r;
+}
+
+}  // namespace bn254

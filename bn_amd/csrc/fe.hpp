@@ -18,14 +18,26 @@
 #pragma once
 #include <stdint.h>
 
+// BN_FN     small glue, always inlined
+// BN_LEAF   the multiplier-sized leaves (fe_mul, fe_mul2, fe_lc3, fe_inverse): real functions on the GPU (operands travel in
+//           VGPRs: an Fe is 9 dwords, under the 16-dword by-value limit of the AMDGPU calling convention), so the hot code
+//           of a whole pairing stays inside the instruction cache instead of being replicated 19 000 times
+// BN_COARSE Fq6/Fq12-sized steps: real functions too; their operands live in private (scratch) memory in the one-lane
+//           mapping and in VGPRs in the lane-pair mapping
 #if defined(BN_HOSTSIM)
 #define BN_FN inline
-#define BN_NOINLINE __attribute__((noinline))
+#define BN_LEAF inline
+#define BN_COARSE inline
 #define BN254_CONSTANT constexpr
 #else
 #include <hip/hip_runtime.h>
 #define BN_FN __device__ __forceinline__
-#define BN_NOINLINE __device__ __noinline__
+#ifndef BN_LEAF
+#define BN_LEAF __device__ __noinline__ inline
+#endif
+#ifndef BN_COARSE
+#define BN_COARSE __device__ __noinline__ inline
+#endif
 #define BN254_CONSTANT __device__ constexpr
 #endif
 #include "bn254_constants.hpp"
@@ -176,7 +188,7 @@ BN_FN Fe fe_reduce(const Fe &a) {
 // of the tower (Karatsuba recombination, multiplication by xi = 9+i) gets back to standard form; the reference spends a
 // conditional add/subtract per Fq add instead (arith.rs:238-253).  Result: normalized limbs, value < 3q.
 template <int C1, int C2, int C3>
-BN_FN Fe fe_lc3(const Fe &x, const Fe &y, const Fe &z) {
+BN_LEAF Fe fe_lc3(const Fe &x, const Fe &y, const Fe &z) {
     constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3;
     BN_REQUIRE((C1 == 0 || x.lb <= 8) && (C2 == 0 || y.lb <= 8) && (C3 == 0 || z.lb <= 8), "fe_lc3 lb");
     BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb <= 1000, "fe_lc3 vb");
@@ -208,7 +220,7 @@ BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any l
 // :257-263).  One 64-bit accumulator per column, 81 + 81 v_mad_u64_u32, no carry instructions.
 // Column bound: 9*(la*lb) * 2^58 + 9 * 2^58 + carry < 2^64  <=>  la*lb <= 6.
 // Value: result < (A*B/169.3 + 1) q, so A*B <= 169 gives < 2q.
-BN_FN Fe fe_mul(const Fe &a, const Fe &b) {
+BN_LEAF Fe fe_mul(const Fe &a, const Fe &b) {
     BN_REQUIRE(a.lb * b.lb <= 6, "fe_mul column overflow");
     BN_REQUIRE(a.vb * b.vb <= 169, "fe_mul value bound");
     uint64_t acc = 0;
@@ -240,7 +252,7 @@ BN_FN Fe fe_mul(const Fe &a, const Fe &b) {
 BN_FN Fe fe_sqr(const Fe &a) { return fe_mul(a, a); }
 
 // (a*u + c*v) / R with ONE reduction: 162 + 81 mads.   Column bound: la*lu + lc*lv <= 6; value: A*U + C*V <= 169.
-BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
+BN_LEAF Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
     BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 6, "fe_mul2 column overflow");
     BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 169, "fe_mul2 value bound");
     uint64_t acc = 0;
@@ -343,7 +355,7 @@ BN_FN Fe fe_select(bool take_b, const Fe &a, const Fe &b) {
 
 // a^(q-2) (Fermat).  Uniform across lanes; replaces the data-dependent binary EEA of arith.rs:281-327 + fp.rs:103-112.
 // The inverse is unique mod q, so after canonicalisation the bytes equal the reference's.  inverse(0) = 0.
-BN_FN Fe fe_inverse(const Fe &a_in) {
+BN_LEAF Fe fe_inverse(const Fe &a_in) {
     Fe a = a_in;
     BN_REQUIRE(a.lb <= 2 && a.vb <= 8, "fe_inverse input");
     Fe r = fe_one();

@@ -42,6 +42,7 @@ BN_FN Fq2A f2_zero(const Fq2A *) { return {fe_zero(), fe_zero()}; }
 BN_FN Fq2A f2_one(const Fq2A *) { return {fe_one(), fe_zero()}; }
 template <class T>
 BN_FN Fq2A f2_const(const Fq2A *, const T &tab) { return {fe_const(tab[0]), fe_const(tab[1])}; }
+BN_FN bool f2_is_zero(const Fq2A &a) { return fe_is_zero(a.c0) & fe_is_zero(a.c1); }
 BN_FN Fq2A f2_select(bool take_b, const Fq2A &a, const Fq2A &b) { return {fe_select(take_b, a.c0, b.c0), fe_select(take_b, a.c1, b.c1)}; }
 
 // a: lb <= 2, vb <= 6;  b: S

@@ -19,7 +19,7 @@ template <class F2> struct Line { F2 ell_0, ell_vw, ell_vv; };  // ell_vw / ell_
 
 // groups/mod.rs:612-634.   e = 3b' * z^2 folds the reference's d = 3c, e = b'*d into one constant product.
 template <class F2>
-BN_FN Line<F2> doubling_step(G2Proj<F2> &r) {
+BN_COARSE Line<F2> doubling_step(G2Proj<F2> &r) {
     F2 a = f2_scale(f2_mul(r.x, r.y), fe_const(k::TWO_INV));
     F2 b = f2_sqr(r.y), c = f2_sqr(r.z);
     F2 e = f2_mul_const(c, k::G2_3B);
@@ -38,7 +38,7 @@ BN_FN Line<F2> doubling_step(G2Proj<F2> &r) {
 }
 // groups/mod.rs:592-610
 template <class F2>
-BN_FN Line<F2> addition_step(G2Proj<F2> &r, const G2Aff<F2> &base) {
+BN_COARSE Line<F2> addition_step(G2Proj<F2> &r, const G2Aff<F2> &base) {
     F2 d = f2_lc3<1, -1, 0>(r.x, f2_mul(r.z, base.x), r.x);
     F2 e = f2_lc3<1, -1, 0>(r.y, f2_mul(r.z, base.y), r.y);
     F2 f = f2_sqr(d), g = f2_sqr(e);
@@ -56,7 +56,7 @@ BN_FN Line<F2> addition_step(G2Proj<F2> &r, const G2Aff<F2> &base) {
 }
 // groups/mod.rs:550-555
 template <class F2>
-BN_FN G2Aff<F2> mul_by_q(const G2Aff<F2> &a) {
+BN_COARSE G2Aff<F2> mul_by_q(const G2Aff<F2> &a) {
     return {f2_mul_const(f2_conj_lazy(a.x), k::TWIST_MUL_BY_Q_X), f2_mul_const(f2_conj_lazy(a.y), k::TWIST_MUL_BY_Q_Y)};
 }
 // f <- f * line(P)   (groups/mod.rs:502,507,513,516)
@@ -91,7 +91,7 @@ BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q) {
 
 // fq12.rs:229-246 + 97-101: f^u by square-and-multiply (u has 63 bits, top bit consumed by res = f), then conjugate
 template <class F2>
-BN_FN Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
+BN_COARSE Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
     Fq12<F2> res = f;
 #pragma unroll 1
     for (int i = 61; i >= 0; --i) {

@@ -31,7 +31,7 @@ template <class F2> BN_FN Fq6<F2> f6_mul_by_v(const Fq6<F2> &a) { return {f2_mul
 
 // fq6.rs:144-158: 6 Fq2 products (Karatsuba), the two xi-multiplications folded into the final reductions
 template <class F2>
-BN_FN Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
+BN_COARSE Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
     F2 aa = f2_mul(a.c0, b.c0), bb = f2_mul(a.c1, b.c1), cc = f2_mul(a.c2, b.c2);
     F2 t0 = f2_mul(f2_add(a.c1, a.c2), f2_norm(f2_add(b.c1, b.c2)));
     F2 t1 = f2_mul(f2_add(a.c0, a.c1), f2_norm(f2_add(b.c0, b.c1)));
@@ -46,7 +46,7 @@ BN_FN Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
 }
 // fq6.rs:113-127 (CH-SQR2)
 template <class F2>
-BN_FN Fq6<F2> f6_sqr(const Fq6<F2> &a) {
+BN_COARSE Fq6<F2> f6_sqr(const Fq6<F2> &a) {
     F2 s0 = f2_sqr(a.c0), ab = f2_mul(a.c0, a.c1);
     F2 s2 = f2_sqr(f2_lc3<1, -1, 1>(a.c0, a.c1, a.c2));
     F2 bc = f2_mul(a.c1, a.c2), s4 = f2_sqr(a.c2);
@@ -69,7 +69,7 @@ BN_FN Fq6<F2> f6_frobenius(const Fq6<F2> &a) {
 }
 // fq6.rs:129-141
 template <class F2>
-BN_FN Fq6<F2> f6_inverse(const Fq6<F2> &a) {
+BN_COARSE Fq6<F2> f6_inverse(const Fq6<F2> &a) {
     F2 c0 = f2_lc3<1, -1, 0>(f2_sqr(a.c0), f2_mul(a.c1, f2_mul_xi(a.c2)), a.c0);
     F2 c1 = f2_lc_xi<1, -1>(f2_sqr(a.c2), f2_mul(a.c0, a.c1));
     F2 c2 = f2_lc3<1, -1, 0>(f2_sqr(a.c1), f2_mul(a.c0, a.c2), a.c0);
@@ -82,7 +82,7 @@ BN_FN Fq6<F2> f6_inverse(const Fq6<F2> &a) {
 template <class F2> BN_FN Fq12<F2> f12_one() { return {f6_one<F2>(), f6_zero<F2>()}; }
 // fq12.rs:295-307
 template <class F2>
-BN_FN Fq12<F2> f12_mul(const Fq12<F2> &a, const Fq12<F2> &b) {
+BN_COARSE Fq12<F2> f12_mul(const Fq12<F2> &a, const Fq12<F2> &b) {
     Fq6<F2> aa = f6_mul(a.c0, b.c0), bb = f6_mul(a.c1, b.c1);
     Fq6<F2> t = f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1));
     Fq12<F2> r;
@@ -94,7 +94,7 @@ BN_FN Fq12<F2> f12_mul(const Fq12<F2> &a, const Fq12<F2> &b) {
 }
 // fq12.rs:275-282 (complex squaring over Fq6)
 template <class F2>
-BN_FN Fq12<F2> f12_sqr(const Fq12<F2> &a) {
+BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     Fq6<F2> ab = f6_mul(a.c0, a.c1);
     Fq6<F2> u;                                                // v*c1 + c0
     u.c0 = f2_lc_xi<1, 1>(a.c1.c2, a.c0.c0);
@@ -109,10 +109,10 @@ BN_FN Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     return r;
 }
 // fq12.rs:103-105
-template <class F2> BN_FN Fq12<F2> f12_conj(const Fq12<F2> &a) { return {a.c0, f6_neg(a.c1)}; }
+template <class F2> BN_COARSE Fq12<F2> f12_conj(const Fq12<F2> &a) { return {a.c0, f6_neg(a.c1)}; }
 // fq12.rs:284-292
 template <class F2>
-BN_FN Fq12<F2> f12_inverse(const Fq12<F2> &a) {
+BN_COARSE Fq12<F2> f12_inverse(const Fq12<F2> &a) {
     Fq6<F2> s1 = f6_sqr(a.c1);
     Fq6<F2> s0 = f6_sqr(a.c0);
     Fq6<F2> d;                                                // c0^2 - v*c1^2
@@ -124,7 +124,7 @@ BN_FN Fq12<F2> f12_inverse(const Fq12<F2> &a) {
 }
 // fq12.rs:90-95, P in {1,2,3}
 template <int P, class F2>
-BN_FN Fq12<F2> f12_frobenius(const Fq12<F2> &a) {
+BN_COARSE Fq12<F2> f12_frobenius(const Fq12<F2> &a) {
     Fq6<F2> c1 = f6_frobenius<P>(a.c1);
     F2 g = f2_const(F2P, k::FROB12_C1[P]);
     return {f6_frobenius<P>(a.c0), f6_scale(c1, g)};
@@ -132,7 +132,7 @@ BN_FN Fq12<F2> f12_frobenius(const Fq12<F2> &a) {
 
 // fq12.rs:107-176: f * (x0 + x2 v^2 + x4 v w), 13 Fq2 products; (ell_0, ell_vw, ell_vv) -> (x0, x4, x2) as in the reference
 template <class F2>
-BN_FN Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &ell_vw, const F2 &ell_vv) {
+BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &ell_vw, const F2 &ell_vv) {
     const F2 &z0 = f.c0.c0, &z1 = f.c0.c1, &z2 = f.c0.c2, &z3 = f.c1.c0, &z4 = f.c1.c1, &z5 = f.c1.c2;
     const F2 &x0 = ell_0, &x2 = ell_vv, &x4 = ell_vw;
     F2 d0 = f2_mul(z0, x0), d2 = f2_mul(z2, x2), d4 = f2_mul(z4, x4);
@@ -165,7 +165,7 @@ BN_FN void f4_sq(const F2 &a, const F2 &b, F2 &t_even, F2 &tmp_out) {       // (
     tmp_out = tmp;
 }
 template <class F2>
-BN_FN Fq12<F2> f12_cyclotomic_sqr(const Fq12<F2> &f) {
+BN_COARSE Fq12<F2> f12_cyclotomic_sqr(const Fq12<F2> &f) {
     const F2 &z0 = f.c0.c0, &z4 = f.c0.c1, &z3 = f.c0.c2, &z2 = f.c1.c0, &z1 = f.c1.c1, &z5 = f.c1.c2;
     F2 t0, t2, t4, p01, p23, p45;                            // t1 = 2 p01, t3 = 2 p23, t5 = 2 p45
     f4_sq(z0, z1, t0, p01);

@@ -1,0 +1,114 @@
+"""Batch engine over the C ABI.  Arrays are numpy uint64 in the reference's #[repr(C)] layouts:
+   Fr (n,4)  G1 (n,12)  G2 (n,24)  Gt (n,48)   - Montgomery limbs, little endian."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+FR_BYTES, G1_WORDS, G2_WORDS, GT_WORDS = 32, 12, 24, 48
+
+
+def _arr(a, width):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2 or a.shape[1] != width:
+        raise ValueError(f"expected shape (n,{width}) uint64, got {a.shape}")
+    return a
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    """one context = one GPU (include/bn254_hip.h: bn254_ctx)"""
+
+    def __init__(self, device=0, mapping=None):
+        self._lib = _native.lib()
+        if self._lib.bn254_device_count() <= 0:
+            raise _native.Bn254Error("no HIP device: bn_amd has no CPU fallback")
+        h = C.c_void_p()
+        _native.check(self._lib.bn254_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        if mapping is not None:
+            _native.check(self._lib.bn254_ctx_set_mapping(self._h, int(mapping)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bn254_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer API
+    def pairing_batch(self, p, q):
+        p = _arr(p, G1_WORDS); q = _arr(q, G2_WORDS)
+        if p.shape[0] != q.shape[0]:
+            raise ValueError("p and q differ in length")
+        out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        _native.check(self._lib.bn254_pairing_batch(self._h, _p(p), _p(q), _p(out), p.shape[0]))
+        return out
+
+    def pairing_product(self, p, q):
+        p = _arr(p, G1_WORDS) if len(p) else np.zeros((0, G1_WORDS), np.uint64)
+        q = _arr(q, G2_WORDS) if len(q) else np.zeros((0, G2_WORDS), np.uint64)
+        if p.shape[0] != q.shape[0]:
+            raise ValueError("p and q differ in length")
+        out = np.empty(GT_WORDS, np.uint64)
+        _native.check(self._lib.bn254_pairing_product(self._h, _p(p), _p(q), p.shape[0], _p(out)))
+        return out
+
+    def g1_mul_batch(self, p, k):
+        p = _arr(p, G1_WORDS); k = _arr(k, 4)
+        out = np.empty_like(p)
+        _native.check(self._lib.bn254_g1_mul_batch(self._h, _p(p), _p(k), _p(out), p.shape[0]))
+        return out
+
+    def g2_mul_batch(self, p, k):
+        p = _arr(p, G2_WORDS); k = _arr(k, 4)
+        out = np.empty_like(p)
+        _native.check(self._lib.bn254_g2_mul_batch(self._h, _p(p), _p(k), _p(out), p.shape[0]))
+        return out
+
+    # ---- device-resident API: raw device pointers (ints) + hipStream_t (int or 0)
+    def pairing_batch_dev(self, d_p, d_q, d_out, n, stream=0):
+        _native.check(self._lib.bn254_pairing_batch_dev(self._h, d_p, d_q, d_out, n, stream))
+
+    def miller_batch_dev(self, d_p, d_q, d_f, n, stream=0):
+        _native.check(self._lib.bn254_miller_batch_dev(self._h, d_p, d_q, d_f, n, stream))
+
+    def final_exp_batch_dev(self, d_f, d_out, n, stream=0):
+        _native.check(self._lib.bn254_final_exp_batch_dev(self._h, d_f, d_out, n, stream))
+
+    def gt_product_dev(self, d_in, n, d_out, stream=0):
+        _native.check(self._lib.bn254_gt_product_dev(self._h, d_in, n, d_out, stream))
+
+    def miller_product_dev(self, d_p, d_q, n, d_partial, stream=0):
+        _native.check(self._lib.bn254_miller_product_dev(self._h, d_p, d_q, n, d_partial, stream))
+
+    def g1_mul_dev(self, d_p, d_k, d_out, n, stream=0, normalize=True):
+        f = self._lib.bn254_g1_mul_batch_dev if normalize else self._lib.bn254_g1_mul_jacobian_dev
+        _native.check(f(self._h, d_p, d_k, d_out, n, stream))
+
+    def g2_mul_dev(self, d_p, d_k, d_out, n, stream=0, normalize=True):
+        f = self._lib.bn254_g2_mul_batch_dev if normalize else self._lib.bn254_g2_mul_jacobian_dev
+        _native.check(f(self._h, d_p, d_k, d_out, n, stream))
+
+    # ---- measurement
+    def profile(self, on=True):
+        _native.check(self._lib.bn254_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        _native.check(self._lib.bn254_profile_reset(self._h))
+
+    def kernel_stats(self, kernel):
+        ms = C.c_double(); cnt = C.c_uint64()
+        _native.check(self._lib.bn254_kernel_stats(self._h, kernel.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

@@ -1,0 +1,103 @@
+/*
+ * bn254_hip.h - C ABI of the MI355X-native batched BN254 optimal-ate pairing engine.
+ *
+ * Drop-in boundary for the `pairing()` hot path of the reference crate zcash-hackworks/bn v0.4.3.  The reference has no
+ * FFI of its own: its boundary is the public Rust API, whose types are all #[repr(C)] newtype chains, which fixes the
+ * C layouts below (citations are file:line under the reference's src/):
+ *
+ *   bn_fr  = bn::Fr -> fields::Fr -> U256 -> [u64;4]        lib.rs:15-17, fields/fp.rs:11-13, arith.rs:9-11
+ *   bn_g1  = bn::G1 -> G<G1Params>{x,y,z: Fq}               lib.rs:79-81, groups/mod.rs:36-41
+ *   bn_g2  = bn::G2 -> G<G2Params>{x,y,z: Fq2{c0,c1}}       lib.rs:122-124, fields/fq2.rs:24-29
+ *   bn_gt  = bn::Gt -> Fq12{c0,c1: Fq6{c0,c1,c2: Fq2}}      lib.rs:165-167, fields/fq12.rs:26-31, fields/fq6.rs:42-48
+ *
+ * Every Fq/Fr is 4 little-endian u64 limbs holding the Montgomery image a*2^256 mod m, always < m (canonical), exactly
+ * the bytes the reference keeps in memory.  Points are Jacobian (X/Z^2, Y/Z^3); infinity is z == 0.
+ *
+ * Semantics replaced:
+ *   bn254_pairing_batch    out[i] = bn::pairing(p[i], q[i])                         lib.rs:181-183, groups/mod.rs:764-771
+ *   bn254_pairing_product  fold(Gt::one(), |acc,(p,q)| acc * pairing(p,q))          shootout/main.rs:11-16, lib.rs:175-179
+ *   bn254_g1_mul_batch     out[i] = normalize(p[i] * k[i])                          lib.rs:116-120,88-95, groups/mod.rs:250-270
+ *   bn254_g2_mul_batch     same over G2                                             lib.rs:159-163,131-138
+ * Outputs are bit-identical to the reference's on the same inputs (pairing values are canonical field elements; scalar
+ * multiples are compared after `normalize()` because Jacobian coordinates depend on the addition chain).
+ *
+ * Error behaviour: the reference path is infallible for valid points (the `expect` at groups/mod.rs:768 cannot fire);
+ * a point at infinity in either argument gives Gt::one() (groups/mod.rs:766).  So the only failures are device failures:
+ * every function returns 0 on success or a negative BN254_E_* / positive hipError_t code; nothing panics, throws or
+ * aborts across this boundary.  Inputs are trusted to be valid subgroup points exactly as the Rust type system guarantees
+ * for G1/G2 values; behaviour on other limb patterns is unspecified (but memory safe).
+ *
+ * Ownership: the caller owns every buffer passed in; the library owns device memory and streams inside a context and keeps
+ * no pointer after a call returns.  A context is bound to one GPU; calls on one context are serialised by the caller
+ * (use one context per thread / per GPU).  There is NO CPU fallback: without a usable MI355X the calls fail with
+ * BN254_E_NO_DEVICE.
+ */
+#ifndef BN254_HIP_H
+#define BN254_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } bn_fr;                    /* 32 B  */
+typedef struct { uint64_t x[4], y[4], z[4]; } bn_g1;        /* 96 B  */
+typedef struct { uint64_t x[8], y[8], z[8]; } bn_g2;        /* 192 B: each coordinate = (c0[4], c1[4]) */
+typedef struct { uint64_t c[48]; } bn_gt;                   /* 384 B: c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1 */
+
+typedef struct bn254_ctx bn254_ctx;
+
+enum {
+    BN254_OK = 0,
+    BN254_E_NO_DEVICE = -1,     /* no HIP device / device index out of range */
+    BN254_E_BAD_ARG = -2,       /* null pointer with n > 0, n too large */
+    BN254_E_ALLOC = -3          /* device allocation failed */
+    /* positive values are hipError_t codes */
+};
+
+/* ---- contexts ------------------------------------------------------------------------------------------------------ */
+int bn254_device_count(void);
+int bn254_ctx_create(int device, bn254_ctx **out);
+void bn254_ctx_destroy(bn254_ctx *ctx);
+const char *bn254_error_string(int code);
+/* 0: one pairing per lane (Fq2A); 1: one pairing per lane PAIR (Fq2B, the default).  Results are identical. */
+int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping);
+
+/* ---- host-buffer entry points (what a binding of the reference's API calls) ------------------------------------------ */
+/* ctx == NULL uses a process-wide default context on the current HIP device. */
+int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n);
+int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out);
+int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n);
+int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n);
+
+/* ---- device-resident entry points (inputs/outputs already in HBM; `stream` is a hipStream_t or NULL) ------------------ */
+/* Same layouts (array of structs) in device memory.  Asynchronous on `stream`; the caller synchronises. */
+int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_out, size_t n, void *stream);
+/* the two halves of a pairing, for the multi-pairing product: Miller loop only (infinity -> one), then final exponentiation */
+int bn254_miller_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_f, size_t n, void *stream);
+int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size_t n, void *stream);
+/* d_out[0] = product of d_in[0..n) in Fq12 (lib.rs:175-179 semantics; order-independent because Fq12 is commutative) */
+int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream);
+/* local part of a sharded multi-pairing: un-exponentiated product of the Miller values of n pairs -> one Fq12 */
+int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream);
+int bn254_g1_mul_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
+int bn254_g2_mul_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
+/* raw Jacobian result of the reference's MSB-first double-and-add (what G::random produces, groups/mod.rs:220-222):
+   used to generate benchmark inputs with z != 1 on the device */
+int bn254_g1_mul_jacobian_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
+int bn254_g2_mul_jacobian_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
+
+/* ---- measurement ----------------------------------------------------------------------------------------------------- */
+/* When enabled, every kernel launch is bracketed by hipEvents on its own stream; bn254_kernel_stats then reports the
+   accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
+int bn254_profile_enable(bn254_ctx *ctx, int on);
+int bn254_profile_reset(bn254_ctx *ctx);
+/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul".  Synchronises the recorded events. */
+int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BN254_HIP_H */

@@ -5,6 +5,7 @@
 // This library is never loaded by the product (bn_amd/); it is not a CPU fallback.
 #define BN_HOSTSIM 1
 #include "../../bn_amd/csrc/io.hpp"
+#include "../../bn_amd/csrc/curve.hpp"
 #include <cstring>
 
 using namespace bn254;
@@ -72,3 +73,21 @@ EXPORT void hs_pairing(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
     if (inf) f = f12_one<F2>();
     f12_store(f, o);
 }
+
+// G * Fr through the engine: raw Jacobian result of the reference's double-and-add chain, and its normalized image
+template <class F, int W>
+static void hs_mul_generic(const uint32_t *pt, const uint32_t *k, uint32_t *o, int normalize, typename F::T (*ld)(const uint32_t *), void (*st)(const typename F::T &, uint32_t *)) {
+    Jac<F> p = {ld(pt), ld(pt + W), ld(pt + 2 * W)};
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    Jac<F> r = scalar_mul_reference_chain<F>(p, raw);
+    if (normalize) r = jac_normalize<F>(r);
+    st(r.x, o); st(r.y, o + W); st(r.z, o + 2 * W);
+}
+static Fe ld1(const uint32_t *w) { return fe_from_u32x8(w); }
+static void st1(const Fe &a, uint32_t *w) { fe_to_u32x8(a, w); }
+static F2 ld2(const uint32_t *w) { return f2_load((F2 *)0, w); }
+static void st2(const F2 &a, uint32_t *w) { f2_store(a, w); }
+EXPORT void hs_g1_mul(const uint32_t *p, const uint32_t *k, int normalize, uint32_t *o) { hs_mul_generic<FqField, 8>(p, k, o, normalize, ld1, st1); }
+EXPORT void hs_g2_mul(const uint32_t *p, const uint32_t *k, int normalize, uint32_t *o) { hs_mul_generic<Fq2Field<F2>, 16>(p, k, o, normalize, ld2, st2); }
+EXPORT void hs_fr_from_mont(const uint32_t *k, uint32_t *o) { fr_from_mont(k, o); }

@@ -1,0 +1,115 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI versus the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import bn_model as M
+from bn_oracle import FQ, FR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import bn_amd
+    return bn_amd.Engine(0)
+
+
+def _scalars(rng, n):
+    return [int.from_bytes(rng.bytes(64), "little") % M.R_ORD for _ in range(n)]
+
+
+def _fr(oracle, vals):
+    return np.stack([oracle.fp_from_int(FR, v) for v in vals])
+
+
+def _points(oracle, rng, n):
+    """Jacobian z != 1 points r*G1, s*G2 exactly as benches/api.rs builds inputs (G::random = one * Fr::random)"""
+    k1 = _fr(oracle, _scalars(rng, n)); k2 = _fr(oracle, _scalars(rng, n))
+    P = oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (n, 1)), k1)
+    Q = oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (n, 1)), k2)
+    return P, Q
+
+
+def test_reference_kats_on_gpu(oracle, kats, eng):
+    """groups/mod.rs:773-796 (test_reduced_pairing) through the GPU"""
+    k1 = oracle.fp_from_decimal(FR, kats["test_reduced_pairing"]["k1"]); k2 = oracle.fp_from_decimal(FR, kats["test_reduced_pairing"]["k2"])
+    P = oracle.g1_mul(oracle.g1_one(), k1); Q = oracle.g2_mul(oracle.g2_one(), k2)
+    gt = eng.pairing_batch(P, Q)[0]
+    assert oracle.fq12_to_ints(gt) == [int(x) for x in kats["test_reduced_pairing"]["expected"]]
+
+
+def test_pairing_batch_matches_oracle(oracle, eng):
+    rng = np.random.default_rng(101)
+    n = 200                                   # ragged: not a multiple of the wave size
+    P, Q = _points(oracle, rng, n)
+    got = eng.pairing_batch(P, Q)
+    want = oracle.pairing_batch(P, Q)
+    assert got.shape == (n, 48)
+    assert np.array_equal(got, want)
+
+
+def test_pairing_edge_cases(oracle, eng):
+    rng = np.random.default_rng(102)
+    P, Q = _points(oracle, rng, 6)
+    P[1] = oracle.g1_zero(); Q[2] = oracle.g2_zero(); P[3] = oracle.g1_zero(); Q[3] = oracle.g2_zero()   # infinity -> one
+    P[4] = oracle.g1_one(); Q[4] = oracle.g2_one()                                                      # z == 1 shortcut inputs
+    P[5] = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, M.R_ORD - 1))
+    got = eng.pairing_batch(P, Q)
+    assert np.array_equal(got, oracle.pairing_batch(P, Q))
+    one = oracle.fq12_one()
+    for i in (1, 2, 3):
+        assert np.array_equal(got[i], one)
+    assert eng.pairing_batch(np.zeros((0, 12), np.uint64), np.zeros((0, 24), np.uint64)).shape == (0, 48)   # empty batch
+
+
+def test_scalar_mul_matches_oracle(oracle, eng):
+    rng = np.random.default_rng(103)
+    n = 70
+    ks = _scalars(rng, n); ks[:6] = [0, 1, 2, M.R_ORD - 1, M.R_ORD - 2, 1 << 200]
+    k = _fr(oracle, ks)
+    P, Q = _points(oracle, rng, n)
+    P[7] = oracle.g1_zero(); Q[7] = oracle.g2_zero(); P[8] = oracle.g1_one(); Q[8] = oracle.g2_one()
+    assert np.array_equal(eng.g1_mul_batch(P, k), oracle.g1_mul_batch(P, k))
+    assert np.array_equal(eng.g2_mul_batch(Q, k), oracle.g2_mul_batch(Q, k))
+
+
+def test_pairing_product_matches_fold(oracle, eng):
+    rng = np.random.default_rng(104)
+    for n in (0, 1, 5, 130):
+        P, Q = _points(oracle, rng, n) if n else (np.zeros((0, 12), np.uint64), np.zeros((0, 24), np.uint64))
+        if n > 3:
+            P[2] = oracle.g1_zero()             # a pair with a point at infinity contributes one
+        got = eng.pairing_product(P, Q)
+        assert np.array_equal(got, oracle.pairing_product(P, Q)), n
+
+
+def test_bilinearity_on_gpu(oracle, eng):
+    """groups/mod.rs:798-823 (test_binlinearity): e(sP,Q) == e(P,sQ) == e(P,Q)^s, != 1"""
+    rng = np.random.default_rng(105)
+    n = 8
+    P, Q = _points(oracle, rng, n)
+    s = _fr(oracle, _scalars(rng, n))
+    sP = eng.g1_mul_batch(P, s); sQ = eng.g2_mul_batch(Q, s)
+    a = eng.pairing_batch(sP, Q); b = eng.pairing_batch(P, sQ); c = eng.pairing_batch(P, Q)
+    assert np.array_equal(a, b)
+    one = oracle.fq12_one()
+    for i in range(n):
+        assert np.array_equal(oracle.gt_pow(c[i], s[i]), a[i])
+        assert not np.array_equal(a[i], one)
+
+
+def test_reference_api_mirror(oracle):
+    """examples/joux.rs through the mirrored API (bn_amd.api)"""
+    import bn_amd
+    rng = np.random.default_rng(106)
+    a, b, c = (bn_amd.Fr.random(rng) for _ in range(3))
+    pa, qa = bn_amd.G1.one() * a, bn_amd.G2.one() * a
+    pb, qb = bn_amd.G1.one() * b, bn_amd.G2.one() * b
+    pc, qc = bn_amd.G1.one() * c, bn_amd.G2.one() * c
+    # each party's shared key e(P_b, Q_c)^a etc. - compare through the oracle's Gt::pow
+    ka = oracle.gt_pow(bn_amd.pairing(pb, qc).limbs, a.limbs)
+    kb = oracle.gt_pow(bn_amd.pairing(pc, qa).limbs, b.limbs)
+    kc = oracle.gt_pow(bn_amd.pairing(pa, qb).limbs, c.limbs)
+    assert np.array_equal(ka, kb) and np.array_equal(kb, kc)
+    assert bn_amd.pairing(bn_amd.G1.zero(), bn_amd.G2.one()) == bn_amd.Gt.one()
+    assert (bn_amd.G1.one() * bn_amd.Fr(5)) == (bn_amd.G1.one() * bn_amd.Fr(2)) * bn_amd.Fr(3) * bn_amd.Fr(5) * bn_amd.Fr(6).inverse()
