@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Benchmark of the BN254 pairing hot path on MI355X (BASELINE.json metric: optimal-ate pairings/sec, bit-exact).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of `pairing_batch` over one batch of 2^16 synthetic (r*G1, s*G2) pairs per GPU, resident in HBM
+(BASELINE.json configs[1]; with N GPUs every rank owns its own 2^16 pairs: weak scaling, no data-path collective).
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     the dominant kernel's algorithmic 32x32->64 MACs per launch / its HIP-event-measured duration, against the
+               measured v_mad_u64_u32 peak of the chip (this path is integer-VALU bound, not HBM or MFMA: SURVEY.md 8d);
+               `traffic` is the rocprofv3 HBM byte count per launch from profiles/ (null if not collected)
+  cpu_baseline the reference-faithful CPU port (oracle/) timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+BATCH = 1 << 16
+# algorithmic work per pairing (DESIGN.md "Work per pairing"): Fq multiplication equivalents of the reference's formulas
+# with 3-mult Fq2 products and add-only beta/xi, x 136 MAC32 (8x32-bit-limb Montgomery), split by kernel
+MAC32_PER_PAIRING = 2.583e6
+KERNEL_SHARE = {"miller": 9919 / 18686, "final_exp": 8767 / 18686}
+PEAK_TMAC32 = 30.1            # measured v_mad_u64_u32 issue peak, profiles/r01_ubench_valu_rates.txt (1024 SIMDs x 0.459 G/s x 64)
+ALGO_BYTES_PER_PAIRING = 672
+
+
+def cpu_baseline(batch_p, batch_q):
+    """reference-faithful CPU port on all host cores, bounded sample (~20 s of CPU work)"""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import bn_oracle
+    bn_oracle.build()
+    o = bn_oracle.Oracle()
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter(); o.pairing_batch(batch_p[:8], batch_q[:8], nthreads=1); t1 = (time.perf_counter() - t0) / 8
+    n = int(min(len(batch_p), max(cores, min(4096, 20.0 / t1))))
+    t0 = time.perf_counter(); o.pairing_batch(batch_p[:n], batch_q[:n], nthreads=cores); dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
+            "sample": f"{n} pairings of the same synthetic batch on {cores} threads ({dt:.2f} s wall); 1 thread: {t1 * 1e3:.2f} ms/pairing"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH, help="pairings per GPU per step")
+    ap.add_argument("--mapping", type=int, default=None, help="0: one lane per pairing, 1: lane pair per pairing")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import bn_amd
+    from bn_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: bn_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    eng = D.TorchEngine(bn_amd.Engine(local_rank, mapping=args.mapping), dev)
+    n = args.batch
+    lo = rank * n
+    P, Q = D.synthetic_points(eng, lo, lo + n)              # untimed: inputs resident in HBM before the clock starts
+    out = eng.empty(n, 48)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        D.pairing_batch_sharded(eng, P, Q, out)
+    eng.e.profile(True); eng.e.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        D.pairing_batch_sharded(eng, P, Q, out)
+    sync()
+    elapsed = time.perf_counter() - t0
+    eng.e.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        stats = {k: eng.e.kernel_stats(k) for k in ("miller", "final_exp")}
+        dom = max(stats, key=lambda k: stats[k][0])
+        ms, cnt = stats[dom]
+        avg_s = ms * 1e-3 / max(cnt, 1)
+        achieved = n * MAC32_PER_PAIRING * KERNEL_SHARE[dom] / avg_s / 1e12
+        traffic = None
+        tf = ROOT / "profiles" / "pmc_traffic.json"
+        if tf.exists():
+            traffic = json.loads(tf.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "BN254 optimal-ate pairings/sec (bit-exact vs ref)", "value": value, "unit": "pairings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit Montgomery, exact integer)",
+            "data": "synthetic",
+            "config": {"workload": f"{n} independent pairings per GPU per step, inputs r*G1 / s*G2 (Jacobian, z != 1) resident in HBM "
+                                   "(BASELINE.json configs[1])", "pairings_per_gpu": n, "parallelism": f"dp{world} (sharded, no collective)",
+                       "mapping": args.mapping},
+            "roofline": {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": achieved,
+                         "peak": PEAK_TMAC32, "unit": "TMAC32/s", "frac": achieved / PEAK_TMAC32, "traffic": traffic,
+                         "avg_launch_ms": avg_s * 1e3, "launches": cnt,
+                         "algorithmic_hbm_bytes_per_launch": n * ALGO_BYTES_PER_PAIRING,
+                         "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in stats.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            Pn = P[:4096].cpu().numpy().view(np.uint64); Qn = Q[:4096].cpu().numpy().view(np.uint64)
+            line["cpu_baseline"] = cpu_baseline(Pn, Qn)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
