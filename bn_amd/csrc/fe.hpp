@@ -72,6 +72,45 @@ struct Fe {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Leaf calling convention.  A struct argument larger than the 16 registers clang's AMDGPU ABI grants to ALL aggregate
+// arguments together is passed through private memory (scratch), which is HBM traffic (measured: profiles/r01a_*).
+// Vectors are not: a <9 x i32> travels in 9 VGPRs.  So every multiplier-sized leaf is a real (noinline) function whose
+// operands and result are u32x9 vectors, wrapped by an inline function with the natural Fe signature.
+#if defined(BN_HOSTSIM)
+#define BN_LEAF1(NAME, BODY) BN_FN Fe NAME(const Fe &a) { return BODY(a); }
+#define BN_LEAF2(NAME, BODY) BN_FN Fe NAME(const Fe &a, const Fe &b) { return BODY(a, b); }
+#define BN_LEAF3T(NAME, BODY)                                                                     \
+    template <int C1, int C2, int C3> BN_FN Fe NAME(const Fe &a, const Fe &b, const Fe &c) { return BODY<C1, C2, C3>(a, b, c); }
+#else
+typedef uint32_t u32x9 __attribute__((ext_vector_type(9)));
+BN_FN Fe bn_unv(u32x9 v) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = v[i];
+    return r;
+}
+BN_FN u32x9 bn_tov(const Fe &f) {
+    u32x9 v;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = f.l[i];
+    return v;
+}
+#define BN_LEAF1(NAME, BODY)                                                                      \
+    BN_LEAF u32x9 NAME##_leaf(u32x9 a) { return bn_tov(BODY(bn_unv(a))); }                       \
+    BN_FN Fe NAME(const Fe &a) { return bn_unv(NAME##_leaf(bn_tov(a))); }
+#define BN_LEAF2(NAME, BODY)                                                                      \
+    BN_LEAF u32x9 NAME##_leaf(u32x9 a, u32x9 b) { return bn_tov(BODY(bn_unv(a), bn_unv(b))); }   \
+    BN_FN Fe NAME(const Fe &a, const Fe &b) { return bn_unv(NAME##_leaf(bn_tov(a), bn_tov(b))); }
+#define BN_LEAF3T(NAME, BODY)                                                                     \
+    template <int C1, int C2, int C3> BN_LEAF u32x9 NAME##_leaf(u32x9 a, u32x9 b, u32x9 c) {     \
+        return bn_tov(BODY<C1, C2, C3>(bn_unv(a), bn_unv(b), bn_unv(c)));                         \
+    }                                                                                             \
+    template <int C1, int C2, int C3> BN_FN Fe NAME(const Fe &a, const Fe &b, const Fe &c) {      \
+        return bn_unv(NAME##_leaf<C1, C2, C3>(bn_tov(a), bn_tov(b), bn_tov(c)));                  \
+    }
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------
 // constants as Fe
 template <class T>
 BN_FN Fe fe_const(const T &tab) {
@@ -187,18 +226,21 @@ BN_FN Fe fe_reduce(const Fe &a) {
 // forms the linear combination, subtracts floor-ish(value/q)*q and renormalizes.  This is how every "sum of products"
 // of the tower (Karatsuba recombination, multiplication by xi = 9+i) gets back to standard form; the reference spends a
 // conditional add/subtract per Fq add instead (arith.rs:238-253).  Result: normalized limbs, value < 3q.
+// core: the middle term's sign is a per-lane run-time flag (needed by the lane-pair Fq2 mapping, where the even lane
+// subtracts and the odd lane adds the partner's limb in xi-multiplications)
 template <int C1, int C2, int C3>
-BN_LEAF Fe fe_lc3(const Fe &x, const Fe &y, const Fe &z) {
+BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) {
     constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3;
     BN_REQUIRE((C1 == 0 || x.lb <= 8) && (C2 == 0 || y.lb <= 8) && (C3 == 0 || z.lb <= 8), "fe_lc3 lb");
     BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb <= 1000, "fe_lc3 vb");
     // signed estimate of floor(value / 2^232) that never exceeds the truth: positive terms use a low estimate of their
     // top (carries parked in lower limbs ignored), negative terms a high one (+9)
-    auto top = [](const Fe &f, bool hi) -> int64_t { return (int64_t)f.l[8] + (int64_t)(f.l[7] >> 29) + (hi ? 9 : 0); };
-    int64_t te = -600;   // safety margin covering the truncation of FE_MU24 (|te| < 2^32 -> < 2^9 units)
-    if (C1 != 0) te += (int64_t)C1 * top(x, C1 < 0);
-    if (C2 != 0) te += (int64_t)C2 * top(y, C2 < 0);
-    if (C3 != 0) te += (int64_t)C3 * top(z, C3 < 0);
+    auto top = [](const Fe &f) -> int64_t { return (int64_t)f.l[8] + (int64_t)(f.l[7] >> 29); };
+    int64_t c2 = neg2 ? -(int64_t)C2 : (int64_t)C2;
+    int64_t te = -600 - 9 * (int64_t)(A1 + A2 + A3);   // margins: FE_MU24 truncation (< 2^9 units) and the +9 of negative terms
+    if (C1 != 0) te += (int64_t)C1 * top(x);
+    if (C2 != 0) te += c2 * top(y);
+    if (C3 != 0) te += (int64_t)C3 * top(z);
     int64_t kq = (te * (int64_t)k::FE_MU24) >> 45;          // floor; kq <= floor(value/q), kq >= value/q - 2
     Fe r;
     int64_t carry = 0;
@@ -206,13 +248,16 @@ BN_LEAF Fe fe_lc3(const Fe &x, const Fe &y, const Fe &z) {
     for (int i = 0; i < 9; ++i) {
         int64_t t = carry - kq * (int64_t)k::Q[i];
         if (C1 != 0) t += (int64_t)C1 * (int64_t)x.l[i];
-        if (C2 != 0) t += (int64_t)C2 * (int64_t)y.l[i];
+        if (C2 != 0) t += c2 * (int64_t)y.l[i];
         if (C3 != 0) t += (int64_t)C3 * (int64_t)z.l[i];
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
     BN_SETB(r, 1, 3);
     return r;
 }
+template <int C1, int C2, int C3>
+BN_FN Fe fe_lc3_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3>(x, y, z, false); }
+BN_LEAF3T(fe_lc3, fe_lc3_body)
 BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any lazy value -> standard form (1,3)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -220,7 +265,7 @@ BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any l
 // :257-263).  One 64-bit accumulator per column, 81 + 81 v_mad_u64_u32, no carry instructions.
 // Column bound: 9*(la*lb) * 2^58 + 9 * 2^58 + carry < 2^64  <=>  la*lb <= 6.
 // Value: result < (A*B/169.3 + 1) q, so A*B <= 169 gives < 2q.
-BN_LEAF Fe fe_mul(const Fe &a, const Fe &b) {
+BN_FN Fe fe_mul_body(const Fe &a, const Fe &b) {
     BN_REQUIRE(a.lb * b.lb <= 6, "fe_mul column overflow");
     BN_REQUIRE(a.vb * b.vb <= 169, "fe_mul value bound");
     uint64_t acc = 0;
@@ -249,10 +294,11 @@ BN_LEAF Fe fe_mul(const Fe &a, const Fe &b) {
     BN_SETB(r, 1, 2);
     return r;
 }
+BN_LEAF2(fe_mul, fe_mul_body)
 BN_FN Fe fe_sqr(const Fe &a) { return fe_mul(a, a); }
 
 // (a*u + c*v) / R with ONE reduction: 162 + 81 mads.   Column bound: la*lu + lc*lv <= 6; value: A*U + C*V <= 169.
-BN_LEAF Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
+BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
     BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 6, "fe_mul2 column overflow");
     BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 169, "fe_mul2 value bound");
     uint64_t acc = 0;
@@ -355,7 +401,7 @@ BN_FN Fe fe_select(bool take_b, const Fe &a, const Fe &b) {
 
 // a^(q-2) (Fermat).  Uniform across lanes; replaces the data-dependent binary EEA of arith.rs:281-327 + fp.rs:103-112.
 // The inverse is unique mod q, so after canonicalisation the bytes equal the reference's.  inverse(0) = 0.
-BN_LEAF Fe fe_inverse(const Fe &a_in) {
+BN_FN Fe fe_inverse_body(const Fe &a_in) {
     Fe a = a_in;
     BN_REQUIRE(a.lb <= 2 && a.vb <= 8, "fe_inverse input");
     Fe r = fe_one();
@@ -367,5 +413,6 @@ BN_LEAF Fe fe_inverse(const Fe &a_in) {
     }
     return r;
 }
+BN_LEAF1(fe_inverse, fe_inverse_body)
 
 }  // namespace bn254
