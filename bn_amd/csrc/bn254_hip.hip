@@ -116,9 +116,12 @@ __global__ void __launch_bounds__(BLOCK) bn254_g2_mul_k(const uint32_t *p, const
 }  // namespace
 
 // ======================================================================================================== host side
+extern "C" int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, hipStream_t s);      // bn254_kernels_b.hip
+extern "C" int bn254_launch_final_exp_B(const void *f, void *out, size_t n, hipStream_t s);
+
 struct bn254_ctx {
     int device = 0;
-    int mapping = 0;
+    int mapping = 1;                    // 1: lane-pair mapping (default), 0: one lane per pairing
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
     void *ws = nullptr;                 // workspace (Miller values, product-tree levels)
     size_t ws_bytes = 0;
@@ -170,11 +173,13 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK);
 
 int launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s) {
     Scope sc(c, s, "miller");
+    if (c->mapping == 1) return bn254_launch_miller_B(p, q, f, n, s);
     hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
 int launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s) {
     Scope sc(c, s, "final_exp");
+    if (c->mapping == 1) return bn254_launch_final_exp_B(f, out, n, s);
     hipLaunchKernelGGL(bn254_final_exp_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }

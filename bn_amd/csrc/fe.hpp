@@ -28,6 +28,7 @@
 #define BN_FN inline
 #define BN_LEAF inline
 #define BN_COARSE inline
+#define BN_OUTER inline
 #define BN254_CONSTANT constexpr
 #else
 #include <hip/hip_runtime.h>
@@ -38,6 +39,9 @@
 #ifndef BN_COARSE
 #define BN_COARSE __device__ __noinline__ inline
 #endif
+// BN_OUTER  big, rarely executed steps (inversions, Frobenius maps, the straight-line part of the final exponentiation):
+//           always real functions, so the hot loops are not diluted by their code
+#define BN_OUTER __device__ __noinline__ inline
 #define BN254_CONSTANT __device__ constexpr
 #endif
 #include "bn254_constants.hpp"

@@ -80,5 +80,104 @@ BN_FN Fq2A f2_inverse(const Fq2A &a) {            // fq2.rs:125-136 with a unifo
 BN_FN Fq2A f2_load(const Fq2A *, const uint32_t *w) { return {fe_from_u32x8(w), fe_from_u32x8(w + 8)}; }
 BN_FN void f2_store(const Fq2A &a, uint32_t *w) { fe_to_u32x8(a.c0, w); fe_to_u32x8(a.c1, w + 8); }
 BN_FN Fe f2_scalar_load(const Fq2A *, const uint32_t *w) { return fe_from_u32x8(w); }
+template <class TAB> BN_FN Fe f2_scalar_const(const Fq2A *, const TAB &tab) { return fe_const(tab); }
 
+
+// ===================================================================================================== policy B
+// One Fq2 element per PAIR of adjacent lanes (even lane: c0, odd lane: c1).  T is the per-lane scalar: Fe on the GPU;
+// the host simulation instantiates it with a 2-lane value type so the same code is checked on the CPU.
+// Lane primitives (defined per build): lane_odd<T>(), lane_partner(x), lane_pick(even_choice, odd_choice), lane_bcast<T>(Fe).
+#if !defined(BN_HOSTSIM)
+BN_FN bool lane_is_odd() { return (threadIdx.x & 1u) != 0; }
+BN_FN Fe lane_partner(const Fe &x) {          // DPP quad_perm [1,0,3,2]: swap the two lanes of every pair, no LDS, no memory
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], 0xB1, 0xF, 0xF, true);
+    return r;
+}
+BN_FN bool lane_partner_flag(bool f) { return __builtin_amdgcn_mov_dpp((int)f, 0xB1, 0xF, 0xF, true) != 0; }
+BN_FN Fe lane_pick(const Fe &even_choice, const Fe &odd_choice) { return fe_select(lane_is_odd(), even_choice, odd_choice); }
+BN_FN Fe lane_bcast(const Fe *, const Fe &x) { return x; }
+BN_FN Fe lane_load_pair(const Fe *, const uint32_t *w0, const uint32_t *w1) { return fe_from_u32x8(lane_is_odd() ? w1 : w0); }
+BN_FN void lane_store_pair(const Fe &a, uint32_t *w0, uint32_t *w1) { fe_to_u32x8(a, lane_is_odd() ? w1 : w0); }
+BN_FN bool lane_pair_all_zero(const Fe &a) { bool z = fe_is_zero(a); return z && lane_partner_flag(z); }
+// reduce(C1*x + s*C2*y + C3*z), s = -1 on even lanes, +1 on odd lanes
+template <int C1, int C2, int C3>
+BN_FN Fe fe_lc3_par_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3>(x, y, z, !lane_is_odd()); }
+BN_LEAF3T(fe_lc3_par, fe_lc3_par_body)
+#endif
+
+template <class T>
+struct Fq2B {
+    T v;                 // this lane's component
+    using Scalar = T;    // an Fq replicated in both lanes of the pair
+};
+#define TP ((const T *)nullptr)
+
+// the product leaf: own_a*u + partner_a*v with one reduction (see the header comment).  a: lb <= 2, vb <= 6;  b: S
+template <class T>
+BN_FN T f2b_mul_body(const T &a, const T &b) {
+    T pa = lane_partner(a), pb = lane_partner(b);
+    T u = lane_pick(b, pb);
+    T v = lane_pick(fe_neg<1, 7>(pb), b);
+    return fe_mul2(a, u, pa, v);
+}
+// complex squaring: even lane (a0+a1)(a0-a1), odd lane (2 a0) a1 : ONE plain Montgomery product per lane
+template <class T>
+BN_FN T f2b_sqr_body(const T &a) {
+    T pa = lane_partner(a);
+    T s = lane_pick(fe_add(a, pa), fe_dbl(pa));
+    T t = lane_pick(fe_sub<1, 4>(a, pa), a);
+    return fe_mul_body(s, t);
+}
+#if defined(BN_HOSTSIM)
+template <class T> BN_FN T f2b_mul(const T &a, const T &b) { return f2b_mul_body(a, b); }
+template <class T> BN_FN T f2b_sqr(const T &a) { return f2b_sqr_body(a); }
+#else
+BN_LEAF u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_body(bn_unv(a), bn_unv(b))); }
+BN_LEAF u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_body(bn_unv(a))); }
+BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a), bn_tov(b))); }
+BN_FN Fe f2b_sqr(const Fe &a) { return bn_unv(f2b_sqr_leaf(bn_tov(a))); }
+#endif
+
+template <class T> BN_FN Fq2B<T> f2_add(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_add(a.v, b.v)}; }
+template <class T> BN_FN Fq2B<T> f2_dbl(const Fq2B<T> &a) { return {fe_dbl(a.v)}; }
+template <int LB, int K, class T> BN_FN Fq2B<T> f2_sub(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_sub<LB, K>(a.v, b.v)}; }
+template <class T> BN_FN Fq2B<T> f2_norm(const Fq2B<T> &a) { return {fe_norm(a.v)}; }
+template <class T> BN_FN Fq2B<T> f2_std(const Fq2B<T> &a) { return {fe_std(a.v)}; }
+template <int C1, int C2, int C3, class T>
+BN_FN Fq2B<T> f2_lc3(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc3<C1, C2, C3>(x.v, y.v, z.v)}; }
+template <class T> BN_FN Fq2B<T> f2_neg(const Fq2B<T> &a) { return {fe_lc3<-1, 0, 0>(a.v, a.v, a.v)}; }
+template <class T> BN_FN Fq2B<T> f2_conj(const Fq2B<T> &a) { return {lane_pick(a.v, fe_lc3<-1, 0, 0>(a.v, a.v, a.v))}; }
+template <class T> BN_FN Fq2B<T> f2_neg_lazy(const Fq2B<T> &a) { return {fe_neg<1, 4>(a.v)}; }
+template <class T> BN_FN Fq2B<T> f2_conj_lazy(const Fq2B<T> &a) { return {lane_pick(a.v, fe_neg<1, 4>(a.v))}; }
+template <class T> BN_FN Fq2B<T> f2_zero(const Fq2B<T> *) { return {lane_bcast(TP, fe_zero())}; }
+template <class T> BN_FN Fq2B<T> f2_one(const Fq2B<T> *) { return {lane_pick(lane_bcast(TP, fe_one()), lane_bcast(TP, fe_zero()))}; }
+template <class T, class TAB>
+BN_FN Fq2B<T> f2_const(const Fq2B<T> *, const TAB &tab) { return {lane_pick(lane_bcast(TP, fe_const(tab[0])), lane_bcast(TP, fe_const(tab[1])))}; }
+template <class T> BN_FN Fq2B<T> f2_select(bool take_b, const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_select(take_b, a.v, b.v)}; }
+template <class T> BN_FN Fq2B<T> f2_mul(const Fq2B<T> &a, const Fq2B<T> &b) { return {f2b_mul(a.v, b.v)}; }
+template <class T> BN_FN Fq2B<T> f2_sqr(const Fq2B<T> &a) { return {f2b_sqr(a.v)}; }
+template <class T> BN_FN Fq2B<T> f2_scale(const Fq2B<T> &a, const T &s) { return {fe_mul(a.v, s)}; }
+// reduce(CX*xi*x + CY*y): even lane 9CX*x0 - CX*x1 + CY*y0, odd lane 9CX*x1 + CX*x0 + CY*y1
+template <int CX, int CY, class T>
+BN_FN Fq2B<T> f2_lc_xi(const Fq2B<T> &x, const Fq2B<T> &y) { return {fe_lc3_par<9 * CX, CX, CY>(x.v, lane_partner(x.v), y.v)}; }
+template <class T> BN_FN Fq2B<T> f2_mul_xi(const Fq2B<T> &x) { return f2_lc_xi<1, 0>(x, x); }
+template <class T, class TAB>
+BN_FN Fq2B<T> f2_mul_const(const Fq2B<T> &a, const TAB &tab) { return f2_mul(a, f2_const((const Fq2B<T> *)nullptr, tab)); }
+// fq2.rs:125-136: norm = a0^2 + a1^2 (one square per lane, exchanged), ONE Fermat chain for the pair
+template <class T>
+BN_FN Fq2B<T> f2_inverse(const Fq2B<T> &a) {
+    T sq = fe_sqr(a.v);
+    T n = fe_lc3<1, 1, 0>(sq, lane_partner(sq), sq);
+    T t = fe_inverse(n);
+    T r = fe_mul(a.v, t);
+    return {lane_pick(r, fe_lc3<-1, 0, 0>(r, r, r))};
+}
+template <class T> BN_FN bool f2_is_zero(const Fq2B<T> &a) { return lane_pair_all_zero(a.v); }
+template <class T> BN_FN Fq2B<T> f2_load(const Fq2B<T> *, const uint32_t *w) { return {lane_load_pair(TP, w, w + 8)}; }
+template <class T> BN_FN void f2_store(const Fq2B<T> &a, uint32_t *w) { lane_store_pair(a.v, w, w + 8); }
+template <class T> BN_FN T f2_scalar_load(const Fq2B<T> *, const uint32_t *w) { return lane_load_pair(TP, w, w); }
+template <class T, class TAB> BN_FN T f2_scalar_const(const Fq2B<T> *, const TAB &tab) { return lane_bcast(TP, fe_const(tab)); }
+#undef TP
 }  // namespace bn254

@@ -20,11 +20,11 @@ template <class F2> struct Line { F2 ell_0, ell_vw, ell_vv; };  // ell_vw / ell_
 // groups/mod.rs:612-634.   e = 3b' * z^2 folds the reference's d = 3c, e = b'*d into one constant product.
 template <class F2>
 BN_COARSE Line<F2> doubling_step(G2Proj<F2> &r) {
-    F2 a = f2_scale(f2_mul(r.x, r.y), fe_const(k::TWO_INV));
+    F2 a = f2_scale(f2_mul(r.x, r.y), f2_scalar_const(F2P, k::TWO_INV));
     F2 b = f2_sqr(r.y), c = f2_sqr(r.z);
     F2 e = f2_mul_const(c, k::G2_3B);
     F2 f3 = f2_add(f2_add(e, e), e);                                     // f = 3e, lazy
-    F2 g = f2_scale(f2_add(b, f3), fe_const(k::TWO_INV));                // (b + f)/2
+    F2 g = f2_scale(f2_add(b, f3), f2_scalar_const(F2P, k::TWO_INV));                // (b + f)/2
     F2 h = f2_lc3<1, -1, -1>(f2_sqr(f2_lc3<1, 1, 0>(r.y, r.z, r.z)), b, c);
     F2 j = f2_sqr(r.x), e_sq = f2_sqr(e);
     Line<F2> l;
@@ -56,7 +56,7 @@ BN_COARSE Line<F2> addition_step(G2Proj<F2> &r, const G2Aff<F2> &base) {
 }
 // groups/mod.rs:550-555
 template <class F2>
-BN_COARSE G2Aff<F2> mul_by_q(const G2Aff<F2> &a) {
+BN_OUTER G2Aff<F2> mul_by_q(const G2Aff<F2> &a) {
     return {f2_mul_const(f2_conj_lazy(a.x), k::TWIST_MUL_BY_Q_X), f2_mul_const(f2_conj_lazy(a.y), k::TWIST_MUL_BY_Q_Y)};
 }
 // f <- f * line(P)   (groups/mod.rs:502,507,513,516)
@@ -65,33 +65,39 @@ BN_FN Fq12<F2> apply_line(const Fq12<F2> &f, const Line<F2> &l, const G1Aff<S> &
     return f12_mul_by_024(f, l.ell_0, f2_scale(l.ell_vw, p.y), f2_scale(l.ell_vv, p.x));
 }
 
-// groups/mod.rs:486-519 fused with :557-588.  Loop bits are compile-time constants (6u+2, top bit skipped): no divergence.
+// groups/mod.rs:486-519 fused with :557-588.  The schedule (6u+2 with the top bit skipped: 64 doublings, an addition of Q
+// after every set bit, then the additions of pi(Q) and -pi^2(Q)) is a compile-time constant, so every branch below is
+// wave-uniform.  Written as ONE loop of 66 steps x up to 2 passes so that each of f^2, the two line functions and the
+// sparse multiplication exists exactly once in the instruction stream.
 template <class F2, class S>
 BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q) {
     G2Proj<F2> r = {q.x, q.y, f2_one(F2P)};
     Fq12<F2> f = f12_one<F2>();
+    G2Aff<F2> base = q;
 #pragma unroll 1
-    for (int i = 63; i >= 0; --i) {
-        Line<F2> l = doubling_step(r);
-        f = apply_line(f12_sqr(f), l, p);
-        if ((k::ATE_LOOP_LOW64 >> i) & 1) {
-            l = addition_step(r, q);
+    for (int j = 0; j < 66; ++j) {
+        const bool tail = j >= 64;
+        const bool bit = tail ? true : (((k::ATE_LOOP_LOW64 >> (63 - (j & 63))) & 1) != 0);
+        if (j == 64) base = mul_by_q(q);                                   // pi(Q)            groups/mod.rs:578
+        if (j == 65) { base = mul_by_q(base); base.y = f2_neg(base.y); }    // -pi^2(Q)         groups/mod.rs:579
+#pragma unroll 1
+        for (int pass = tail ? 1 : 0; pass < (bit ? 2 : 1); ++pass) {
+            Line<F2> l;
+            if (pass == 0) {
+                f = f12_sqr(f);
+                l = doubling_step(r);
+            } else {
+                l = addition_step(r, base);
+            }
             f = apply_line(f, l, p);
         }
     }
-    G2Aff<F2> q1 = mul_by_q(q);
-    G2Aff<F2> q2 = mul_by_q(q1);
-    q2.y = f2_neg(q2.y);
-    Line<F2> l = addition_step(r, q1);
-    f = apply_line(f, l, p);
-    l = addition_step(r, q2);
-    f = apply_line(f, l, p);
     return f;
 }
 
 // fq12.rs:229-246 + 97-101: f^u by square-and-multiply (u has 63 bits, top bit consumed by res = f), then conjugate
 template <class F2>
-BN_COARSE Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
+BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
     Fq12<F2> res = f;
 #pragma unroll 1
     for (int i = 61; i >= 0; --i) {
@@ -104,33 +110,33 @@ BN_COARSE Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
 template <class F2>
 BN_FN Fq12<F2> final_exp_first_chunk(const Fq12<F2> &f) {
     Fq12<F2> b = f12_inverse(f);
-    Fq12<F2> c = f12_mul(f12_conj(f), b);
-    return f12_mul(f12_frobenius<2>(c), c);
+    Fq12<F2> c = f12_mul_o(f12_conj(f), b);
+    return f12_mul_o(f12_frobenius<2>(c), c);
 }
 // fq12.rs:54-84
 template <class F2>
 BN_FN Fq12<F2> final_exp_last_chunk(const Fq12<F2> &s) {
     Fq12<F2> a = exp_by_neg_z(s);
-    Fq12<F2> b = f12_cyclotomic_sqr(a);
-    Fq12<F2> c = f12_cyclotomic_sqr(b);
-    Fq12<F2> d = f12_mul(c, b);
+    Fq12<F2> b = f12_cyclotomic_sqr_o(a);
+    Fq12<F2> c = f12_cyclotomic_sqr_o(b);
+    Fq12<F2> d = f12_mul_o(c, b);
     Fq12<F2> e = exp_by_neg_z(d);
-    Fq12<F2> f = f12_cyclotomic_sqr(e);
+    Fq12<F2> f = f12_cyclotomic_sqr_o(e);
     Fq12<F2> g = exp_by_neg_z(f);
     Fq12<F2> h = f12_conj(d);
     Fq12<F2> i = f12_conj(g);
-    Fq12<F2> j = f12_mul(i, e);
-    Fq12<F2> kk = f12_mul(j, h);
-    Fq12<F2> l = f12_mul(kk, b);
-    Fq12<F2> m = f12_mul(kk, e);
-    Fq12<F2> n = f12_mul(s, m);
+    Fq12<F2> j = f12_mul_o(i, e);
+    Fq12<F2> kk = f12_mul_o(j, h);
+    Fq12<F2> l = f12_mul_o(kk, b);
+    Fq12<F2> m = f12_mul_o(kk, e);
+    Fq12<F2> n = f12_mul_o(s, m);
     Fq12<F2> o = f12_frobenius<1>(l);
-    Fq12<F2> p = f12_mul(o, n);
+    Fq12<F2> p = f12_mul_o(o, n);
     Fq12<F2> q = f12_frobenius<2>(kk);
-    Fq12<F2> r = f12_mul(q, p);
-    Fq12<F2> t = f12_mul(f12_conj(s), l);
+    Fq12<F2> r = f12_mul_o(q, p);
+    Fq12<F2> t = f12_mul_o(f12_conj(s), l);
     Fq12<F2> u = f12_frobenius<3>(t);
-    return f12_mul(u, r);
+    return f12_mul_o(u, r);
 }
 template <class F2>
 BN_FN Fq12<F2> final_exponentiation(const Fq12<F2> &f) { return final_exp_last_chunk(final_exp_first_chunk(f)); }
@@ -146,6 +152,27 @@ BN_FN G1Aff<Fe> g1_to_affine(const Fe &x, const Fe &y, const Fe &z) {
     Fe zi = fe_inverse(z);
     Fe zi2 = fe_sqr(zi);
     return {fe_mul(x, zi2), fe_mul(y, fe_mul(zi2, zi))};
+}
+
+
+// Prologue of a pairing in the lane-pair mapping: both Jacobian -> affine conversions with ONE Fermat chain per pair
+// (the even lane inverts z_P, the odd lane inverts norm(z_Q) = z0^2 + z1^2; the results are swapped by DPP).
+template <class T>
+BN_FN void pair_prologue(const T &px, const T &py, const T &pz, const Fq2B<T> &qx, const Fq2B<T> &qy, const Fq2B<T> &qz,
+                         G1Aff<T> &p, G2Aff<Fq2B<T>> &q) {
+    T sq = fe_sqr(qz.v);
+    T n = fe_lc3<1, 1, 0>(sq, lane_partner(sq), sq);                 // norm(z_Q), same in both lanes
+    T inv = fe_inverse(lane_pick(pz, n));
+    T pinv = lane_partner(inv);
+    T izp = lane_pick(inv, pinv), in = lane_pick(pinv, inv);          // 1/z_P and 1/norm in both lanes
+    T zi2p = fe_sqr(izp);
+    p.x = fe_mul(px, zi2p);
+    p.y = fe_mul(py, fe_mul(zi2p, izp));
+    T r = fe_mul(qz.v, in);
+    Fq2B<T> zi = {lane_pick(r, fe_lc3<-1, 0, 0>(r, r, r))};           // conj(z_Q) / norm
+    Fq2B<T> zi2 = f2_sqr(zi);
+    q.x = f2_mul(qx, zi2);
+    q.y = f2_mul(qy, f2_mul(zi2, zi));
 }
 
 #undef F2P

@@ -69,7 +69,7 @@ BN_FN Fq6<F2> f6_frobenius(const Fq6<F2> &a) {
 }
 // fq6.rs:129-141
 template <class F2>
-BN_COARSE Fq6<F2> f6_inverse(const Fq6<F2> &a) {
+BN_OUTER Fq6<F2> f6_inverse(const Fq6<F2> &a) {
     F2 c0 = f2_lc3<1, -1, 0>(f2_sqr(a.c0), f2_mul(a.c1, f2_mul_xi(a.c2)), a.c0);
     F2 c1 = f2_lc_xi<1, -1>(f2_sqr(a.c2), f2_mul(a.c0, a.c1));
     F2 c2 = f2_lc3<1, -1, 0>(f2_sqr(a.c1), f2_mul(a.c0, a.c2), a.c0);
@@ -109,10 +109,10 @@ BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     return r;
 }
 // fq12.rs:103-105
-template <class F2> BN_COARSE Fq12<F2> f12_conj(const Fq12<F2> &a) { return {a.c0, f6_neg(a.c1)}; }
+template <class F2> BN_OUTER Fq12<F2> f12_conj(const Fq12<F2> &a) { return {a.c0, f6_neg(a.c1)}; }
 // fq12.rs:284-292
 template <class F2>
-BN_COARSE Fq12<F2> f12_inverse(const Fq12<F2> &a) {
+BN_OUTER Fq12<F2> f12_inverse(const Fq12<F2> &a) {
     Fq6<F2> s1 = f6_sqr(a.c1);
     Fq6<F2> s0 = f6_sqr(a.c0);
     Fq6<F2> d;                                                // c0^2 - v*c1^2
@@ -124,7 +124,7 @@ BN_COARSE Fq12<F2> f12_inverse(const Fq12<F2> &a) {
 }
 // fq12.rs:90-95, P in {1,2,3}
 template <int P, class F2>
-BN_COARSE Fq12<F2> f12_frobenius(const Fq12<F2> &a) {
+BN_OUTER Fq12<F2> f12_frobenius(const Fq12<F2> &a) {
     Fq6<F2> c1 = f6_frobenius<P>(a.c1);
     F2 g = f2_const(F2P, k::FROB12_C1[P]);
     return {f6_frobenius<P>(a.c0), f6_scale(c1, g)};
@@ -180,6 +180,10 @@ BN_COARSE Fq12<F2> f12_cyclotomic_sqr(const Fq12<F2> &f) {
     r.c1.c2 = f2_lc3<6, 2, 0>(p23, z5, z5);
     return r;
 }
+
+// out-of-line twins for the straight-line (non-loop) callers
+template <class F2> BN_OUTER Fq12<F2> f12_mul_o(const Fq12<F2> &a, const Fq12<F2> &b) { return f12_mul(a, b); }
+template <class F2> BN_OUTER Fq12<F2> f12_cyclotomic_sqr_o(const Fq12<F2> &a) { return f12_cyclotomic_sqr(a); }
 
 #undef F2P
 }  // namespace bn254

@@ -4,6 +4,7 @@
 // flow is data independent, so one simulated pairing exercises every bound check).
 // This library is never loaded by the product (bn_amd/); it is not a CPU fallback.
 #define BN_HOSTSIM 1
+#include "lanepair.hpp"
 #include "../../bn_amd/csrc/io.hpp"
 #include "../../bn_amd/csrc/curve.hpp"
 #include <cstring>
@@ -91,3 +92,31 @@ static void st2(const F2 &a, uint32_t *w) { f2_store(a, w); }
 EXPORT void hs_g1_mul(const uint32_t *p, const uint32_t *k, int normalize, uint32_t *o) { hs_mul_generic<FqField, 8>(p, k, o, normalize, ld1, st1); }
 EXPORT void hs_g2_mul(const uint32_t *p, const uint32_t *k, int normalize, uint32_t *o) { hs_mul_generic<Fq2Field<F2>, 16>(p, k, o, normalize, ld2, st2); }
 EXPORT void hs_fr_from_mont(const uint32_t *k, uint32_t *o) { fr_from_mont(k, o); }
+
+// ---------------------------------------------------------------- lane-pair mapping (Fq2B) executed on a simulated lane pair
+typedef Fq2B<FeP> F2B;
+EXPORT void hsb_fq2_mul(const uint32_t *a, const uint32_t *b, uint32_t *o) { f2_store(f2_mul(f2_load((F2B *)0, a), f2_load((F2B *)0, b)), o); }
+EXPORT void hsb_fq2_sqr(const uint32_t *a, uint32_t *o) { f2_store(f2_sqr(f2_load((F2B *)0, a)), o); }
+EXPORT void hsb_fq2_mul_xi(const uint32_t *a, uint32_t *o) { f2_store(f2_mul_xi(f2_load((F2B *)0, a)), o); }
+EXPORT void hsb_fq2_inverse(const uint32_t *a, uint32_t *o) { f2_store(f2_inverse(f2_load((F2B *)0, a)), o); }
+EXPORT void hsb_fq12_mul(const uint32_t *a, const uint32_t *b, uint32_t *o) { f12_store(f12_mul(f12_load<F2B>(a), f12_load<F2B>(b)), o); }
+EXPORT void hsb_fq12_sqr(const uint32_t *a, uint32_t *o) { f12_store(f12_sqr(f12_load<F2B>(a)), o); }
+EXPORT void hsb_fq12_inverse(const uint32_t *a, uint32_t *o) { f12_store(f12_inverse(f12_load<F2B>(a)), o); }
+EXPORT void hsb_fq12_cyclotomic_sqr(const uint32_t *a, uint32_t *o) { f12_store(f12_cyclotomic_sqr(f12_load<F2B>(a)), o); }
+EXPORT void hsb_fq12_frobenius(const uint32_t *a, int p, uint32_t *o) {
+    Fq12<F2B> f = f12_load<F2B>(a);
+    f12_store(p == 1 ? f12_frobenius<1>(f) : p == 2 ? f12_frobenius<2>(f) : f12_frobenius<3>(f), o);
+}
+EXPORT void hsb_fq12_mul_by_024(const uint32_t *a, const uint32_t *l0, const uint32_t *lvw, const uint32_t *lvv, uint32_t *o) {
+    f12_store(f12_mul_by_024(f12_load<F2B>(a), f2_load((F2B *)0, l0), f2_load((F2B *)0, lvw), f2_load((F2B *)0, lvv)), o);
+}
+EXPORT void hsb_final_exponentiation(const uint32_t *a, uint32_t *o) { f12_store(final_exponentiation(f12_load<F2B>(a)), o); }
+EXPORT void hsb_pairing(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
+    bool inf = words_all_zero(g1 + 16, 8) || words_all_zero(g2 + 32, 16);
+    G1Aff<FeP> p; G2Aff<F2B> q;
+    pair_prologue<FeP>(f2_scalar_load((F2B *)0, g1), f2_scalar_load((F2B *)0, g1 + 8), f2_scalar_load((F2B *)0, g1 + 16),
+                       f2_load((F2B *)0, g2), f2_load((F2B *)0, g2 + 16), f2_load((F2B *)0, g2 + 32), p, q);
+    Fq12<F2B> f = final_exponentiation(miller_loop(p, q));
+    if (inf) f = f12_one<F2B>();
+    f12_store(f, o);
+}

@@ -1,0 +1,36 @@
+// TEST INFRASTRUCTURE (host simulation only): a 2-lane value type that executes the lane-pair Fq2 mapping (Fq2B) on the CPU.
+// Every fe_* primitive is lifted element-wise; lane_partner swaps the lanes (the GPU does it with DPP quad_perm [1,0,3,2]).
+#pragma once
+#include "../../bn_amd/csrc/fe.hpp"
+
+namespace bn254 {
+struct FeP { Fe v[2]; };
+
+BN_FN FeP lane_partner(const FeP &x) { return {{x.v[1], x.v[0]}}; }
+BN_FN FeP lane_pick(const FeP &even_choice, const FeP &odd_choice) { return {{even_choice.v[0], odd_choice.v[1]}}; }
+BN_FN FeP lane_bcast(const FeP *, const Fe &x) { return {{x, x}}; }
+BN_FN FeP fe_add(const FeP &a, const FeP &b) { return {{fe_add(a.v[0], b.v[0]), fe_add(a.v[1], b.v[1])}}; }
+BN_FN FeP fe_dbl(const FeP &a) { return fe_add(a, a); }
+template <int LB, int K> BN_FN FeP fe_sub(const FeP &a, const FeP &b) { return {{fe_sub<LB, K>(a.v[0], b.v[0]), fe_sub<LB, K>(a.v[1], b.v[1])}}; }
+template <int LB, int K> BN_FN FeP fe_neg(const FeP &a) { return {{fe_neg<LB, K>(a.v[0]), fe_neg<LB, K>(a.v[1])}}; }
+BN_FN FeP fe_norm(const FeP &a) { return {{fe_norm(a.v[0]), fe_norm(a.v[1])}}; }
+BN_FN FeP fe_std(const FeP &a) { return {{fe_std(a.v[0]), fe_std(a.v[1])}}; }
+template <int C1, int C2, int C3>
+BN_FN FeP fe_lc3(const FeP &x, const FeP &y, const FeP &z) { return {{fe_lc3<C1, C2, C3>(x.v[0], y.v[0], z.v[0]), fe_lc3<C1, C2, C3>(x.v[1], y.v[1], z.v[1])}}; }
+template <int C1, int C2, int C3>      // middle term: minus on the even lane, plus on the odd lane
+BN_FN FeP fe_lc3_par(const FeP &x, const FeP &y, const FeP &z) {
+    return {{fe_lc3_core<C1, C2, C3>(x.v[0], y.v[0], z.v[0], true), fe_lc3_core<C1, C2, C3>(x.v[1], y.v[1], z.v[1], false)}};
+}
+BN_FN FeP fe_mul(const FeP &a, const FeP &b) { return {{fe_mul(a.v[0], b.v[0]), fe_mul(a.v[1], b.v[1])}}; }
+BN_FN FeP fe_mul_body(const FeP &a, const FeP &b) { return fe_mul(a, b); }
+BN_FN FeP fe_sqr(const FeP &a) { return fe_mul(a, a); }
+BN_FN FeP fe_mul2(const FeP &a, const FeP &u, const FeP &c, const FeP &v) {
+    return {{fe_mul2(a.v[0], u.v[0], c.v[0], v.v[0]), fe_mul2(a.v[1], u.v[1], c.v[1], v.v[1])}};
+}
+BN_FN FeP fe_inverse(const FeP &a) { return {{fe_inverse(a.v[0]), fe_inverse(a.v[1])}}; }
+BN_FN FeP fe_select(bool take_b, const FeP &a, const FeP &b) { return {{fe_select(take_b, a.v[0], b.v[0]), fe_select(take_b, a.v[1], b.v[1])}}; }
+// I/O of a pair: the even lane reads/writes w0, the odd lane w1
+BN_FN FeP lane_load_pair(const FeP *, const uint32_t *w0, const uint32_t *w1) { return {{fe_from_u32x8(w0), fe_from_u32x8(w1)}}; }
+BN_FN void lane_store_pair(const FeP &a, uint32_t *w0, uint32_t *w1) { fe_to_u32x8(a.v[0], w0); fe_to_u32x8(a.v[1], w1); }
+BN_FN bool lane_pair_all_zero(const FeP &a) { return fe_is_zero(a.v[0]) && fe_is_zero(a.v[1]); }
+}  // namespace bn254
