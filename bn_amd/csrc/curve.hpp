@@ -19,6 +19,7 @@ struct FqField {
     static BN_FN T mul(const T &a, const T &b) { return fe_mul(a, b); }
     static BN_FN T sqr(const T &a) { return fe_sqr(a); }
     template <int C1, int C2, int C3> static BN_FN T lc3(const T &x, const T &y, const T &z) { return fe_lc3<C1, C2, C3>(x, y, z); }
+    template <int C1, int C2, int C3> static BN_FN T lc3w(const T &x, const T &y, const T &z) { return fe_lc3w<C1, C2, C3>(x, y, z); }
     static BN_FN T zero() { return fe_zero(); }
     static BN_FN T one() { return fe_one(); }
     static BN_FN T select(bool b, const T &x, const T &y) { return fe_select(b, x, y); }
@@ -31,6 +32,7 @@ struct Fq2Field {
     static BN_FN T mul(const T &a, const T &b) { return f2_mul(a, b); }
     static BN_FN T sqr(const T &a) { return f2_sqr(a); }
     template <int C1, int C2, int C3> static BN_FN T lc3(const T &x, const T &y, const T &z) { return f2_lc3<C1, C2, C3>(x, y, z); }
+    template <int C1, int C2, int C3> static BN_FN T lc3w(const T &x, const T &y, const T &z) { return f2_lc3w<C1, C2, C3>(x, y, z); }
     static BN_FN T zero() { return f2_zero((const F2 *)nullptr); }
     static BN_FN T one() { return f2_one((const F2 *)nullptr); }
     static BN_FN T select(bool b, const T &x, const T &y) { return f2_select(b, x, y); }
@@ -46,7 +48,7 @@ BN_COARSE Jac<F> jac_double(const Jac<F> &p) {
     using T = typename F::T;
     T a = F::sqr(p.x), b = F::sqr(p.y), c = F::sqr(b);
     T t = F::sqr(F::template lc3<1, 1, 0>(p.x, b, b));
-    T d = F::template lc3<2, -2, -2>(t, a, c);
+    T d = F::template lc3w<2, -2, -2>(t, a, c);
     T e = F::template lc3<3, 0, 0>(a, a, a);
     T f = F::sqr(e);
     Jac<F> r;

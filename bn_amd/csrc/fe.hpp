@@ -56,7 +56,7 @@
             std::abort();                                                                                   \
         }                                                                                                   \
     } while (0)
-#define BN_SETB(x, LBV, VBV) ((x).lb = (LBV), (x).vb = (VBV))
+#define BN_SETB(x, LBV, VBV) ((x).lb = (LBV), (x).vb = (VBV), (x).sg = false)
 #define BN_IFB(...) __VA_ARGS__
 #else
 #define BN_REQUIRE(cond, what) ((void)0)
@@ -72,6 +72,7 @@ struct Fe {
     uint32_t l[9];
 #if defined(BN_BOUNDS)
     uint32_t lb = 1, vb = 1;
+    bool sg = false;      // "signed lazy": limbs are int32 in two's complement, the value may be negative (only fe_lc3 takes these)
 #endif
 };
 
@@ -154,19 +155,34 @@ struct Bias {
 // ---------------------------------------------------------------------------------------------------------------------
 // lazy additive ops (arith.rs:238-253,266-273 do these with a conditional correction per call; here: none)
 BN_FN Fe fe_add(const Fe &a, const Fe &b) {
-    BN_REQUIRE(a.lb + b.lb <= 8, "fe_add limb overflow");
+    BN_REQUIRE(a.lb + b.lb <= ((a.sg || b.sg) ? 4u : 8u), "fe_add limb overflow");
     BN_REQUIRE(a.vb + b.vb <= 1024, "fe_add value overflow");
     Fe r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+    BN_IFB(bool sg_ = a.sg || b.sg;)
     BN_SETB(r, a.lb + b.lb, a.vb + b.vb);
+    BN_IFB(r.sg = sg_;)
     return r;
 }
 BN_FN Fe fe_dbl(const Fe &a) { return fe_add(a, a); }
+// signed lazy difference: plain limb-wise a - b, limbs become int32 (two's complement), no bias and no carries.  Only
+// fe_lc3 may consume the result (it interprets every input limb as a signed 32-bit integer).
+BN_FN Fe fe_ssub(const Fe &a, const Fe &b) {
+    BN_REQUIRE(a.lb + b.lb <= 4, "fe_ssub limb overflow (|limb| must stay < 2^31)");
+    BN_REQUIRE(a.vb + b.vb <= 1024, "fe_ssub value overflow");
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i];
+    BN_SETB(r, a.lb + b.lb, a.vb + b.vb);
+    BN_IFB(r.sg = true;)
+    return r;
+}
 
 // a - b (mod q) as a + K*q - b, b must satisfy lb <= LB and vb <= K-1
 template <int LB, int K>
 BN_FN Fe fe_sub(const Fe &a, const Fe &b) {
+    BN_REQUIRE(!a.sg && !b.sg, "fe_sub on a signed lazy value");
     BN_REQUIRE(b.lb <= (uint32_t)LB, "fe_sub: subtrahend limbs exceed the bias");
     BN_REQUIRE(b.vb + 1 <= (uint32_t)K, "fe_sub: subtrahend value exceeds the bias");
     BN_REQUIRE(a.lb + LB + 1 <= 8, "fe_sub limb overflow");
@@ -180,6 +196,7 @@ BN_FN Fe fe_sub(const Fe &a, const Fe &b) {
 }
 template <int LB, int K>
 BN_FN Fe fe_neg(const Fe &b) {
+    BN_REQUIRE(!b.sg, "fe_neg on a signed lazy value");
     BN_REQUIRE(b.lb <= (uint32_t)LB, "fe_neg: limbs exceed the bias");
     BN_REQUIRE(b.vb + 1 <= (uint32_t)K, "fe_neg: value exceeds the bias");
     constexpr Bias<LB, K> B{};
@@ -192,6 +209,7 @@ BN_FN Fe fe_neg(const Fe &b) {
 
 // carry propagation only: limbs back to 29 bits, value unchanged
 BN_FN Fe fe_norm(const Fe &a) {
+    BN_REQUIRE(!a.sg, "fe_norm on a signed lazy value");
     Fe r;
     uint32_t c = 0;
 #pragma unroll
@@ -210,7 +228,7 @@ BN_FN Fe fe_norm(const Fe &a) {
 // `scale` multiplies the input by a small constant first (1, 9, ...): reduce(scale * a).
 template <int SCALE = 1>
 BN_FN Fe fe_reduce(const Fe &a) {
-    BN_REQUIRE(a.lb <= 8, "fe_reduce lb");
+    BN_REQUIRE(a.lb <= 8 && !a.sg, "fe_reduce lb");
     BN_REQUIRE((uint64_t)a.vb * SCALE <= 1000, "fe_reduce vb");
     // top ~ floor(SCALE*value / 2^232), never above it (carries still parked in lower limbs are ignored: at most ~8*SCALE)
     uint32_t top = (uint32_t)SCALE * (a.l[8] + (a.l[7] >> 29));
@@ -235,30 +253,69 @@ BN_FN Fe fe_reduce(const Fe &a) {
 template <int C1, int C2, int C3>
 BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) {
     constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3;
-    BN_REQUIRE((C1 == 0 || x.lb <= 8) && (C2 == 0 || y.lb <= 8) && (C3 == 0 || z.lb <= 8), "fe_lc3 lb");
+    // Every input limb is read as a SIGNED 32-bit integer (so inputs may be signed lazy differences, fe_ssub): |limb| < 2^31,
+    // i.e. lb <= 4.  Terms with a small coefficient are first combined in 32-bit arithmetic ("narrow"); the others enter the
+    // 64-bit chain on their own.
+    constexpr bool N1 = C1 != 0 && A1 <= 2, N2 = C2 != 0 && A2 <= 2, N3 = C3 != 0 && A3 <= 2;
+    BN_IFB(if (!((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4)))
+               std::fprintf(stderr, "fe_lc3<%d,%d,%d> lbs %u %u %u\n", C1, C2, C3, x.lb, y.lb, z.lb);)
+    BN_REQUIRE((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4), "fe_lc3: input limbs must fit int32");
     BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb <= 1000, "fe_lc3 vb");
-    // signed estimate of floor(value / 2^232) that never exceeds the truth: positive terms use a low estimate of their
-    // top (carries parked in lower limbs ignored), negative terms a high one (+9)
-    auto top = [](const Fe &f) -> int64_t { return (int64_t)f.l[8] + (int64_t)(f.l[7] >> 29); };
-    int64_t c2 = neg2 ? -(int64_t)C2 : (int64_t)C2;
-    int64_t te = -600 - 9 * (int64_t)(A1 + A2 + A3);   // margins: FE_MU24 truncation (< 2^9 units) and the +9 of negative terms
+    BN_IFB(if ((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) > 4)
+               std::fprintf(stderr, "fe_lc3<%d,%d,%d> lbs %u %u %u\n", C1, C2, C3, x.lb, y.lb, z.lb);)
+    BN_REQUIRE((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) <= 4, "fe_lc3 narrow part exceeds 32 bits");
+    // signed estimate of floor(value / 2^232) that never exceeds the truth (margins: carries still parked in lower limbs,
+    // at most 9 per unit coefficient, and the truncation of FE_MU24, < 2^9 units)
+    auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8] + ((int32_t)f.l[7] >> 29); };
+    const int32_t c2 = neg2 ? -C2 : C2;
+    int64_t te = -600 - 9 * (int64_t)(A1 + A2 + A3);
     if (C1 != 0) te += (int64_t)C1 * top(x);
-    if (C2 != 0) te += c2 * top(y);
+    if (C2 != 0) te += (int64_t)c2 * top(y);
     if (C3 != 0) te += (int64_t)C3 * top(z);
-    int64_t kq = (te * (int64_t)k::FE_MU24) >> 45;          // floor; kq <= floor(value/q), kq >= value/q - 2
+    const int64_t kq = (te * (int64_t)k::FE_MU24) >> 45;     // floor; kq <= floor(value/q), kq >= value/q - 2
+    Fe r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int32_t nsum = 0;
+        if (N1) nsum += C1 * (int32_t)x.l[i];
+        if (N2) { int32_t yy = C2 * (int32_t)y.l[i]; nsum += neg2 ? -yy : yy; }
+        if (N3) nsum += C3 * (int32_t)z.l[i];
+        int64_t t = carry + (int64_t)nsum - kq * (int64_t)k::Q[i];
+        if (C1 != 0 && !N1) t += (int64_t)C1 * (int64_t)(int32_t)x.l[i];
+        if (C2 != 0 && !N2) t += (int64_t)c2 * (int64_t)(int32_t)y.l[i];
+        if (C3 != 0 && !N3) t += (int64_t)C3 * (int64_t)(int32_t)z.l[i];
+        if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
+    }
+    BN_SETB(r, 1, 3);
+    return r;
+}
+// all-64-bit variant for UNSIGNED lazy inputs with limbs beyond 31 bits (lb up to 8); rare call sites only
+template <int C1, int C2, int C3>
+BN_FN Fe fe_lc3w_body(const Fe &x, const Fe &y, const Fe &z) {
+    constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3;
+    BN_REQUIRE((C1 == 0 || (x.lb <= 8 && !x.sg)) && (C2 == 0 || (y.lb <= 8 && !y.sg)) && (C3 == 0 || (z.lb <= 8 && !z.sg)), "fe_lc3w lb");
+    BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb <= 1000, "fe_lc3w vb");
+    auto top = [](const Fe &f) -> int64_t { return (int64_t)f.l[8] + (int64_t)(f.l[7] >> 29); };
+    int64_t te = -600 - 9 * (int64_t)(A1 + A2 + A3);
+    if (C1 != 0) te += (int64_t)C1 * top(x);
+    if (C2 != 0) te += (int64_t)C2 * top(y);
+    if (C3 != 0) te += (int64_t)C3 * top(z);
+    const int64_t kq = (te * (int64_t)k::FE_MU24) >> 45;
     Fe r;
     int64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         int64_t t = carry - kq * (int64_t)k::Q[i];
         if (C1 != 0) t += (int64_t)C1 * (int64_t)x.l[i];
-        if (C2 != 0) t += c2 * (int64_t)y.l[i];
+        if (C2 != 0) t += (int64_t)C2 * (int64_t)y.l[i];
         if (C3 != 0) t += (int64_t)C3 * (int64_t)z.l[i];
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
     BN_SETB(r, 1, 3);
     return r;
 }
+BN_LEAF3T(fe_lc3w, fe_lc3w_body)
 template <int C1, int C2, int C3>
 BN_FN Fe fe_lc3_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3>(x, y, z, false); }
 BN_LEAF3T(fe_lc3, fe_lc3_body)
@@ -270,6 +327,7 @@ BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any l
 // Column bound: 9*(la*lb) * 2^58 + 9 * 2^58 + carry < 2^64  <=>  la*lb <= 6.
 // Value: result < (A*B/169.3 + 1) q, so A*B <= 169 gives < 2q.
 BN_FN Fe fe_mul_body(const Fe &a, const Fe &b) {
+    BN_REQUIRE(!a.sg && !b.sg, "fe_mul on a signed lazy value");
     BN_REQUIRE(a.lb * b.lb <= 6, "fe_mul column overflow");
     BN_REQUIRE(a.vb * b.vb <= 169, "fe_mul value bound");
     uint64_t acc = 0;
@@ -303,6 +361,7 @@ BN_FN Fe fe_sqr(const Fe &a) { return fe_mul(a, a); }
 
 // (a*u + c*v) / R with ONE reduction: 162 + 81 mads.   Column bound: la*lu + lc*lv <= 6; value: A*U + C*V <= 169.
 BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
+    BN_REQUIRE(!a.sg && !u.sg && !c.sg && !v.sg, "fe_mul2 on a signed lazy value");
     BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 6, "fe_mul2 column overflow");
     BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 169, "fe_mul2 value bound");
     uint64_t acc = 0;

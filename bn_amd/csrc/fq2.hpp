@@ -29,12 +29,17 @@ BN_FN Fq2A f2_add(const Fq2A &a, const Fq2A &b) { return {fe_add(a.c0, b.c0), fe
 BN_FN Fq2A f2_dbl(const Fq2A &a) { return f2_add(a, a); }
 template <int LB, int K>
 BN_FN Fq2A f2_sub(const Fq2A &a, const Fq2A &b) { return {fe_sub<LB, K>(a.c0, b.c0), fe_sub<LB, K>(a.c1, b.c1)}; }
+BN_FN Fq2A f2_ssub(const Fq2A &a, const Fq2A &b) { return {fe_ssub(a.c0, b.c0), fe_ssub(a.c1, b.c1)}; }
 BN_FN Fq2A f2_norm(const Fq2A &a) { return {fe_norm(a.c0), fe_norm(a.c1)}; }
 BN_FN Fq2A f2_std(const Fq2A &a) { return {fe_std(a.c0), fe_std(a.c1)}; }
 // componentwise reduce(C1*x + C2*y + C3*z)
 template <int C1, int C2, int C3>
 BN_FN Fq2A f2_lc3(const Fq2A &x, const Fq2A &y, const Fq2A &z) {
     return {fe_lc3<C1, C2, C3>(x.c0, y.c0, z.c0), fe_lc3<C1, C2, C3>(x.c1, y.c1, z.c1)};
+}
+template <int C1, int C2, int C3>
+BN_FN Fq2A f2_lc3w(const Fq2A &x, const Fq2A &y, const Fq2A &z) {
+    return {fe_lc3w<C1, C2, C3>(x.c0, y.c0, z.c0), fe_lc3w<C1, C2, C3>(x.c1, y.c1, z.c1)};
 }
 BN_FN Fq2A f2_neg(const Fq2A &a) { return f2_lc3<-1, 0, 0>(a, a, a); }
 BN_FN Fq2A f2_conj(const Fq2A &a) { return {a.c0, fe_lc3<-1, 0, 0>(a.c1, a.c1, a.c1)}; }
@@ -143,10 +148,13 @@ BN_FN Fe f2b_sqr(const Fe &a) { return bn_unv(f2b_sqr_leaf(bn_tov(a))); }
 template <class T> BN_FN Fq2B<T> f2_add(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_add(a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_dbl(const Fq2B<T> &a) { return {fe_dbl(a.v)}; }
 template <int LB, int K, class T> BN_FN Fq2B<T> f2_sub(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_sub<LB, K>(a.v, b.v)}; }
+template <class T> BN_FN Fq2B<T> f2_ssub(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_ssub(a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_norm(const Fq2B<T> &a) { return {fe_norm(a.v)}; }
 template <class T> BN_FN Fq2B<T> f2_std(const Fq2B<T> &a) { return {fe_std(a.v)}; }
 template <int C1, int C2, int C3, class T>
 BN_FN Fq2B<T> f2_lc3(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc3<C1, C2, C3>(x.v, y.v, z.v)}; }
+template <int C1, int C2, int C3, class T>
+BN_FN Fq2B<T> f2_lc3w(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc3w<C1, C2, C3>(x.v, y.v, z.v)}; }
 template <class T> BN_FN Fq2B<T> f2_neg(const Fq2B<T> &a) { return {fe_lc3<-1, 0, 0>(a.v, a.v, a.v)}; }
 template <class T> BN_FN Fq2B<T> f2_conj(const Fq2B<T> &a) { return {lane_pick(a.v, fe_lc3<-1, 0, 0>(a.v, a.v, a.v))}; }
 template <class T> BN_FN Fq2B<T> f2_neg_lazy(const Fq2B<T> &a) { return {fe_neg<1, 4>(a.v)}; }

@@ -28,7 +28,7 @@ BN_COARSE Line<F2> doubling_step(G2Proj<F2> &r) {
     F2 h = f2_lc3<1, -1, -1>(f2_sqr(f2_lc3<1, 1, 0>(r.y, r.z, r.z)), b, c);
     F2 j = f2_sqr(r.x), e_sq = f2_sqr(e);
     Line<F2> l;
-    l.ell_0 = f2_mul_xi(f2_sub<1, 4>(e, b));                             // xi * (e - b)
+    l.ell_0 = f2_mul_xi(f2_ssub(e, b));                             // xi * (e - b)
     l.ell_vw = f2_neg_lazy(h);
     l.ell_vv = f2_add(f2_add(j, j), j);
     r.x = f2_mul(a, f2_lc3<1, -3, 0>(b, e, e));                          // a (b - f)
@@ -45,7 +45,7 @@ BN_COARSE Line<F2> addition_step(G2Proj<F2> &r, const G2Aff<F2> &base) {
     F2 h = f2_mul(d, f), i = f2_mul(r.x, f);
     F2 j = f2_lc3<1, -2, 0>(f2_add(f2_mul(r.z, g), h), i, i);
     Line<F2> l;
-    l.ell_0 = f2_mul_xi(f2_sub<1, 4>(f2_mul(e, base.x), f2_mul(d, base.y)));
+    l.ell_0 = f2_mul_xi(f2_ssub(f2_mul(e, base.x), f2_mul(d, base.y)));
     l.ell_vv = f2_neg_lazy(e);
     l.ell_vw = d;
     F2 ny = f2_lc3<1, -1, 0>(f2_mul(e, f2_lc3<1, -1, 0>(i, j, j)), f2_mul(h, r.y), h);

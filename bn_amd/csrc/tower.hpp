@@ -36,8 +36,8 @@ BN_COARSE Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
     F2 t0 = f2_mul(f2_add(a.c1, a.c2), f2_norm(f2_add(b.c1, b.c2)));
     F2 t1 = f2_mul(f2_add(a.c0, a.c1), f2_norm(f2_add(b.c0, b.c1)));
     F2 t2 = f2_mul(f2_add(a.c0, a.c2), f2_norm(f2_add(b.c0, b.c2)));
-    F2 x0 = f2_sub<1, 4>(f2_sub<1, 4>(t0, bb), cc);            // a1 b2 + a2 b1, lazy
-    F2 y1 = f2_sub<1, 4>(f2_sub<1, 4>(t1, aa), bb);            // a0 b1 + a1 b0, lazy
+    F2 x0 = f2_ssub(f2_ssub(t0, bb), cc);            // a1 b2 + a2 b1, lazy
+    F2 y1 = f2_ssub(f2_ssub(t1, aa), bb);            // a0 b1 + a1 b0, lazy
     Fq6<F2> r;
     r.c0 = f2_lc_xi<1, 1>(x0, aa);
     r.c1 = f2_lc_xi<1, 1>(cc, y1);
@@ -54,7 +54,7 @@ BN_COARSE Fq6<F2> f6_sqr(const Fq6<F2> &a) {
     Fq6<F2> r;
     r.c0 = f2_lc_xi<1, 1>(s3, s0);
     r.c1 = f2_lc_xi<1, 1>(s4, s1);
-    r.c2 = f2_lc3<1, -1, -1>(f2_add(f2_add(s1, s2), s3), s0, s4);
+    r.c2 = f2_lc3w<1, -1, -1>(f2_add(f2_add(s1, s2), s3), s0, s4);
     return r;
 }
 template <class F2> BN_FN Fq6<F2> f6_scale(const Fq6<F2> &a, const F2 &by) { return {f2_mul(a.c0, by), f2_mul(a.c1, by), f2_mul(a.c2, by)}; }
@@ -102,7 +102,7 @@ BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     u.c2 = f2_lc3<1, 1, 0>(a.c1.c1, a.c0.c2, a.c0.c2);
     Fq6<F2> t = f6_mul(u, f6_add(a.c0, a.c1));
     Fq12<F2> r;
-    r.c0.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_sub<1, 4>(t.c0, ab.c0));      // t - ab - v*ab
+    r.c0.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_ssub(t.c0, ab.c0));      // t - ab - v*ab
     r.c0.c1 = f2_lc3<1, -1, -1>(t.c1, ab.c1, ab.c0);
     r.c0.c2 = f2_lc3<1, -1, -1>(t.c2, ab.c2, ab.c1);
     r.c1 = f6_lc3<2, 0, 0>(ab, ab, ab);
@@ -149,9 +149,9 @@ BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &
     r.c0.c0 = f2_lc_xi<1, 1>(f2_add(z1x2, d4), d0);
     r.c0.c1 = f2_lc_xi<1, 1>(f2_add(z5x4, d2), z1x0);
     r.c0.c2 = f2_lc3<1, -1, -1>(f2_add(m02, z3x4), d0, d2);
-    r.c1.c0 = f2_lc_xi<1, 1>(f2_sub<1, 4>(f2_sub<1, 4>(m24, d2), d4), z3x0);
-    r.c1.c1 = f2_lc_xi<1, 1>(z5x2, f2_sub<1, 4>(f2_sub<1, 4>(m04, d0), d4));
-    r.c1.c2 = f2_lc3<1, -1, 0>(ms, s1, s1);
+    r.c1.c0 = f2_lc_xi<1, 1>(f2_ssub(f2_ssub(m24, d2), d4), z3x0);
+    r.c1.c1 = f2_lc_xi<1, 1>(z5x2, f2_ssub(f2_ssub(m04, d0), d4));
+    r.c1.c2 = f2_lc3w<1, -1, 0>(ms, s1, s1);
     return r;
 }
 
@@ -161,7 +161,7 @@ template <class F2>
 BN_FN void f4_sq(const F2 &a, const F2 &b, F2 &t_even, F2 &tmp_out) {       // (a + b s)^2, s^2 = xi: even = a^2 + xi b^2, tmp = a b
     F2 tmp = f2_mul(a, b);
     F2 m = f2_mul(f2_add(a, b), f2_lc_xi<1, 1>(b, a));
-    t_even = f2_lc_xi<-1, 1>(tmp, f2_sub<1, 4>(m, tmp));
+    t_even = f2_lc_xi<-1, 1>(tmp, f2_ssub(m, tmp));
     tmp_out = tmp;
 }
 template <class F2>

@@ -32,9 +32,17 @@ EXPORT void hs_fe_lazy_mix(const uint32_t *a, const uint32_t *b, const uint32_t 
     Fe x = fe_from_u32x8(a), y = fe_from_u32x8(b), z = fe_from_u32x8(c);
     Fe s = fe_add(fe_add(x, y), fe_add(x, y));                    // 2x + 2y  (4,8)
     Fe d = fe_sub<1, 3>(fe_sub<1, 3>(s, y), z);                   // 2x + y - z (8, 14)
-    Fe r = fe_lc3<9, -1, 3>(d, x, z);                             // 18x + 9y - 9z - x + 3z = 17x + 9y - 6z
+    Fe r = fe_lc3w<9, -1, 3>(d, x, z);                            // 18x + 9y - 9z - x + 3z = 17x + 9y - 6z
     Fe n = fe_norm(fe_add(r, fe_reduce<9>(y)));                   // + 9y
     fe_to_u32x8(fe_mul(n, fe_one()), o);                          // = 17x + 18y - 6z
+}
+// signed lazy differences through the narrow/wide reduction: 9(x-y-z) - (y-x) + z = 10x - 10y - 8z
+EXPORT void hs_fe_signed_mix(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *o) {
+    Fe x = fe_from_u32x8(a), y = fe_from_u32x8(b), z = fe_from_u32x8(c);
+    Fe u = fe_ssub(fe_ssub(x, y), z);
+    Fe r = fe_lc3<9, -1, 1>(u, fe_ssub(y, x), z);
+    Fe r2 = fe_lc3_core<9, 1, 1>(u, fe_ssub(y, x), z, true);     // run-time negated middle term: same value
+    fe_to_u32x8(fe_mul(fe_lc3<1, 1, -1>(r, r2, r), fe_one()), o);
 }
 EXPORT void hs_fe_mul2(const uint32_t *a, const uint32_t *u, const uint32_t *c, const uint32_t *v, uint32_t *o) {
     fe_to_u32x8(fe_mul2(fe_from_u32x8(a), fe_from_u32x8(u), fe_from_u32x8(c), fe_from_u32x8(v)), o);

@@ -45,6 +45,8 @@ def test_fe_lazy_forms(oracle, hs):
         ai, bi, ci = (oracle.fp_to_int(FQ, x) for x in (a, b, c))
         want = oracle.fp_from_int(FQ, (17 * ai + 18 * bi - 6 * ci) % M.Q)
         assert np.array_equal(hs.call("hs_fe_lazy_mix", a, b, c, out_words=8), want)
+        want = oracle.fp_from_int(FQ, (10 * ai - 10 * bi - 8 * ci) % M.Q)
+        assert np.array_equal(hs.call("hs_fe_signed_mix", a, b, c, out_words=8), want)
         want = oracle.fp_add(FQ, oracle.fp_mul(FQ, a, b), oracle.fp_mul(FQ, c, d))
         assert np.array_equal(hs.call("hs_fe_mul2", a, b, c, d, out_words=8), want)
 
@@ -110,3 +112,56 @@ def test_pairing_random_and_edges(oracle, hs):
     one = oracle.fq12_one()
     assert np.array_equal(hs.call("hs_pairing", oracle.g1_zero(), oracle.g2_one(), out_words=96), one)
     assert np.array_equal(hs.call("hs_pairing", oracle.g1_one(), oracle.g2_zero(), out_words=96), one)
+
+
+def test_lane_pair_mapping(oracle, hs, kats):
+    """Fq2B (one element per lane pair) executed on a simulated lane pair: same bytes as the oracle"""
+    rng = np.random.default_rng(17)
+    for _ in range(20):
+        a, b = _rf(oracle, rng, 2), _rf(oracle, rng, 2)
+        assert np.array_equal(hs.call("hsb_fq2_mul", a, b, out_words=16), oracle.fq2_mul(a, b))
+        assert np.array_equal(hs.call("hsb_fq2_sqr", a, out_words=16), oracle.fq2_sqr(a))
+        assert np.array_equal(hs.call("hsb_fq2_mul_xi", a, out_words=16), oracle.fq2_mul_xi(a))
+        assert np.array_equal(hs.call("hsb_fq2_inverse", a, out_words=16), oracle.fq2_inverse(a))
+    for a in [oracle.fq12_from_ints(kats["fq12_test_vector"]["start"]), oracle.fq12_one()] + [_rf(oracle, rng, 12) for _ in range(3)]:
+        b = _rf(oracle, rng, 12)
+        assert np.array_equal(hs.call("hsb_fq12_mul", a, b, out_words=96), oracle.fq12_mul(a, b))
+        assert np.array_equal(hs.call("hsb_fq12_sqr", a, out_words=96), oracle.fq12_sqr(a))
+        assert np.array_equal(hs.call("hsb_fq12_cyclotomic_sqr", a, out_words=96), oracle.fq12_cyclotomic_squared(a))
+        assert np.array_equal(hs.call("hsb_fq12_inverse", a, out_words=96), oracle.fq12_inverse(a))
+        for p in (1, 2, 3):
+            assert np.array_equal(hs.call("hsb_fq12_frobenius", a, p, out_words=96), oracle.fq12_frobenius_map(a, p))
+        l = _rf(oracle, rng, 6)
+        assert np.array_equal(hs.call("hsb_fq12_mul_by_024", a, l[:8], l[8:16], l[16:], out_words=96),
+                              oracle.fq12_mul_by_024(a, l[:8], l[8:16], l[16:]))
+    a = _rf(oracle, rng, 12)
+    assert np.array_equal(hs.call("hsb_final_exponentiation", a, out_words=96), oracle.fq12_final_exponentiation(a))
+    I = lambda l: [int(x) for x in l]
+    k1 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k1"]); k2 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k2"])
+    P = oracle.g1_mul(oracle.g1_one(), k1); Q = oracle.g2_mul(oracle.g2_one(), k2)
+    assert oracle.fq12_to_ints(hs.call("hsb_pairing", P, Q, out_words=96)) == I(kats["test_reduced_pairing"]["expected"])
+    for _ in range(3):
+        P = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)); Q = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng))
+        assert np.array_equal(hs.call("hsb_pairing", P, Q, out_words=96), oracle.pairing(P, Q))
+    assert np.array_equal(hs.call("hsb_pairing", oracle.g1_zero(), Q, out_words=96), oracle.fq12_one())
+    assert np.array_equal(hs.call("hsb_pairing", oracle.g1_one(), oracle.g2_one(), out_words=96), oracle.pairing(oracle.g1_one(), oracle.g2_one()))
+
+
+def _fr(oracle, rng):
+    return oracle.fp_from_int(FR, int.from_bytes(rng.bytes(40), "little") % M.R_ORD)
+
+
+def test_scalar_mul_reference_chain(oracle, hs):
+    """G * Fr through the engine's Jacobian code: the raw coordinates equal the reference's double-and-add chain bit for bit"""
+    rng = np.random.default_rng(18)
+    ks = [0, 1, 2, 3, M.R_ORD - 1, M.R_ORD - 2, 1 << 200] + [int.from_bytes(rng.bytes(40), "little") % M.R_ORD for _ in range(3)]
+    b1 = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, 777)); b2 = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_int(FR, 999))
+    for kv in ks:
+        k = oracle.fp_from_int(FR, kv)
+        raw = hs.call("hs_fr_from_mont", k, out_words=8)
+        assert sum(int(x) << (64 * i) for i, x in enumerate(raw)) == kv
+        for base, fn, w, om, on in ((b1, "hs_g1_mul", 12, oracle.g1_mul, oracle.g1_normalize), (oracle.g1_zero(), "hs_g1_mul", 12, oracle.g1_mul, oracle.g1_normalize),
+                                    (b2, "hs_g2_mul", 24, oracle.g2_mul, oracle.g2_normalize), (oracle.g2_one(), "hs_g2_mul", 24, oracle.g2_mul, oracle.g2_normalize)):
+            want = om(base, k)
+            assert np.array_equal(hs.call(fn, base, k, 0, out_words=2 * w), want)
+            assert np.array_equal(hs.call(fn, base, k, 1, out_words=2 * w), on(want))
