@@ -76,9 +76,9 @@ def all_gather_partials(partial, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return partial.reshape(1, GT_WORDS)
     world = dist.get_world_size(group)
-    out = torch.empty((world, GT_WORDS), dtype=partial.dtype, device=partial.device)
-    dist.all_gather_into_tensor(out, partial.contiguous(), group=group)
-    return out
+    out = torch.empty(world * GT_WORDS, dtype=partial.dtype, device=partial.device)
+    dist.all_gather_into_tensor(out, partial.contiguous().reshape(GT_WORDS), group=group)
+    return out.reshape(world, GT_WORDS)
 
 
 def pairing_product_sharded(eng, p_local, q_local, group=None):

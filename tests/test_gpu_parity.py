@@ -126,3 +126,50 @@ def test_both_lane_mappings_agree_with_oracle(oracle, mapping):
     P[5] = oracle.g1_zero(); Q[6] = oracle.g2_zero(); P[7] = oracle.g1_one(); Q[7] = oracle.g2_one()
     assert np.array_equal(e.pairing_batch(P, Q), oracle.pairing_batch(P, Q))
     assert np.array_equal(e.pairing_product(P[:33], Q[:33]), oracle.pairing_product(P[:33], Q[:33]))
+
+
+def test_device_resident_path_and_input_generator(oracle):
+    """what bench.py runs: inputs generated on the device by the reference's double-and-add chain (bit-identical Jacobian
+    limbs to the oracle's), pairings through the device-pointer API on torch tensors, and the sharded product on one rank"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    eng = D.TorchEngine(bn_amd.Engine(0), dev)
+    lo, hi = 1000, 1000 + 150
+    P, Q = D.synthetic_points(eng, lo, hi)
+    k1 = D.synthetic_scalars(lo, hi, 0); k2 = D.synthetic_scalars(lo, hi, 1)
+    n = hi - lo
+    Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
+    assert np.array_equal(Pn, oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (n, 1)), k1))
+    assert np.array_equal(Qn, oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (n, 1)), k2))
+    out = D.pairing_batch_sharded(eng, P, Q)
+    torch.cuda.synchronize()
+    want = oracle.pairing_batch(Pn, Qn)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    gt = D.pairing_product_sharded(eng, P, Q)
+    torch.cuda.synchronize()
+    assert np.array_equal(gt.cpu().numpy().view(np.uint64), oracle.pairing_product(Pn, Qn))
+
+
+def test_full_size_batch_properties(oracle):
+    """BASELINE.json configs[1] size (2^16): a 1024-index random sample against the oracle, both lane mappings agree on the
+    whole batch, determinism, and product(batch) == pairing_product (size-independent checks)"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    n = 1 << 16
+    engB = D.TorchEngine(bn_amd.Engine(0, mapping=1), dev)
+    engA = D.TorchEngine(bn_amd.Engine(0, mapping=0), dev)
+    P, Q = D.synthetic_points(engB, 0, n)
+    outB = D.pairing_batch_sharded(engB, P, Q); outB2 = D.pairing_batch_sharded(engB, P, Q); outA = D.pairing_batch_sharded(engA, P, Q)
+    torch.cuda.synchronize()
+    assert torch.equal(outB, outB2) and torch.equal(outA, outB)
+    idx = np.random.default_rng(5).choice(n, 1024, replace=False)
+    Pn = P.cpu().numpy().view(np.uint64)[idx]; Qn = Q.cpu().numpy().view(np.uint64)[idx]
+    assert np.array_equal(outB.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn, Qn))
+    prod_of_batch = engB.gt_product(outB)                       # product of the 2^16 reduced pairings ...
+    prod = D.pairing_product_sharded(engB, P, Q)                # ... equals the multi-pairing with ONE final exponentiation
+    torch.cuda.synchronize()
+    assert torch.equal(prod_of_batch, prod)

@@ -1,0 +1,163 @@
+"""CPU tests of everything around the kernels: the C-ABI library loads and exports every declared symbol, the generated device
+constants equal the reference's literals, sharding + the one all-gather of the multi-pairing (gloo, world_size 2), input
+generation.  No GPU compute here."""
+import json
+import os
+import pathlib
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bn_model as M
+from bn_oracle import FQ, FR
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from bn_amd import _native
+    hdr = (ROOT / "include" / "bn254_hip.h").read_text()
+    declared = set(re.findall(r"^(?:int|void|const char \*)\s*\*?(bn254_\w+)\s*\(", hdr, re.M))
+    assert len(declared) >= 20
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    _native.build()
+    lib = _native.lib()                       # resolves every symbol, AttributeError otherwise
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.bn254_error_string(-1).decode().startswith("no usable HIP device")
+
+
+def test_fails_loudly_without_gpu():
+    import bn_amd
+    from bn_amd import _native
+    if _native.lib().bn254_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_native.Bn254Error):
+        bn_amd.Engine(0)
+    with pytest.raises(_native.Bn254Error):
+        bn_amd.pairing(bn_amd.G1.one(), bn_amd.G2.one())
+
+
+def _hdr_arrays():
+    txt = (ROOT / "bn_amd" / "csrc" / "bn254_constants.hpp").read_text()
+    out = {}
+    for m in re.finditer(r"BN254_CONSTANT uint32_t (\w+)((?:\[\d+\])+) = (\{.*?\});", txt, re.S):
+        vals = [int(x, 16) for x in re.findall(r"0x[0-9a-f]+", m.group(3))]
+        out[m.group(1)] = vals
+    for m in re.finditer(r"BN254_CONSTANT uint(?:32|64)_t (\w+) = (0x[0-9a-f]+)", txt):
+        out[m.group(1)] = int(m.group(2), 16)
+    return out
+
+
+def _val(limbs9):
+    return sum(v << (29 * i) for i, v in enumerate(limbs9))
+
+
+def test_device_constants_equal_reference_literals(ref_consts):
+    """bn254_constants.hpp (radix 2^29, Montgomery 2^261, derived from u) -> reference image (radix 2^64, Montgomery 2^256)"""
+    h = _hdr_arrays()
+    R261 = 1 << 261
+    def ref_image(limbs9):                       # internal Montgomery value -> the reference's 4 x u64 Montgomery limbs
+        canon = _val(limbs9) * pow(R261, -1, M.Q) % M.Q
+        return M.to_mont_limbs(canon)
+    assert _val(h["Q"]) == M.Q and h["QINV"] == (-pow(M.Q, -1, 1 << 29)) % (1 << 29)
+    assert _val(h["ONE"]) == R261 % M.Q and _val(h["C_IN"]) == (1 << 266) % M.Q and _val(h["C_OUT"]) == (1 << 256) % M.Q
+    assert h["FE_MU"] == (1 << 285) // M.Q and h["FE_MU24"] == (1 << 277) // M.Q
+    assert ref_image(h["TWO_INV"]) == ref_consts["two_inv"]
+    assert [ref_image(h["G2_B"][:9]), ref_image(h["G2_B"][9:])] == ref_consts["g2_coeff_b"]
+    b3 = [(3 * _val(h["G2_B"][:9])) % M.Q, (3 * _val(h["G2_B"][9:])) % M.Q]
+    assert [_val(h["G2_3B"][:9]), _val(h["G2_3B"][9:])] == b3
+    for name, key in (("FROB6_C1", "fq6_frobenius_coeffs_c1"), ("FROB6_C2", "fq6_frobenius_coeffs_c2"), ("FROB12_C1", "fq12_frobenius_coeffs_c1")):
+        tab = h[name]
+        assert len(tab) == 4 * 2 * 9
+        for p in (1, 2, 3):
+            c0 = tab[(2 * p) * 9:(2 * p + 1) * 9]; c1 = tab[(2 * p + 1) * 9:(2 * p + 2) * 9]
+            lit = ref_consts[key][str(p)]
+            assert ref_image(c0) == lit[0]
+            assert (ref_image(c1) == lit[1]) if len(lit) == 2 else (_val(c1) == 0)
+    assert [ref_image(h["TWIST_MUL_BY_Q_X"][:9]), ref_image(h["TWIST_MUL_BY_Q_X"][9:])] == ref_consts["twist_mul_by_q_x"]
+    assert [ref_image(h["TWIST_MUL_BY_Q_Y"][:9]), ref_image(h["TWIST_MUL_BY_Q_Y"][9:])] == ref_consts["twist_mul_by_q_y"]
+    assert [h["ATE_LOOP_LOW64"], 1, 0, 0] == ref_consts["ate_loop_count"]
+    assert [h["BN_U"], 0, 0, 0] == ref_consts["exp_by_neg_z_u"]
+    fr = h["FR_MOD32"]
+    assert sum(v << (32 * i) for i, v in enumerate(fr)) == M.R_ORD and h["FR_INV32"] == ref_consts["Fr"]["inv"] & 0xffffffff
+
+
+def test_shard_range_covers_everything():
+    from bn_amd.distributed import shard_range
+    for n in (0, 1, 7, 1 << 16, (1 << 20) + 3):
+        for world in (1, 2, 3, 8):
+            rs = [shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+
+
+def test_synthetic_scalars(oracle):
+    from bn_amd import distributed as D
+    a = D.synthetic_scalars(10, 20, 0); b = D.synthetic_scalars(10, 20, 1)
+    assert a.shape == (10, 4) and not np.array_equal(a, b)
+    assert np.array_equal(a[3:6], D.synthetic_scalars(13, 16, 0))            # index-addressed: shards agree with the whole
+    for row in a:
+        v = oracle.fp_to_int(FR, row)
+        assert 0 <= v < M.R_ORD and np.array_equal(oracle.fp_from_int(FR, v), row)
+    g1, g2 = D.generator_limbs()
+    assert np.array_equal(g1, oracle.g1_one()) and np.array_equal(g2, oracle.g2_one())
+
+
+WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [%(root)r, %(root)r + "/oracle", %(root)r + "/tests"]
+import bn_oracle
+from bn_amd import distributed as D
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+o = bn_oracle.Oracle()
+class OracleEngine:                       # test double: same five methods as TorchEngine, CPU tensors, oracle arithmetic
+    def _np(self, t): return t.numpy().view(np.uint64)
+    def _t(self, a): return torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
+    def pairing_batch(self, p, q, out=None): return self._t(o.pairing_batch(self._np(p), self._np(q), 1))
+    def miller_product(self, p, q):
+        acc = o.fq12_one()
+        for a, b in zip(self._np(p), self._np(q)): acc = o.fq12_mul(acc, o.miller_only(a, b))
+        return self._t(acc)
+    def gt_product(self, vals):
+        acc = o.fq12_one()
+        for v in self._np(vals): acc = o.fq12_mul(acc, v)
+        return self._t(acc)
+    def final_exp(self, f): return self._t(o.fq12_final_exponentiation(self._np(f)))
+n = %(n)d
+data = np.load(%(data)r)
+lo, hi = D.shard_range(n, rank, world)
+eng = OracleEngine()
+P = torch.from_numpy(data["P"][lo:hi].view(np.int64)); Q = torch.from_numpy(data["Q"][lo:hi].view(np.int64))
+gt = D.pairing_product_sharded(eng, P, Q)
+loc = D.pairing_batch_sharded(eng, P, Q)
+np.save(%(out)r + f".{rank}.npy", np.concatenate([gt.numpy().view(np.uint64).reshape(1, 48), loc.numpy().view(np.uint64).reshape(-1, 48)]))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sharded_product_and_batch_gloo_world2(oracle, tmp_path):
+    """the N>1 host path: contiguous shards, ONE all_gather of 384 B per rank, world-1 multiplications, one final exponentiation"""
+    rng = np.random.default_rng(21)
+    n = 7
+    k1 = np.stack([oracle.fp_from_int(FR, int.from_bytes(rng.bytes(40), "little") % M.R_ORD) for _ in range(n)])
+    k2 = np.stack([oracle.fp_from_int(FR, int.from_bytes(rng.bytes(40), "little") % M.R_ORD) for _ in range(n)])
+    P = oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (n, 1)), k1); Q = oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (n, 1)), k2)
+    P[2] = oracle.g1_zero()
+    data = tmp_path / "pq.npz"; np.savez(data, P=P, Q=Q)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": str(ROOT), "n": n, "data": str(data), "out": str(tmp_path / "res")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    assert [p.wait(timeout=300) for p in procs] == [0, 0]
+    want = oracle.pairing_product(P, Q)
+    allb = oracle.pairing_batch(P, Q)
+    got = [np.load(str(tmp_path / f"res.{r}.npy")) for r in range(2)]
+    assert np.array_equal(got[0][0], want) and np.array_equal(got[1][0], want)          # every rank holds the same Gt
+    assert np.array_equal(np.concatenate([got[0][1:], got[1][1:]]), allb)                # shards concatenate to the batch
