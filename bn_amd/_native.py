@@ -55,9 +55,33 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in one process do
+    not work (the second sees no GPU), so when torch is installed we bind to ITS runtime, whichever of the two gets
+    imported first.  Nothing of torch itself is imported here."""
+    override = os.environ.get("BN254_HIP_RUNTIME")
+    cands = [override] if override else []
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            cands.append(os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    for c in cands:
+        if c and os.path.exists(c):
+            try:
+                C.CDLL(c, mode=C.RTLD_GLOBAL)
+                return c
+            except OSError:
+                continue
+    return None
+
+
 def lib():
     global _lib
     if _lib is None:
+        _preload_shared_hip_runtime()
         if not LIB_PATH.exists():
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950).  bn_amd has no CPU fallback.")
