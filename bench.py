@@ -37,9 +37,15 @@ def cpu_baseline(batch_p, batch_q):
     import bn_oracle
     bn_oracle.build()
     o = bn_oracle.Oracle()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                   # respect a cgroup CPU quota (the GPU box grants 16 of its 256 hardware threads)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     t0 = time.perf_counter(); o.pairing_batch(batch_p[:8], batch_q[:8], nthreads=1); t1 = (time.perf_counter() - t0) / 8
-    n = int(min(len(batch_p), max(cores, min(4096, 20.0 / t1))))
+    n = int(min(len(batch_p), max(cores, min(4096, 20.0 / t1))))   # ~20 s of single-thread work
     t0 = time.perf_counter(); o.pairing_batch(batch_p[:n], batch_q[:n], nthreads=cores); dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
             "sample": f"{n} pairings of the same synthetic batch on {cores} threads ({dt:.2f} s wall); 1 thread: {t1 * 1e3:.2f} ms/pairing"}
