@@ -1,0 +1,87 @@
+// bn254.hpp - header-only C++ facade over the C ABI (bn254_hip.h), mirroring the public API of the reference crate
+// zcash-hackworks/bn (src/lib.rs): same names, argument meaning and error behaviour, so code written against the crate reads
+// the same here.  Values are the crate's #[repr(C)] memory images; all curve/pairing arithmetic runs on the GPU.
+//
+//   reference (Rust)                              here (C++)
+//   bn::pairing(p, q) -> Gt        lib.rs:181     bn::pairing(p, q)
+//   G1::one() / zero() / is_zero   lib.rs:83-87   bn::G1::one() / zero() / is_zero()
+//   g * fr                         lib.rs:116     g * fr                  (returned normalized, lib.rs:88-95)
+//   Gt::one(), a == b              lib.rs:169     bn::Gt::one(), a == b   (canonical limbs: memcmp)
+//   (fold of shootout/main.rs)                    bn::pairing_batch(...), bn::pairing_product(...)
+#pragma once
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bn254_hip.h"
+
+namespace bn {
+
+struct Error : std::runtime_error {
+    int code;
+    explicit Error(int c) : std::runtime_error(std::string("bn254_hip: ") + bn254_error_string(c)), code(c) {}
+};
+inline void check(int rc) { if (rc != 0) throw Error(rc); }
+
+// R mod q, the Montgomery image of 1 (fp.rs:170-177)
+static const uint64_t FQ_ONE[4] = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full};
+static const uint64_t FQ_TWO[4] = {0xa6ba871b8b1e1b3aull, 0x14f1d651eb8e167bull, 0xccdd46def0f28c58ull, 0x1c14ef83340fbe5eull};
+static const uint64_t FR_ONE[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full};
+
+struct Fr {
+    bn_fr v;
+    static Fr one() { Fr r; std::memcpy(r.v.l, FR_ONE, 32); return r; }     // lib.rs:21
+    static Fr zero() { Fr r; std::memset(&r.v, 0, 32); return r; }          // lib.rs:20
+};
+struct G1 {
+    bn_g1 v;
+    static G1 one() {                                                        // groups/mod.rs:355-361
+        G1 r; std::memcpy(r.v.x, FQ_ONE, 32); std::memcpy(r.v.y, FQ_TWO, 32); std::memcpy(r.v.z, FQ_ONE, 32); return r;
+    }
+    static G1 zero() { G1 r; std::memset(&r.v, 0, sizeof r.v); std::memcpy(r.v.y, FQ_ONE, 32); return r; }   // (0,1,0)
+    bool is_zero() const { return (v.z[0] | v.z[1] | v.z[2] | v.z[3]) == 0; }
+    G1 operator*(const Fr &k) const { G1 r; check(bn254_g1_mul_batch(nullptr, &v, &k.v, &r.v, 1)); return r; }
+    void normalize() { *this = *this * Fr::one(); }                          // lib.rs:88-95
+};
+struct G2 {
+    bn_g2 v;
+    static G2 one() {                                                        // groups/mod.rs:377-390
+        static const uint64_t X[8] = {0x8e83b5d102bc2026ull, 0xdceb1935497b0172ull, 0xfbb8264797811adfull, 0x19573841af96503bull,
+                                      0xafb4737da84c6140ull, 0x6043dd5a5802d8c4ull, 0x09e950fc52a02f86ull, 0x14fef0833aea7b6bull};
+        static const uint64_t Y[8] = {0x619dfa9d886be9f6ull, 0xfe7fd297f59e9b78ull, 0xff9e1a62231b7dfeull, 0x28fd7eebae9e4206ull,
+                                      0x64095b56c71856eeull, 0xdc57f922327d3cbbull, 0x55f935be33351076ull, 0x0da4a0e693fd6482ull};
+        G2 r; std::memcpy(r.v.x, X, 64); std::memcpy(r.v.y, Y, 64); std::memset(r.v.z, 0, 64); std::memcpy(r.v.z, FQ_ONE, 32); return r;
+    }
+    static G2 zero() { G2 r; std::memset(&r.v, 0, sizeof r.v); std::memcpy(r.v.y, FQ_ONE, 32); return r; }
+    bool is_zero() const { uint64_t o = 0; for (int i = 0; i < 8; ++i) o |= v.z[i]; return o == 0; }
+    G2 operator*(const Fr &k) const { G2 r; check(bn254_g2_mul_batch(nullptr, &v, &k.v, &r.v, 1)); return r; }
+    void normalize() { *this = *this * Fr::one(); }
+};
+struct Gt {
+    bn_gt v;
+    static Gt one() { Gt r; std::memset(&r.v, 0, sizeof r.v); std::memcpy(r.v.c, FQ_ONE, 32); return r; }     // lib.rs:169
+    bool operator==(const Gt &o) const { return std::memcmp(&v, &o.v, sizeof v) == 0; }
+    bool operator!=(const Gt &o) const { return !(*this == o); }
+};
+static_assert(sizeof(Fr) == 32 && sizeof(G1) == 96 && sizeof(G2) == 192 && sizeof(Gt) == 384, "layouts must equal the crate's #[repr(C)] types");
+
+// lib.rs:181-183
+inline Gt pairing(const G1 &p, const G2 &q) { Gt r; check(bn254_pairing_batch(nullptr, &p.v, &q.v, &r.v, 1)); return r; }
+// out[i] = pairing(p[i], q[i])
+inline std::vector<Gt> pairing_batch(const std::vector<G1> &p, const std::vector<G2> &q) {
+    if (p.size() != q.size()) throw std::invalid_argument("pairing_batch: length mismatch");
+    std::vector<Gt> out(p.size());
+    check(bn254_pairing_batch(nullptr, reinterpret_cast<const bn_g1 *>(p.data()), reinterpret_cast<const bn_g2 *>(q.data()),
+                              reinterpret_cast<bn_gt *>(out.data()), p.size()));
+    return out;
+}
+// fold(Gt::one(), acc * pairing(p, q))   (shootout/main.rs:11-16)
+inline Gt pairing_product(const std::vector<G1> &p, const std::vector<G2> &q) {
+    if (p.size() != q.size()) throw std::invalid_argument("pairing_product: length mismatch");
+    Gt r;
+    check(bn254_pairing_product(nullptr, reinterpret_cast<const bn_g1 *>(p.data()), reinterpret_cast<const bn_g2 *>(q.data()), p.size(), &r.v));
+    return r;
+}
+
+}  // namespace bn

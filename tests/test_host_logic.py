@@ -161,3 +161,25 @@ def test_sharded_product_and_batch_gloo_world2(oracle, tmp_path):
     got = [np.load(str(tmp_path / f"res.{r}.npy")) for r in range(2)]
     assert np.array_equal(got[0][0], want) and np.array_equal(got[1][0], want)          # every rank holds the same Gt
     assert np.array_equal(np.concatenate([got[0][1:], got[1][1:]]), allb)                # shards concatenate to the batch
+
+
+def test_cpp_facade_constants_match_oracle(oracle, tmp_path):
+    """include/bn254.hpp mirrors src/lib.rs: its G1::one/G2::one/Gt::one/Fr::one images are the reference's"""
+    from bn_amd import _native
+    _native.build()
+    src = tmp_path / "dump.cpp"
+    src.write_text(r'''
+#include "bn254.hpp"
+#include <cstdio>
+template <class T> void dump(const T &t) { const uint64_t *w = reinterpret_cast<const uint64_t *>(&t); for (size_t i = 0; i < sizeof(T) / 8; ++i) std::printf("%llu ", (unsigned long long)w[i]); std::printf("\n"); }
+int main() { dump(bn::G1::one()); dump(bn::G1::zero()); dump(bn::G2::one()); dump(bn::G2::zero()); dump(bn::Gt::one()); dump(bn::Fr::one());
+             return bn::G1::zero().is_zero() && !bn::G2::one().is_zero() ? 0 : 1; }
+''')
+    exe = tmp_path / "dump"
+    subprocess.check_call(["g++", "-std=c++17", "-I", str(ROOT / "include"), str(src), "-o", str(exe),
+                           "-L", str(ROOT / "bn_amd"), "-lbn254_hip", "-Wl,-rpath," + str(ROOT / "bn_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    lines = subprocess.check_output([str(exe)]).decode().strip().split("\n")
+    got = [np.array([int(x) for x in l.split()], np.uint64) for l in lines]
+    want = [oracle.g1_one(), oracle.g1_zero(), oracle.g2_one(), oracle.g2_zero(), oracle.fq12_one(), oracle.fp_from_int(FR, 1)]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
