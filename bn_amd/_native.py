@@ -44,8 +44,9 @@ def build(force=False, verbose=False):
     deps = [SRC, SRC_B] + sorted((HERE / "csrc").glob("*.hpp")) + [HERE.parent / "include" / "bn254_hip.h"]
     if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(d.stat().st_mtime for d in deps):
         return LIB_PATH
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           str(SRC), str(SRC_B), "-o", str(LIB_PATH)]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+    cmd += os.environ.get("BN254_EXTRA_HIPCC_FLAGS", "").split()           # experiments only
+    cmd += [str(SRC), str(SRC_B), "-o", str(LIB_PATH)]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

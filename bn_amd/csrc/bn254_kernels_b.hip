@@ -7,6 +7,9 @@
 // This translation unit is compiled with the Fq6/Fq12-sized steps INLINED (BN_COARSE), so that values stay in VGPRs across
 // them; only the multiplier-sized leaves and the rarely executed outer steps are calls.
 #define BN_COARSE __device__ __forceinline__
+#ifdef BN_B_INLINE_REDUCTIONS
+#define BN_INLINE_REDUCTIONS 1
+#endif
 #include <hip/hip_runtime.h>
 #include "io.hpp"
 

@@ -58,10 +58,13 @@
     } while (0)
 #define BN_SETB(x, LBV, VBV) ((x).lb = (LBV), (x).vb = (VBV), (x).sg = false)
 #define BN_IFB(...) __VA_ARGS__
+namespace bn254 { struct OpCounts { unsigned long mul, mul2, lc3, lc3w, norm, addsub, reduce, select; }; inline OpCounts &op_counts() { static OpCounts c{}; return c; } }
+#define BN_COUNT(f) (++bn254::op_counts().f)
 #else
 #define BN_REQUIRE(cond, what) ((void)0)
 #define BN_SETB(x, LBV, VBV) ((void)0)
 #define BN_IFB(...)
+#define BN_COUNT(f) ((void)0)
 #endif
 
 namespace bn254 {
@@ -106,6 +109,10 @@ BN_FN u32x9 bn_tov(const Fe &f) {
 #define BN_LEAF2(NAME, BODY)                                                                      \
     BN_LEAF u32x9 NAME##_leaf(u32x9 a, u32x9 b) { return bn_tov(BODY(bn_unv(a), bn_unv(b))); }   \
     BN_FN Fe NAME(const Fe &a, const Fe &b) { return bn_unv(NAME##_leaf(bn_tov(a), bn_tov(b))); }
+#if defined(BN_INLINE_REDUCTIONS)
+#define BN_LEAF3T(NAME, BODY)                                                                     \
+    template <int C1, int C2, int C3> BN_FN Fe NAME(const Fe &a, const Fe &b, const Fe &c) { return BODY<C1, C2, C3>(a, b, c); }
+#else
 #define BN_LEAF3T(NAME, BODY)                                                                     \
     template <int C1, int C2, int C3> BN_LEAF u32x9 NAME##_leaf(u32x9 a, u32x9 b, u32x9 c) {     \
         return bn_tov(BODY<C1, C2, C3>(bn_unv(a), bn_unv(b), bn_unv(c)));                         \
@@ -113,6 +120,7 @@ BN_FN u32x9 bn_tov(const Fe &f) {
     template <int C1, int C2, int C3> BN_FN Fe NAME(const Fe &a, const Fe &b, const Fe &c) {      \
         return bn_unv(NAME##_leaf<C1, C2, C3>(bn_tov(a), bn_tov(b), bn_tov(c)));                  \
     }
+#endif
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -155,6 +163,7 @@ struct Bias {
 // ---------------------------------------------------------------------------------------------------------------------
 // lazy additive ops (arith.rs:238-253,266-273 do these with a conditional correction per call; here: none)
 BN_FN Fe fe_add(const Fe &a, const Fe &b) {
+    BN_COUNT(addsub);
     BN_REQUIRE(a.lb + b.lb <= ((a.sg || b.sg) ? 4u : 8u), "fe_add limb overflow");
     BN_REQUIRE(a.vb + b.vb <= 1024, "fe_add value overflow");
     Fe r;
@@ -169,6 +178,7 @@ BN_FN Fe fe_dbl(const Fe &a) { return fe_add(a, a); }
 // signed lazy difference: plain limb-wise a - b, limbs become int32 (two's complement), no bias and no carries.  Only
 // fe_lc3 may consume the result (it interprets every input limb as a signed 32-bit integer).
 BN_FN Fe fe_ssub(const Fe &a, const Fe &b) {
+    BN_COUNT(addsub);
     BN_REQUIRE(a.lb + b.lb <= 4, "fe_ssub limb overflow (|limb| must stay < 2^31)");
     BN_REQUIRE(a.vb + b.vb <= 1024, "fe_ssub value overflow");
     Fe r;
@@ -182,6 +192,7 @@ BN_FN Fe fe_ssub(const Fe &a, const Fe &b) {
 // a - b (mod q) as a + K*q - b, b must satisfy lb <= LB and vb <= K-1
 template <int LB, int K>
 BN_FN Fe fe_sub(const Fe &a, const Fe &b) {
+    BN_COUNT(addsub);
     BN_REQUIRE(!a.sg && !b.sg, "fe_sub on a signed lazy value");
     BN_REQUIRE(b.lb <= (uint32_t)LB, "fe_sub: subtrahend limbs exceed the bias");
     BN_REQUIRE(b.vb + 1 <= (uint32_t)K, "fe_sub: subtrahend value exceeds the bias");
@@ -196,6 +207,7 @@ BN_FN Fe fe_sub(const Fe &a, const Fe &b) {
 }
 template <int LB, int K>
 BN_FN Fe fe_neg(const Fe &b) {
+    BN_COUNT(addsub);
     BN_REQUIRE(!b.sg, "fe_neg on a signed lazy value");
     BN_REQUIRE(b.lb <= (uint32_t)LB, "fe_neg: limbs exceed the bias");
     BN_REQUIRE(b.vb + 1 <= (uint32_t)K, "fe_neg: value exceeds the bias");
@@ -209,6 +221,7 @@ BN_FN Fe fe_neg(const Fe &b) {
 
 // carry propagation only: limbs back to 29 bits, value unchanged
 BN_FN Fe fe_norm(const Fe &a) {
+    BN_COUNT(norm);
     BN_REQUIRE(!a.sg, "fe_norm on a signed lazy value");
     Fe r;
     uint32_t c = 0;
@@ -252,6 +265,7 @@ BN_FN Fe fe_reduce(const Fe &a) {
 // subtracts and the odd lane adds the partner's limb in xi-multiplications)
 template <int C1, int C2, int C3>
 BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) {
+    BN_COUNT(lc3);
     constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3;
     // Every input limb is read as a SIGNED 32-bit integer (so inputs may be signed lazy differences, fe_ssub): |limb| < 2^31,
     // i.e. lb <= 4.  Terms with a small coefficient are first combined in 32-bit arithmetic ("narrow"); the others enter the
@@ -293,6 +307,7 @@ BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) {
 // all-64-bit variant for UNSIGNED lazy inputs with limbs beyond 31 bits (lb up to 8); rare call sites only
 template <int C1, int C2, int C3>
 BN_FN Fe fe_lc3w_body(const Fe &x, const Fe &y, const Fe &z) {
+    BN_COUNT(lc3w);
     constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3;
     BN_REQUIRE((C1 == 0 || (x.lb <= 8 && !x.sg)) && (C2 == 0 || (y.lb <= 8 && !y.sg)) && (C3 == 0 || (z.lb <= 8 && !z.sg)), "fe_lc3w lb");
     BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb <= 1000, "fe_lc3w vb");
@@ -327,6 +342,7 @@ BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any l
 // Column bound: 9*(la*lb) * 2^58 + 9 * 2^58 + carry < 2^64  <=>  la*lb <= 6.
 // Value: result < (A*B/169.3 + 1) q, so A*B <= 169 gives < 2q.
 BN_FN Fe fe_mul_body(const Fe &a, const Fe &b) {
+    BN_COUNT(mul);
     BN_REQUIRE(!a.sg && !b.sg, "fe_mul on a signed lazy value");
     BN_REQUIRE(a.lb * b.lb <= 6, "fe_mul column overflow");
     BN_REQUIRE(a.vb * b.vb <= 169, "fe_mul value bound");
@@ -361,6 +377,7 @@ BN_FN Fe fe_sqr(const Fe &a) { return fe_mul(a, a); }
 
 // (a*u + c*v) / R with ONE reduction: 162 + 81 mads.   Column bound: la*lu + lc*lv <= 6; value: A*U + C*V <= 169.
 BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
+    BN_COUNT(mul2);
     BN_REQUIRE(!a.sg && !u.sg && !c.sg && !v.sg, "fe_mul2 on a signed lazy value");
     BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 6, "fe_mul2 column overflow");
     BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 169, "fe_mul2 value bound");
@@ -455,6 +472,7 @@ BN_FN bool fe_is_zero(const Fe &a) {
 }
 // per-lane select without divergence
 BN_FN Fe fe_select(bool take_b, const Fe &a, const Fe &b) {
+    BN_COUNT(select);
     Fe r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = take_b ? b.l[i] : a.l[i];

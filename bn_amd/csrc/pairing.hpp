@@ -95,9 +95,26 @@ BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q) {
     return f;
 }
 
-// fq12.rs:229-246 + 97-101: f^u by square-and-multiply (u has 63 bits, top bit consumed by res = f), then conjugate
+// fq12.rs:229-246 + 97-101: f^u, then conjugate.  The reference walks the 63 bits of u (62 cyclotomic squarings, 27
+// multiplications).  On the cyclotomic subgroup f^-1 = conj(f) is free, so the same group element is reached through the
+// non-adjacent form of u (weight 24: 23 multiplications); the value - and therefore every output byte - is identical.
+// Only valid for f in the cyclotomic subgroup, which is where final_exponentiation calls it (after the easy part).
 template <class F2>
 BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
+    Fq12<F2> res = f;
+#pragma unroll 1
+    for (int i = k::BN_U_NAF_LEN - 2; i >= 0; --i) {
+        res = f12_cyclotomic_sqr(res);
+        const int d = k::BN_U_NAF[i];
+        if (d > 0) res = f12_mul(res, f);
+        if (d < 0) res = f12_mul(res, f12_conj(f));
+    }
+    return f12_conj(res);
+}
+// the reference's own schedule (plain binary expansion of u); kept for inputs OFF the cyclotomic subgroup - the known-answer
+// test of fields/mod.rs:171-201 feeds exp_by_neg_z such an element, where conj(f) != f^-1
+template <class F2>
+BN_OUTER Fq12<F2> exp_by_neg_z_reference_schedule(const Fq12<F2> &f) {
     Fq12<F2> res = f;
 #pragma unroll 1
     for (int i = 61; i >= 0; --i) {

@@ -24,6 +24,10 @@ BN_FN Fq6<F2> f6_lc3(const Fq6<F2> &x, const Fq6<F2> &y, const Fq6<F2> &z) {
     return {f2_lc3<C1, C2, C3>(x.c0, y.c0, z.c0), f2_lc3<C1, C2, C3>(x.c1, y.c1, z.c1), f2_lc3<C1, C2, C3>(x.c2, y.c2, z.c2)};
 }
 template <class F2> BN_FN Fq6<F2> f6_add(const Fq6<F2> &a, const Fq6<F2> &b) { return f6_lc3<1, 1, 0>(a, b, b); }
+// a + b in the cheapest form the FIRST operand of f6_mul accepts (lane-pair mapping: carries propagated, not reduced)
+template <class F2> BN_FN Fq6<F2> f6_add_norm(const Fq6<F2> &a, const Fq6<F2> &b) {
+    return {f2_sum_for_mul(a.c0, b.c0), f2_sum_for_mul(a.c1, b.c1), f2_sum_for_mul(a.c2, b.c2)};
+}
 template <class F2> BN_FN Fq6<F2> f6_sub(const Fq6<F2> &a, const Fq6<F2> &b) { return f6_lc3<1, -1, 0>(a, b, b); }
 template <class F2> BN_FN Fq6<F2> f6_neg(const Fq6<F2> &a) { return f6_lc3<-1, 0, 0>(a, a, a); }
 // v * x   (fq6.rs:59-65)
@@ -84,7 +88,7 @@ template <class F2> BN_FN Fq12<F2> f12_one() { return {f6_one<F2>(), f6_zero<F2>
 template <class F2>
 BN_COARSE Fq12<F2> f12_mul(const Fq12<F2> &a, const Fq12<F2> &b) {
     Fq6<F2> aa = f6_mul(a.c0, b.c0), bb = f6_mul(a.c1, b.c1);
-    Fq6<F2> t = f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1));
+    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add(b.c0, b.c1));
     Fq12<F2> r;
     r.c0.c0 = f2_lc_xi<1, 1>(bb.c2, aa.c0);                  // aa + v*bb
     r.c0.c1 = f2_lc3<1, 1, 0>(aa.c1, bb.c0, bb.c0);

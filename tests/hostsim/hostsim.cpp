@@ -58,7 +58,8 @@ EXPORT void hs_fq12_sqr(const uint32_t *a, uint32_t *o) { f12_store(f12_sqr(f12_
 EXPORT void hs_fq12_inverse(const uint32_t *a, uint32_t *o) { f12_store(f12_inverse(f12_load<F2>(a)), o); }
 EXPORT void hs_fq12_conj(const uint32_t *a, uint32_t *o) { f12_store(f12_conj(f12_load<F2>(a)), o); }
 EXPORT void hs_fq12_cyclotomic_sqr(const uint32_t *a, uint32_t *o) { f12_store(f12_cyclotomic_sqr(f12_load<F2>(a)), o); }
-EXPORT void hs_fq12_exp_by_neg_z(const uint32_t *a, uint32_t *o) { f12_store(exp_by_neg_z(f12_load<F2>(a)), o); }
+EXPORT void hs_fq12_exp_by_neg_z(const uint32_t *a, uint32_t *o) { f12_store(exp_by_neg_z_reference_schedule(f12_load<F2>(a)), o); }
+EXPORT void hs_fq12_exp_by_neg_z_naf(const uint32_t *a, uint32_t *o) { f12_store(exp_by_neg_z(f12_load<F2>(a)), o); }
 EXPORT void hs_fq12_frobenius(const uint32_t *a, int p, uint32_t *o) {
     Fq12<F2> f = f12_load<F2>(a);
     f12_store(p == 1 ? f12_frobenius<1>(f) : p == 2 ? f12_frobenius<2>(f) : f12_frobenius<3>(f), o);
@@ -128,3 +129,14 @@ EXPORT void hsb_pairing(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
     if (inf) f = f12_one<F2B>();
     f12_store(f, o);
 }
+
+#ifdef BN_BOUNDS
+EXPORT void hs_counts_reset() { op_counts() = OpCounts{}; }
+EXPORT void hs_counts_get(unsigned long *o) { OpCounts c = op_counts(); o[0] = c.mul; o[1] = c.mul2; o[2] = c.lc3; o[3] = c.lc3w; o[4] = c.norm; o[5] = c.addsub; o[6] = c.reduce; o[7] = c.select; }
+EXPORT void hsb_miller_only(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
+    G1Aff<FeP> p; G2Aff<F2B> q;
+    pair_prologue<FeP>(f2_scalar_load((F2B *)0, g1), f2_scalar_load((F2B *)0, g1 + 8), f2_scalar_load((F2B *)0, g1 + 16),
+                       f2_load((F2B *)0, g2), f2_load((F2B *)0, g2 + 16), f2_load((F2B *)0, g2 + 32), p, q);
+    f12_store(miller_loop(p, q), o);
+}
+#endif

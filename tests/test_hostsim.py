@@ -94,6 +94,9 @@ def test_kats_through_engine(oracle, hs, kats):
     assert oracle.fq12_to_ints(e) == I(kats["test_cyclotomic_exp"]["expected"])
     k1 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k1"]); k2 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k2"])
     P = oracle.g1_mul(oracle.g1_one(), k1); Q = oracle.g2_mul(oracle.g2_one(), k2)
+    # the NAF schedule used inside final_exponentiation equals the reference's on the cyclotomic subgroup
+    cyc = oracle.fq12_final_exp_first_chunk(oracle.miller_only(P, Q))
+    assert np.array_equal(hs.call("hs_fq12_exp_by_neg_z_naf", cyc, out_words=96), oracle.fq12_exp_by_neg_z(cyc))
     assert oracle.fq12_to_ints(hs.call("hs_miller", P, Q, out_words=96)) == I(kats["test_miller_loop"]["expected"])
     assert oracle.fq12_to_ints(hs.call("hs_pairing", P, Q, out_words=96)) == I(kats["test_reduced_pairing"]["expected"])
 
