@@ -51,6 +51,39 @@ def cpu_baseline(batch_p, batch_q):
             "sample": f"{n} pairings of the same synthetic batch on {cores} threads ({dt:.2f} s wall); 1 thread: {t1 * 1e3:.2f} ms/pairing"}
 
 
+def bench_g1mul(args, eng, dev, world, rank, local_rank):
+    """side metric (not the headline): 2^20 normalized G1 scalar multiplications per GPU per step"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bn_amd import distributed as D
+    n = 1 << 20
+    base, _ = D.synthetic_points(eng, rank * (1 << 14), (rank + 1) * (1 << 14))
+    P = base.repeat(n >> 14, 1).contiguous()
+    k = torch.from_numpy(D.synthetic_scalars(0, n >> 4, 1).view(np.int64)).to(dev).repeat(16, 1).contiguous()
+    for _ in range(args.warmup):
+        eng.g1_mul(P, k)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank]); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.g1_mul(P, k)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank]); torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "BN254 G1 scalar multiplications/sec (normalized output, bit-exact vs ref)", "value": world * n * args.steps / elapsed,
+                          "unit": "scalar muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit Montgomery, exact integer)",
+                          "data": "synthetic", "config": {"workload": "2^20 G1 scalar muls by random Fr per GPU per step (BASELINE.json configs[4])"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +92,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="pairings per GPU per step")
     ap.add_argument("--mapping", type=int, default=None, help="0: one lane per pairing, 1: lane pair per pairing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["pairing", "g1mul"], default="pairing",
+                    help="pairing: the headline metric (default); g1mul: BASELINE.json configs[4], 2^20 G1 scalar muls (side metric)")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,6 +116,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     eng = D.TorchEngine(bn_amd.Engine(local_rank, mapping=args.mapping), dev)
+    if args.workload == "g1mul":
+        return bench_g1mul(args, eng, dev, world, rank, local_rank)
     n = args.batch
     lo = rank * n
     P, Q = D.synthetic_points(eng, lo, lo + n)              # untimed: inputs resident in HBM before the clock starts

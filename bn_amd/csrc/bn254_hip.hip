@@ -94,8 +94,8 @@ __device__ __forceinline__ void mul_body(const uint32_t *pt, const uint32_t *km,
 #pragma unroll
     for (int i = 0; i < 3 * W; ++i) w[i] = pt[i];
     Jac<F> p = {ld(w), ld(w + W), ld(w + 2 * W)};
-    Jac<F> r = scalar_mul_reference_chain<F>(p, raw);
-    if (normalize) r = jac_normalize<F>(r);
+    // normalize = 0: the reference's own chain (raw Jacobian limbs, bit-identical to `G * Fr`); 1: windowed + normalized
+    Jac<F> r = normalize ? jac_normalize<F>(scalar_mul_windowed<F>(p, raw)) : scalar_mul_reference_chain<F>(p, raw);
     st(r.x, w); st(r.y, w + W); st(r.z, w + 2 * W);
 #pragma unroll
     for (int i = 0; i < 3 * W; ++i) out[i] = w[i];

@@ -19,6 +19,29 @@ namespace {
 constexpr int BLOCK = 64;
 typedef Fq2B<Fe> F2;
 
+// Miller-loop state parked in LDS: 7 field elements x 9 limbs = 63 dwords per lane, laid out [dword][lane] so that a wave's
+// ds_read/ds_write_b32 touch 64 consecutive banks (conflict-free).  16 KB per wave, 8 waves per CU = 129 KB of the 160 KB.
+constexpr int PARK_DWORDS = 63;
+struct MillerStateLds {
+    uint32_t *base;          // this lane's column of the block's LDS array
+    __device__ __forceinline__ void st_fe(int slot, const Fe &v) const {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) base[(slot * 9 + i) * BLOCK] = v.l[i];
+    }
+    __device__ __forceinline__ Fe ld_fe(int slot) const {
+        Fe v;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v.l[i] = base[(slot * 9 + i) * BLOCK];
+        return v;
+    }
+    __device__ __forceinline__ void put_r(const G2Proj<F2> &v) const { st_fe(0, v.x.v); st_fe(1, v.y.v); st_fe(2, v.z.v); }
+    __device__ __forceinline__ G2Proj<F2> get_r() const { return {{ld_fe(0)}, {ld_fe(1)}, {ld_fe(2)}}; }
+    __device__ __forceinline__ void put_base(const G2Aff<F2> &v) const { st_fe(3, v.x.v); st_fe(4, v.y.v); }
+    __device__ __forceinline__ G2Aff<F2> get_base() const { return {{ld_fe(3)}, {ld_fe(4)}}; }
+    __device__ __forceinline__ void put_p(const G1Aff<Fe> &v) const { st_fe(5, v.x); st_fe(6, v.y); }
+    __device__ __forceinline__ G1Aff<Fe> get_p() const { return {ld_fe(5), ld_fe(6)}; }
+};
+
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_miller_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
@@ -30,7 +53,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
     G2Aff<F2> q;
     pair_prologue<Fe>(f2_scalar_load((const F2 *)nullptr, w1), f2_scalar_load((const F2 *)nullptr, w1 + 8), f2_scalar_load((const F2 *)nullptr, w1 + 16),
                       f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32), p, q);
-    Fq12<F2> f = miller_loop(p, q);
+    __shared__ uint32_t park[PARK_DWORDS * BLOCK];
+    MillerStateLds st = {park + threadIdx.x};
+    Fq12<F2> f = miller_loop(p, q, st);
     Fq12<F2> one = f12_one<F2>();
     f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
     f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);

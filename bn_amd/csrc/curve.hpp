@@ -58,11 +58,10 @@ BN_COARSE Jac<F> jac_double(const Jac<F> &p) {
     return r;
 }
 // groups/mod.rs:275-311, all branches (zero operands, equal points) as per-lane selects; the doubling for equal points is a
-// divergent branch that no lane takes for valid prime-order inputs and scalars < r
+// divergent branch that no lane takes for valid prime-order inputs and scalars < r.  pz / qz: "p (q) is the point at infinity".
 template <class F>
-BN_COARSE Jac<F> jac_add(const Jac<F> &p, const Jac<F> &q) {
+BN_COARSE Jac<F> jac_add_flags(const Jac<F> &p, const Jac<F> &q, bool pz, bool qz) {
     using T = typename F::T;
-    bool pz = F::is_zero(p.z), qz = F::is_zero(q.z);
     T z1s = F::sqr(p.z), z2s = F::sqr(q.z);
     T u1 = F::mul(p.x, z2s), u2 = F::mul(q.x, z1s);
     T s1 = F::mul(p.y, F::mul(q.z, z2s)), s2 = F::mul(q.y, F::mul(p.z, z1s));
@@ -84,6 +83,8 @@ BN_COARSE Jac<F> jac_add(const Jac<F> &p, const Jac<F> &q) {
     r.x = F::select(pz, r.x, q.x); r.y = F::select(pz, r.y, q.y); r.z = F::select(pz, r.z, q.z);     // :276-278
     return r;
 }
+template <class F>
+BN_FN Jac<F> jac_add(const Jac<F> &p, const Jac<F> &q) { return jac_add_flags(p, q, F::is_zero(p.z), F::is_zero(q.z)); }
 
 // Fr out of Montgomery form (fields/fp.rs:15-22: multiply by 1): 8 x u32 words, word-serial Montgomery reduction mod r
 BN_FN void fr_from_mont(const uint32_t *km, uint32_t *raw) {
@@ -137,14 +138,44 @@ BN_FN Jac<F> scalar_mul_reference_chain(const Jac<F> &p, const uint32_t *k_raw) 
     }
     return res;
 }
-// lib.rs:88-95 (normalize): (x/z^2, y/z^3, 1), infinity unchanged
+// Fixed 4-bit windows, MSB first: 252 doublings + 64 additions + a 14-operation table instead of the reference chain's
+// 256 x (double, add) under per-lane predicates.  Same group element as groups/mod.rs:250-270, different Jacobian
+// coordinates - callers normalize (the parity definition of g*_mul_batch).  The 16-entry table is a per-lane array indexed
+// by the lane's own digit, i.e. it lives in private memory; infinity is tracked by flags, not by testing z.
+template <class F>
+BN_FN Jac<F> scalar_mul_windowed(const Jac<F> &p, const uint32_t *k_raw) {
+    Jac<F> tab[16];
+    const bool p_inf = F::is_zero(p.z);
+    tab[0] = {F::zero(), F::one(), F::zero()};
+    tab[1] = p;
+#pragma unroll 1
+    for (int i = 2; i < 16; i += 2) {
+        tab[i] = jac_double(tab[i >> 1]);
+        tab[i + 1] = jac_add_flags(tab[i], p, p_inf, p_inf);
+    }
+    Jac<F> res = tab[0];
+    bool res_inf = true;
+#pragma unroll 1
+    for (int w = 63; w >= 0; --w) {
+#pragma unroll 1
+        for (int d = 0; d < 4; ++d) res = jac_double(res);          // 2^4 * infinity stays infinity (z = 0)
+        const uint32_t digit = (k_raw[w >> 3] >> ((w & 7) * 4)) & 15u;
+        const bool q_inf = p_inf || digit == 0;
+        res = jac_add_flags(res, tab[digit], res_inf, q_inf);
+        res_inf = res_inf && q_inf;
+    }
+    return res;
+}
+// lib.rs:88-95 (normalize): (x/z^2, y/z^3, 1).  Infinity is returned as G::zero() = (0, 1, 0) (groups/mod.rs:208-214): that is
+// what the reference holds for every valid input that multiplies to zero (k = 0 or p = 0; k < r excludes the rest), while
+// the windowed chain above may reach z = 0 with other x, y.
 template <class F>
 BN_FN Jac<F> jac_normalize(const Jac<F> &p) {
     using T = typename F::T;
     bool inf = F::is_zero(p.z);
     T zi = F::inverse(p.z), zi2 = F::sqr(zi);
     Jac<F> r = {F::mul(p.x, zi2), F::mul(p.y, F::mul(zi2, zi)), F::one()};
-    r.x = F::select(inf, r.x, p.x); r.y = F::select(inf, r.y, p.y); r.z = F::select(inf, r.z, p.z);
+    r.x = F::select(inf, r.x, F::zero()); r.y = F::select(inf, r.y, F::one()); r.z = F::select(inf, r.z, F::zero());
     return r;
 }
 

@@ -65,34 +65,63 @@ BN_FN Fq12<F2> apply_line(const Fq12<F2> &f, const Line<F2> &l, const G1Aff<S> &
     return f12_mul_by_024(f, l.ell_0, f2_scale(l.ell_vw, p.y), f2_scale(l.ell_vv, p.x));
 }
 
+// Where the slowly changing state of the Miller loop (the running point R, the point being added, the affine P) lives
+// BETWEEN steps.  Default: ordinary variables.  The lane-pair kernel parks them in LDS (pairing kernels keep f in VGPRs and
+// would otherwise spill exactly these values to private memory = HBM traffic).
+template <class F2, class S>
+struct MillerStateVars {
+    G2Proj<F2> r_;
+    G2Aff<F2> base_;
+    G1Aff<S> p_;
+    BN_FN void put_r(const G2Proj<F2> &v) { r_ = v; }
+    BN_FN G2Proj<F2> get_r() const { return r_; }
+    BN_FN void put_base(const G2Aff<F2> &v) { base_ = v; }
+    BN_FN G2Aff<F2> get_base() const { return base_; }
+    BN_FN void put_p(const G1Aff<S> &v) { p_ = v; }
+    BN_FN G1Aff<S> get_p() const { return p_; }
+};
+
 // groups/mod.rs:486-519 fused with :557-588.  The schedule (6u+2 with the top bit skipped: 64 doublings, an addition of Q
 // after every set bit, then the additions of pi(Q) and -pi^2(Q)) is a compile-time constant, so every branch below is
 // wave-uniform.  Written as ONE loop of 66 steps x up to 2 passes so that each of f^2, the two line functions and the
 // sparse multiplication exists exactly once in the instruction stream.
-template <class F2, class S>
-BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q) {
-    G2Proj<F2> r = {q.x, q.y, f2_one(F2P)};
+template <class F2, class S, class Store>
+BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q, Store &st) {
+    {
+        G2Proj<F2> r0 = {q.x, q.y, f2_one(F2P)};
+        st.put_r(r0);
+        st.put_base(q);
+        st.put_p(p);
+    }
     Fq12<F2> f = f12_one<F2>();
-    G2Aff<F2> base = q;
 #pragma unroll 1
     for (int j = 0; j < 66; ++j) {
         const bool tail = j >= 64;
         const bool bit = tail ? true : (((k::ATE_LOOP_LOW64 >> (63 - (j & 63))) & 1) != 0);
-        if (j == 64) base = mul_by_q(q);                                   // pi(Q)            groups/mod.rs:578
-        if (j == 65) { base = mul_by_q(base); base.y = f2_neg(base.y); }    // -pi^2(Q)         groups/mod.rs:579
+        if (j == 64) st.put_base(mul_by_q(st.get_base()));                          // pi(Q)      groups/mod.rs:578
+        if (j == 65) { G2Aff<F2> b2 = mul_by_q(st.get_base()); b2.y = f2_neg(b2.y); st.put_base(b2); }   // -pi^2(Q)   :579
 #pragma unroll 1
         for (int pass = tail ? 1 : 0; pass < (bit ? 2 : 1); ++pass) {
             Line<F2> l;
             if (pass == 0) {
                 f = f12_sqr(f);
+                G2Proj<F2> r = st.get_r();
                 l = doubling_step(r);
+                st.put_r(r);
             } else {
-                l = addition_step(r, base);
+                G2Proj<F2> r = st.get_r();
+                l = addition_step(r, st.get_base());
+                st.put_r(r);
             }
-            f = apply_line(f, l, p);
+            f = apply_line(f, l, st.get_p());
         }
     }
     return f;
+}
+template <class F2, class S>
+BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q) {
+    MillerStateVars<F2, S> st;
+    return miller_loop(p, q, st);
 }
 
 // fq12.rs:229-246 + 97-101: f^u, then conjugate.  The reference walks the 63 bits of u (62 cyclotomic squarings, 27

@@ -90,7 +90,7 @@ static void hs_mul_generic(const uint32_t *pt, const uint32_t *k, uint32_t *o, i
     Jac<F> p = {ld(pt), ld(pt + W), ld(pt + 2 * W)};
     uint32_t raw[8];
     fr_from_mont(k, raw);
-    Jac<F> r = scalar_mul_reference_chain<F>(p, raw);
+    Jac<F> r = normalize == 2 ? scalar_mul_windowed<F>(p, raw) : scalar_mul_reference_chain<F>(p, raw);
     if (normalize) r = jac_normalize<F>(r);
     st(r.x, o); st(r.y, o + W); st(r.z, o + 2 * W);
 }
