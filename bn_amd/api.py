@@ -135,6 +135,10 @@ class Gt:
     def one():
         l = np.zeros(GT_WORDS, np.uint64); l[:4] = _one_fq()
         return Gt(l)
+    def __mul__(self, o):                 # lib.rs:175-179
+        return Gt(default_engine().gt_mul_batch(self.limbs, o.limbs)[0])
+    def pow(self, k):                     # lib.rs:171
+        return Gt(default_engine().gt_pow_batch(self.limbs, k.limbs)[0])
     def __eq__(self, o): return isinstance(o, Gt) and np.array_equal(self.limbs, o.limbs)   # canonical limbs: memcmp
     def __repr__(self): return "Gt(%s...)" % hex(int(self.limbs[0]))
 

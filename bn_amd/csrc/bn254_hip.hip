@@ -118,6 +118,8 @@ __global__ void __launch_bounds__(BLOCK) bn254_g2_mul_k(const uint32_t *p, const
 // ======================================================================================================== host side
 extern "C" int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, hipStream_t s);      // bn254_kernels_b.hip
 extern "C" int bn254_launch_final_exp_B(const void *f, void *out, size_t n, hipStream_t s);
+extern "C" int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
+extern "C" int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hipStream_t s);
 
 struct bn254_ctx {
     int device = 0;
@@ -315,6 +317,23 @@ int bn254_g2_mul_batch_dev(bn254_ctx *c, const void *p, const void *k, void *o, 
 int bn254_g1_mul_jacobian_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 1, p, k, o, n, s, 0); }
 int bn254_g2_mul_jacobian_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 2, p, k, o, n, s, 0); }
 
+int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_a || !d_b || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Scope sc(ctx, (hipStream_t)stream, "gt_mul");
+    return bn254_launch_gt_mul_B(d_a, d_b, d_out, n, (hipStream_t)stream);
+}
+int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_a || !d_k || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Scope sc(ctx, (hipStream_t)stream, "gt_pow");
+    return bn254_launch_gt_pow_B(d_a, d_k, d_out, n, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------- host-buffer API
 namespace {
 struct DevBuf {
@@ -369,6 +388,23 @@ static int mul_host(bn254_ctx *ctx, int g, const void *p, const bn_fr *k, void *
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;
 }
+static int gt_binop_host(bn254_ctx *ctx, int op, const bn_gt *a, const void *b, size_t bsize, bn_gt *out, size_t n) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!a || !b || !out) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf da, db, dout;
+    if ((rc = da.alloc(n * sizeof(bn_gt))) || (rc = db.alloc(n * bsize)) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
+    HIP_TRY(hipMemcpyAsync(da.p, a, n * sizeof(bn_gt), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db.p, b, n * bsize, hipMemcpyHostToDevice, ctx->stream));
+    rc = op == 0 ? bn254_gt_mul_batch_dev(ctx, da.p, db.p, dout.p, n, ctx->stream) : bn254_gt_pow_batch_dev(ctx, da.p, db.p, dout.p, n, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n) { return gt_binop_host(ctx, 0, a, b, sizeof(bn_gt), out, n); }
+int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n) { return gt_binop_host(ctx, 1, a, k, sizeof(bn_fr), out, n); }
 int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n) { return mul_host(ctx, 1, p, k, out, n); }
 int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n) { return mul_host(ctx, 2, p, k, out, n); }
 

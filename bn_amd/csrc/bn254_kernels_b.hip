@@ -11,6 +11,7 @@
 #define BN_INLINE_REDUCTIONS 1
 #endif
 #include <hip/hip_runtime.h>
+#include "curve.hpp"
 #include "io.hpp"
 
 using namespace bn254;
@@ -70,9 +71,51 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair));
     if (live) f12_store(f, out + 96u * pair);
 }
+// out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;
+    Fq12<F2> r = f12_mul_o(f12_load<F2>(a + 96u * pair), f12_load<F2>(b + 96u * pair));
+    if (live) f12_store(r, out + 96u * pair);
+}
+// out[i] = a[i] ^ k[i]   (Gt::pow, lib.rs:171 -> fields/mod.rs:35-46: 256 x { res = res^2; if bit { res = a * res } } on the scalar
+// taken out of Montgomery form).  Exponent bits differ per element, so the conditional product is a per-pair select.
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;
+    uint32_t kw[8], raw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kw[i] = k[8u * pair + i];
+    fr_from_mont(kw, raw);
+    Fq12<F2> base = f12_load<F2>(a + 96u * pair);
+    Fq12<F2> res = f12_one<F2>();
+#pragma unroll 1
+    for (int i = 255; i >= 0; --i) {
+        res = f12_sqr(res);
+        Fq12<F2> m = f12_mul(base, res);
+        bool bit = (raw[i >> 5] >> (i & 31)) & 1;
+        res.c0.c0 = f2_select(bit, res.c0.c0, m.c0.c0); res.c0.c1 = f2_select(bit, res.c0.c1, m.c0.c1); res.c0.c2 = f2_select(bit, res.c0.c2, m.c0.c2);
+        res.c1.c0 = f2_select(bit, res.c1.c0, m.c1.c0); res.c1.c1 = f2_select(bit, res.c1.c1, m.c1.c1); res.c1.c2 = f2_select(bit, res.c1.c2, m.c1.c2);
+    }
+    if (live) f12_store(res, out + 96u * pair);
+}
 }  // namespace
 
 extern "C" {
+int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_gt_mul_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, (uint32_t)n);
+    return (int)hipGetLastError();
+}
+int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
+    return (int)hipGetLastError();
+}
 int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(bn254_miller_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);

@@ -77,6 +77,18 @@ class Engine:
         _native.check(self._lib.bn254_g2_mul_batch(self._h, _p(p), _p(k), _p(out), p.shape[0]))
         return out
 
+    def gt_mul_batch(self, a, b):
+        a = _arr(a, GT_WORDS); b = _arr(b, GT_WORDS)
+        out = np.empty_like(a)
+        _native.check(self._lib.bn254_gt_mul_batch(self._h, _p(a), _p(b), _p(out), a.shape[0]))
+        return out
+
+    def gt_pow_batch(self, a, k):
+        a = _arr(a, GT_WORDS); k = _arr(k, 4)
+        out = np.empty_like(a)
+        _native.check(self._lib.bn254_gt_pow_batch(self._h, _p(a), _p(k), _p(out), a.shape[0]))
+        return out
+
     # ---- device-resident API: raw device pointers (ints) + hipStream_t (int or 0)
     def pairing_batch_dev(self, d_p, d_q, d_out, n, stream=0):
         _native.check(self._lib.bn254_pairing_batch_dev(self._h, d_p, d_q, d_out, n, stream))

@@ -18,6 +18,8 @@
  *   bn254_pairing_product  fold(Gt::one(), |acc,(p,q)| acc * pairing(p,q))          shootout/main.rs:11-16, lib.rs:175-179
  *   bn254_g1_mul_batch     out[i] = normalize(p[i] * k[i])                          lib.rs:116-120,88-95, groups/mod.rs:250-270
  *   bn254_g2_mul_batch     same over G2                                             lib.rs:159-163,131-138
+ *   bn254_gt_mul_batch     out[i] = a[i] * b[i]                                     lib.rs:175-179, fields/fq12.rs:295-307
+ *   bn254_gt_pow_batch     out[i] = a[i].pow(k[i])                                  lib.rs:171, fields/mod.rs:35-46
  * Outputs are bit-identical to the reference's on the same inputs (pairing values are canonical field elements; scalar
  * multiples are compared after `normalize()` because Jacobian coordinates depend on the addition chain).
  *
@@ -71,6 +73,8 @@ int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *o
 int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out);
 int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n);
 int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n);
+int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n);
+int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n);
 
 /* ---- device-resident entry points (inputs/outputs already in HBM; `stream` is a hipStream_t or NULL) ------------------ */
 /* Same layouts (array of structs) in device memory.  Asynchronous on `stream`; the caller synchronises. */
@@ -82,6 +86,8 @@ int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream);
 /* local part of a sharded multi-pairing: un-exponentiated product of the Miller values of n pairs -> one Fq12 */
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream);
+int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
+int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream);
 int bn254_g1_mul_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
 int bn254_g2_mul_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
 /* raw Jacobian result of the reference's MSB-first double-and-add (what G::random produces, groups/mod.rs:220-222):
@@ -94,7 +100,7 @@ int bn254_g2_mul_jacobian_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, 
    accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
 int bn254_profile_enable(bn254_ctx *ctx, int on);
 int bn254_profile_reset(bn254_ctx *ctx);
-/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul".  Synchronises the recorded events. */
+/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul", "gt_mul", "gt_pow".  Synchronises the recorded events. */
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 
 #ifdef __cplusplus

@@ -198,3 +198,25 @@ def test_g1_mul_full_size_config5(oracle):
     idx = np.random.default_rng(9).choice(n, 512, replace=False)
     Pn = P.cpu().numpy().view(np.uint64)[idx]; kn = k.cpu().numpy().view(np.uint64)[idx]
     assert np.array_equal(out.cpu().numpy().view(np.uint64)[idx], canon_infinity(oracle.g1_mul_batch(Pn, kn)))
+
+
+def test_gt_mul_and_pow_match_oracle(oracle, eng):
+    """Gt * Gt (lib.rs:175-179) and Gt::pow (lib.rs:171) on the GPU, then test_binlinearity (groups/mod.rs:798-823) entirely
+    through the mirrored API: e(P,Q)^s == e(sP,Q) == e(P,sQ), a != 1, a^(-1) * a == 1"""
+    import bn_amd
+    rng = np.random.default_rng(108)
+    n = 9
+    P, Q = _points(oracle, rng, n)
+    g = eng.pairing_batch(P, Q)
+    sv = _scalars(rng, n); sv[:3] = [0, 1, M.R_ORD - 1]
+    s = _fr(oracle, sv)
+    pw = eng.gt_pow_batch(g, s)
+    ml = eng.gt_mul_batch(g, g[::-1].copy())
+    for i in range(n):
+        assert np.array_equal(pw[i], oracle.gt_pow(g[i], s[i]))
+        assert np.array_equal(ml[i], oracle.fq12_mul(g[i], g[n - 1 - i]))
+    p, q, sc = bn_amd.G1.random(rng), bn_amd.G2.random(rng), bn_amd.Fr.random(rng)
+    a = bn_amd.pairing(p, q).pow(sc)
+    assert a == bn_amd.pairing(p * sc, q) == bn_amd.pairing(p, q * sc)
+    assert a != bn_amd.Gt.one()
+    assert a.pow(-bn_amd.Fr.one()) * a == bn_amd.Gt.one()
