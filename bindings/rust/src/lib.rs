@@ -1,0 +1,92 @@
+//! UNVERIFIED SOURCE (no rustc/cargo in the build image; never compiled).
+//!
+//! Batch GPU entry points for the `bn` crate (zcash-hackworks/bn v0.4.3) over the C ABI of `include/bn254_hip.h`.
+//! `bn::{Fr, G1, G2, Gt}` are `#[repr(C)]` newtype chains down to `[u64; 4]` (src/lib.rs:15-17, 79-81, 122-124, 165-167), so a
+//! slice of them is bit-for-bit an array of `bn_fr` / `bn_g1` / `bn_g2` / `bn_gt`: no conversion, no copies beyond the DMA.
+//! Results are `==`-equal (and, for `Gt`, byte-equal) to what the crate computes on the CPU.
+extern crate bn;
+
+use bn::{Fr, G1, G2, Gt};
+use std::os::raw::{c_int, c_void};
+
+extern "C" {
+    fn bn254_pairing_batch(ctx: *mut c_void, p: *const G1, q: *const G2, out: *mut Gt, n: usize) -> c_int;
+    fn bn254_pairing_product(ctx: *mut c_void, p: *const G1, q: *const G2, n: usize, out: *mut Gt) -> c_int;
+    fn bn254_g1_mul_batch(ctx: *mut c_void, p: *const G1, k: *const Fr, out: *mut G1, n: usize) -> c_int;
+    fn bn254_g2_mul_batch(ctx: *mut c_void, p: *const G2, k: *const Fr, out: *mut G2, n: usize) -> c_int;
+    fn bn254_gt_mul_batch(ctx: *mut c_void, a: *const Gt, b: *const Gt, out: *mut Gt, n: usize) -> c_int;
+    fn bn254_gt_pow_batch(ctx: *mut c_void, a: *const Gt, k: *const Fr, out: *mut Gt, n: usize) -> c_int;
+}
+
+/// Error code of the HIP engine: negative `BN254_E_*`, positive `hipError_t`.  There is no CPU fallback.
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub struct GpuError(pub i32);
+
+fn check(rc: c_int) -> Result<(), GpuError> { if rc == 0 { Ok(()) } else { Err(GpuError(rc)) } }
+
+/// `out[i] = bn::pairing(p[i], q[i])` (src/lib.rs:181-183)
+pub fn pairing_batch(p: &[G1], q: &[G2]) -> Result<Vec<Gt>, GpuError> {
+    assert_eq!(p.len(), q.len());
+    let mut out = vec![Gt::one(); p.len()];
+    check(unsafe { bn254_pairing_batch(std::ptr::null_mut(), p.as_ptr(), q.as_ptr(), out.as_mut_ptr(), p.len()) })?;
+    Ok(out)
+}
+
+/// `fold(Gt::one(), |acc, (p, q)| acc * pairing(p, q))` (shootout/main.rs:11-16) with a single final exponentiation
+pub fn pairing_product(p: &[G1], q: &[G2]) -> Result<Gt, GpuError> {
+    assert_eq!(p.len(), q.len());
+    let mut out = Gt::one();
+    check(unsafe { bn254_pairing_product(std::ptr::null_mut(), p.as_ptr(), q.as_ptr(), p.len(), &mut out) })?;
+    Ok(out)
+}
+
+/// `out[i] = p[i] * k[i]`, returned normalized (src/lib.rs:88-95): equal to the crate's result under its projective `==`
+pub fn g1_mul_batch(p: &[G1], k: &[Fr]) -> Result<Vec<G1>, GpuError> {
+    assert_eq!(p.len(), k.len());
+    let mut out = p.to_vec();
+    check(unsafe { bn254_g1_mul_batch(std::ptr::null_mut(), p.as_ptr(), k.as_ptr(), out.as_mut_ptr(), p.len()) })?;
+    Ok(out)
+}
+
+pub fn g2_mul_batch(p: &[G2], k: &[Fr]) -> Result<Vec<G2>, GpuError> {
+    assert_eq!(p.len(), k.len());
+    let mut out = p.to_vec();
+    check(unsafe { bn254_g2_mul_batch(std::ptr::null_mut(), p.as_ptr(), k.as_ptr(), out.as_mut_ptr(), p.len()) })?;
+    Ok(out)
+}
+
+/// `out[i] = a[i] * b[i]` (src/lib.rs:175-179)
+pub fn gt_mul_batch(a: &[Gt], b: &[Gt]) -> Result<Vec<Gt>, GpuError> {
+    assert_eq!(a.len(), b.len());
+    let mut out = a.to_vec();
+    check(unsafe { bn254_gt_mul_batch(std::ptr::null_mut(), a.as_ptr(), b.as_ptr(), out.as_mut_ptr(), a.len()) })?;
+    Ok(out)
+}
+
+/// `out[i] = a[i].pow(k[i])` (src/lib.rs:171)
+pub fn gt_pow_batch(a: &[Gt], k: &[Fr]) -> Result<Vec<Gt>, GpuError> {
+    assert_eq!(a.len(), k.len());
+    let mut out = a.to_vec();
+    check(unsafe { bn254_gt_pow_batch(std::ptr::null_mut(), a.as_ptr(), k.as_ptr(), out.as_mut_ptr(), a.len()) })?;
+    Ok(out)
+}
+
+#[cfg(test)]
+mod tests {
+    // mirrors shootout/main.rs: the GPU fold equals the CPU fold
+    use super::*;
+    #[test]
+    fn product_matches_cpu_fold() {
+        let (mut a, mut b) = (G1::one(), G2::one());
+        let c = Fr::from_str("1901").unwrap().inverse().unwrap();
+        let d = Fr::from_str("2344").unwrap().inverse().unwrap();
+        let (mut ps, mut qs, mut acc) = (vec![], vec![], Gt::one());
+        for _ in 0..64 {
+            acc = acc * bn::pairing(a, b);
+            ps.push(a); qs.push(b);
+            a = a * c; b = b * d;
+        }
+        assert!(pairing_product(&ps, &qs).unwrap() == acc);
+        assert!(pairing_batch(&ps, &qs).unwrap().into_iter().fold(Gt::one(), |x, y| x * y) == acc);
+    }
+}
