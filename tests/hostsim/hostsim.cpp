@@ -26,6 +26,7 @@ EXPORT void hs_fe_add(const uint32_t *a, const uint32_t *b, uint32_t *o) { fe_to
 EXPORT void hs_fe_sub(const uint32_t *a, const uint32_t *b, uint32_t *o) { fe_to_u32x8(fe_sub<1, 3>(fe_from_u32x8(a), fe_from_u32x8(b)), o); }
 EXPORT void hs_fe_roundtrip(const uint32_t *a, uint32_t *o) { fe_to_u32x8(fe_from_u32x8(a), o); }
 EXPORT void hs_fe_inverse(const uint32_t *a, uint32_t *o) { fe_to_u32x8(fe_inverse(fe_from_u32x8(a)), o); }
+EXPORT void hs_fe_inverse_fermat(const uint32_t *a, uint32_t *o) { fe_to_u32x8(fe_inverse_fermat(fe_from_u32x8(a)), o); }
 EXPORT int hs_fe_is_zero(const uint32_t *a) { return fe_is_zero(fe_from_u32x8(a)); }
 // a stress of the lazy forms: ((a+b)+(a+b)) - b - b + 9a ... reduced through lc3, compared with the oracle's canonical ops
 EXPORT void hs_fe_lazy_mix(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *o) {

@@ -53,9 +53,13 @@ def test_fe_lazy_forms(oracle, hs):
 
 
 def test_fe_inverse(oracle, hs):
+    """divsteps (safegcd) inversion == the reference's binary EEA result == the Fermat chain, incl. edge values"""
     rng = np.random.default_rng(13)
-    for a in [oracle.fp_from_int(FQ, v) for v in (1, 2, M.Q - 1, 12345)] + [_rfq(oracle, rng) for _ in range(4)]:
-        assert np.array_equal(hs.call("hs_fe_inverse", a, out_words=8), oracle.fp_inverse(FQ, a))
+    for a in [oracle.fp_from_int(FQ, v) for v in EDGE[1:] + [3, 12345, (1 << 254) % M.Q, M.Q - 3]] + [_rfq(oracle, rng) for _ in range(300)]:
+        want = oracle.fp_inverse(FQ, a)
+        assert np.array_equal(hs.call("hs_fe_inverse", a, out_words=8), want)
+    for a in [_rfq(oracle, rng) for _ in range(3)]:
+        assert np.array_equal(hs.call("hs_fe_inverse_fermat", a, out_words=8), oracle.fp_inverse(FQ, a))
     z = oracle.fp_from_int(FQ, 0)
     assert np.array_equal(hs.call("hs_fe_inverse", z, out_words=8), z)       # engine convention: inverse(0) = 0
 
