@@ -263,29 +263,30 @@ BN_FN Fe fe_reduce(const Fe &a) {
 // conditional add/subtract per Fq add instead (arith.rs:238-253).  Result: normalized limbs, value < 3q.
 // core: the middle term's sign is a per-lane run-time flag (needed by the lane-pair Fq2 mapping, where the even lane
 // subtracts and the odd lane adds the partner's limb in xi-multiplications)
-template <int C1, int C2, int C3>
-BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) {
+template <int C1, int C2, int C3, int C4>
+BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool neg2) {
     BN_COUNT(lc3);
-    constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3;
+    constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3, A4 = C4 < 0 ? -C4 : C4;
     // Every input limb is read as a SIGNED 32-bit integer (so inputs may be signed lazy differences, fe_ssub): |limb| < 2^31,
     // i.e. lb <= 4.  Terms with a small coefficient are first combined in 32-bit arithmetic ("narrow"); the others enter the
     // 64-bit chain on their own.
-    constexpr bool N1 = C1 != 0 && A1 <= 2, N2 = C2 != 0 && A2 <= 2, N3 = C3 != 0 && A3 <= 2;
-    BN_IFB(if (!((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4)))
-               std::fprintf(stderr, "fe_lc3<%d,%d,%d> lbs %u %u %u\n", C1, C2, C3, x.lb, y.lb, z.lb);)
-    BN_REQUIRE((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4), "fe_lc3: input limbs must fit int32");
-    BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb <= 1000, "fe_lc3 vb");
-    BN_IFB(if ((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) > 4)
-               std::fprintf(stderr, "fe_lc3<%d,%d,%d> lbs %u %u %u\n", C1, C2, C3, x.lb, y.lb, z.lb);)
-    BN_REQUIRE((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) <= 4, "fe_lc3 narrow part exceeds 32 bits");
+    constexpr bool N1 = C1 != 0 && A1 <= 2, N2 = C2 != 0 && A2 <= 2, N3 = C3 != 0 && A3 <= 2, N4 = C4 != 0 && A4 <= 2;
+    BN_IFB(if (!((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4) && (C4 == 0 || w.lb <= 4)))
+               std::fprintf(stderr, "fe_lc<%d,%d,%d,%d> lbs %u %u %u %u\n", C1, C2, C3, C4, x.lb, y.lb, z.lb, w.lb);)
+    BN_REQUIRE((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4) && (C4 == 0 || w.lb <= 4), "fe_lc: input limbs must fit int32");
+    BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb + (uint64_t)A4 * w.vb <= 1000, "fe_lc vb");
+    BN_IFB(if ((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) + (N4 ? A4 * w.lb : 0) > 4)
+               std::fprintf(stderr, "fe_lc<%d,%d,%d,%d> lbs %u %u %u %u\n", C1, C2, C3, C4, x.lb, y.lb, z.lb, w.lb);)
+    BN_REQUIRE((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) + (N4 ? A4 * w.lb : 0) <= 4, "fe_lc narrow part exceeds 32 bits");
     // signed estimate of floor(value / 2^232) that never exceeds the truth (margins: carries still parked in lower limbs,
     // at most 9 per unit coefficient, and the truncation of FE_MU24, < 2^9 units)
     auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8] + ((int32_t)f.l[7] >> 29); };
     const int32_t c2 = neg2 ? -C2 : C2;
-    int64_t te = -600 - 9 * (int64_t)(A1 + A2 + A3);
+    int64_t te = -600 - 9 * (int64_t)(A1 + A2 + A3 + A4);
     if (C1 != 0) te += (int64_t)C1 * top(x);
     if (C2 != 0) te += (int64_t)c2 * top(y);
     if (C3 != 0) te += (int64_t)C3 * top(z);
+    if (C4 != 0) te += (int64_t)C4 * top(w);
     const int64_t kq = (te * (int64_t)k::FE_MU24) >> 45;     // floor; kq <= floor(value/q), kq >= value/q - 2
     Fe r;
     int64_t carry = 0;
@@ -295,15 +296,19 @@ BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) {
         if (N1) nsum += C1 * (int32_t)x.l[i];
         if (N2) { int32_t yy = C2 * (int32_t)y.l[i]; nsum += neg2 ? -yy : yy; }
         if (N3) nsum += C3 * (int32_t)z.l[i];
+        if (N4) nsum += C4 * (int32_t)w.l[i];
         int64_t t = carry + (int64_t)nsum - kq * (int64_t)k::Q[i];
         if (C1 != 0 && !N1) t += (int64_t)C1 * (int64_t)(int32_t)x.l[i];
         if (C2 != 0 && !N2) t += (int64_t)c2 * (int64_t)(int32_t)y.l[i];
         if (C3 != 0 && !N3) t += (int64_t)C3 * (int64_t)(int32_t)z.l[i];
+        if (C4 != 0 && !N4) t += (int64_t)C4 * (int64_t)(int32_t)w.l[i];
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
     BN_SETB(r, 1, 3);
     return r;
 }
+template <int C1, int C2, int C3>
+BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) { return fe_lc4_core<C1, C2, C3, 0>(x, y, z, z, neg2); }
 // all-64-bit variant for UNSIGNED lazy inputs with limbs beyond 31 bits (lb up to 8); rare call sites only
 template <int C1, int C2, int C3>
 BN_FN Fe fe_lc3w_body(const Fe &x, const Fe &y, const Fe &z) {

@@ -70,6 +70,11 @@ template <int CX, int CY>
 BN_FN Fq2A f2_lc_xi(const Fq2A &x, const Fq2A &y) {
     return {fe_lc3<9 * CX, -CX, CY>(x.c0, x.c1, y.c0), fe_lc3<9 * CX, CX, CY>(x.c1, x.c0, y.c1)};
 }
+// reduce(CX*xi*x + CY*y + CZ*z)   (inline: four operands do not fit the register-passing convention of the leaves)
+template <int CX, int CY, int CZ>
+BN_FN Fq2A f2_lc_xi2(const Fq2A &x, const Fq2A &y, const Fq2A &z) {
+    return {fe_lc4_core<9 * CX, -CX, CY, CZ>(x.c0, x.c1, y.c0, z.c0, false), fe_lc4_core<9 * CX, CX, CY, CZ>(x.c1, x.c0, y.c1, z.c1, false)};
+}
 BN_FN Fq2A f2_mul_xi(const Fq2A &x) { return f2_lc_xi<1, 0>(x, x); }
 // lazy variants for values that go straight into a multiplication as the FIRST operand (lb <= 2 there)
 BN_FN Fq2A f2_neg_lazy(const Fq2A &a) { return {fe_neg<1, 4>(a.c0), fe_neg<1, 4>(a.c1)}; }
@@ -111,6 +116,8 @@ BN_FN bool lane_pair_all_zero(const Fe &a) { bool z = fe_is_zero(a); return z &&
 template <int C1, int C2, int C3>
 BN_FN Fe fe_lc3_par_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3>(x, y, z, !lane_is_odd()); }
 BN_LEAF3T(fe_lc3_par, fe_lc3_par_body)
+template <int C1, int C2, int C3, int C4>
+BN_FN Fe fe_lc4_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4>(x, y, z, w, !lane_is_odd()); }
 #endif
 
 template <class T>
@@ -172,6 +179,8 @@ template <class T> BN_FN Fq2B<T> f2_scale(const Fq2B<T> &a, const T &s) { return
 // reduce(CX*xi*x + CY*y): even lane 9CX*x0 - CX*x1 + CY*y0, odd lane 9CX*x1 + CX*x0 + CY*y1
 template <int CX, int CY, class T>
 BN_FN Fq2B<T> f2_lc_xi(const Fq2B<T> &x, const Fq2B<T> &y) { return {fe_lc3_par<9 * CX, CX, CY>(x.v, lane_partner(x.v), y.v)}; }
+template <int CX, int CY, int CZ, class T>
+BN_FN Fq2B<T> f2_lc_xi2(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc4_par<9 * CX, CX, CY, CZ>(x.v, lane_partner(x.v), y.v, z.v)}; }
 template <class T> BN_FN Fq2B<T> f2_mul_xi(const Fq2B<T> &x) { return f2_lc_xi<1, 0>(x, x); }
 template <class T, class TAB>
 BN_FN Fq2B<T> f2_mul_const(const Fq2B<T> &a, const TAB &tab) { return f2_mul(a, f2_const((const Fq2B<T> *)nullptr, tab)); }

@@ -161,27 +161,27 @@ BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &
 
 // fq12.rs:178-227 (Granger-Scott squaring; equals f*f only on the cyclotomic subgroup - the KAT of fields/mod.rs:171-201
 // feeds it an element OFF the subgroup, so the formula itself is part of the contract)
+// one Fp4 squaring of Granger-Scott, fused with the "times three, plus/minus twice the old coefficient" that follows it:
+//   tmp = a b,  t_even = (a + b)(a + xi b) - tmp - xi tmp = a^2 + xi b^2
+//   out_even = 3 t_even - 2 z_even          (ONE reduction: 3 m - 3 tmp - 3 xi tmp - 2 z_even)
+//   returns tmp (t_odd = 2 tmp is applied by the caller: 6 tmp + 2 z_odd)
 template <class F2>
-BN_FN void f4_sq(const F2 &a, const F2 &b, F2 &t_even, F2 &tmp_out) {       // (a + b s)^2, s^2 = xi: even = a^2 + xi b^2, tmp = a b
+BN_FN F2 f4_sq_fused(const F2 &a, const F2 &b, const F2 &z_even, F2 &out_even) {
     F2 tmp = f2_mul(a, b);
     F2 m = f2_mul(f2_add(a, b), f2_lc_xi<1, 1>(b, a));
-    t_even = f2_lc_xi<-1, 1>(tmp, f2_ssub(m, tmp));
-    tmp_out = tmp;
+    out_even = f2_lc_xi2<-3, 3, -2>(tmp, f2_ssub(m, tmp), z_even);
+    return tmp;
 }
 template <class F2>
 BN_COARSE Fq12<F2> f12_cyclotomic_sqr(const Fq12<F2> &f) {
     const F2 &z0 = f.c0.c0, &z4 = f.c0.c1, &z3 = f.c0.c2, &z2 = f.c1.c0, &z1 = f.c1.c1, &z5 = f.c1.c2;
-    F2 t0, t2, t4, p01, p23, p45;                            // t1 = 2 p01, t3 = 2 p23, t5 = 2 p45
-    f4_sq(z0, z1, t0, p01);
-    f4_sq(z2, z3, t2, p23);
-    f4_sq(z4, z5, t4, p45);
     Fq12<F2> r;
-    r.c0.c0 = f2_lc3<3, -2, 0>(t0, z0, z0);                   // 2(t0 - z0) + t0
-    r.c1.c1 = f2_lc3<6, 2, 0>(p01, z1, z1);                   // 2(t1 + z1) + t1
-    r.c1.c0 = f2_lc_xi<6, 2>(p45, z2);                        // 2(xi t5 + z2) + xi t5
-    r.c0.c2 = f2_lc3<3, -2, 0>(t4, z3, z3);
-    r.c0.c1 = f2_lc3<3, -2, 0>(t2, z4, z4);
-    r.c1.c2 = f2_lc3<6, 2, 0>(p23, z5, z5);
+    F2 p01 = f4_sq_fused(z0, z1, z0, r.c0.c0);               // z0' = 2(t0 - z0) + t0
+    F2 p23 = f4_sq_fused(z2, z3, z4, r.c0.c1);               // z4' = 2(t2 - z4) + t2
+    F2 p45 = f4_sq_fused(z4, z5, z3, r.c0.c2);               // z3' = 2(t4 - z3) + t4
+    r.c1.c1 = f2_lc3<6, 2, 0>(p01, z1, z1);                   // z1' = 2(t1 + z1) + t1,  t1 = 2 p01
+    r.c1.c0 = f2_lc_xi<6, 2>(p45, z2);                        // z2' = 2(xi t5 + z2) + xi t5
+    r.c1.c2 = f2_lc3<6, 2, 0>(p23, z5, z5);                   // z5' = 2(t3 + z5) + t3
     return r;
 }
 

@@ -24,6 +24,10 @@ template <int C1, int C2, int C3>      // middle term: minus on the even lane, p
 BN_FN FeP fe_lc3_par(const FeP &x, const FeP &y, const FeP &z) {
     return {{fe_lc3_core<C1, C2, C3>(x.v[0], y.v[0], z.v[0], true), fe_lc3_core<C1, C2, C3>(x.v[1], y.v[1], z.v[1], false)}};
 }
+template <int C1, int C2, int C3, int C4>
+BN_FN FeP fe_lc4_par(const FeP &x, const FeP &y, const FeP &z, const FeP &w) {
+    return {{fe_lc4_core<C1, C2, C3, C4>(x.v[0], y.v[0], z.v[0], w.v[0], true), fe_lc4_core<C1, C2, C3, C4>(x.v[1], y.v[1], z.v[1], w.v[1], false)}};
+}
 BN_FN FeP fe_mul(const FeP &a, const FeP &b) { return {{fe_mul(a.v[0], b.v[0]), fe_mul(a.v[1], b.v[1])}}; }
 BN_FN FeP fe_mul_body(const FeP &a, const FeP &b) { return fe_mul(a, b); }
 BN_FN FeP fe_sqr(const FeP &a) { return fe_mul(a, a); }
