@@ -42,6 +42,7 @@ BN_FN Fq2A f2_lc3w(const Fq2A &x, const Fq2A &y, const Fq2A &z) {
     return {fe_lc3w<C1, C2, C3>(x.c0, y.c0, z.c0), fe_lc3w<C1, C2, C3>(x.c1, y.c1, z.c1)};
 }
 BN_FN Fq2A f2_sum_for_mul(const Fq2A &a, const Fq2A &b) { return f2_lc3<1, 1, 0>(a, b, b); }     // Karatsuba needs it reduced
+BN_FN Fq2A f2_sum3_for_mul(const Fq2A &a, const Fq2A &b, const Fq2A &c) { return f2_lc3<1, 1, 1>(a, b, c); }
 BN_FN Fq2A f2_neg(const Fq2A &a) { return f2_lc3<-1, 0, 0>(a, a, a); }
 BN_FN Fq2A f2_conj(const Fq2A &a) { return {a.c0, fe_lc3<-1, 0, 0>(a.c1, a.c1, a.c1)}; }
 BN_FN Fq2A f2_zero(const Fq2A *) { return {fe_zero(), fe_zero()}; }
@@ -164,6 +165,7 @@ BN_FN Fq2B<T> f2_lc3(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { ret
 template <int C1, int C2, int C3, class T>
 BN_FN Fq2B<T> f2_lc3w(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc3w<C1, C2, C3>(x.v, y.v, z.v)}; }
 template <class T> BN_FN Fq2B<T> f2_sum_for_mul(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_norm(fe_add(a.v, b.v))}; }
+template <class T> BN_FN Fq2B<T> f2_sum3_for_mul(const Fq2B<T> &a, const Fq2B<T> &b, const Fq2B<T> &c) { return {fe_norm(fe_add(fe_add(a.v, b.v), c.v))}; }
 template <class T> BN_FN Fq2B<T> f2_neg(const Fq2B<T> &a) { return {fe_lc3<-1, 0, 0>(a.v, a.v, a.v)}; }
 template <class T> BN_FN Fq2B<T> f2_conj(const Fq2B<T> &a) { return {lane_pick(a.v, fe_lc3<-1, 0, 0>(a.v, a.v, a.v))}; }
 template <class T> BN_FN Fq2B<T> f2_neg_lazy(const Fq2B<T> &a) { return {fe_neg<1, 4>(a.v)}; }

@@ -104,7 +104,7 @@ BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     u.c0 = f2_lc_xi<1, 1>(a.c1.c2, a.c0.c0);
     u.c1 = f2_lc3<1, 1, 0>(a.c1.c0, a.c0.c1, a.c0.c1);
     u.c2 = f2_lc3<1, 1, 0>(a.c1.c1, a.c0.c2, a.c0.c2);
-    Fq6<F2> t = f6_mul(u, f6_add(a.c0, a.c1));
+    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), u);
     Fq12<F2> r;
     r.c0.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_ssub(t.c0, ab.c0));      // t - ab - v*ab
     r.c0.c1 = f2_lc3<1, -1, -1>(t.c1, ab.c1, ab.c0);
@@ -146,7 +146,7 @@ BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &
     F2 m02 = f2_mul(f2_add(z0, z2), x02);                   // (z0+z2)(x0+x2)
     F2 m24 = f2_mul(f2_add(z2, z4), x24);                   // (z2+z4)(x2+x4)
     F2 m04 = f2_mul(f2_add(z0, z4), x04);                   // (z0+z4)(x0+x4)
-    F2 s0 = f2_lc3<1, 1, 1>(z1, z3, z5), xs = f2_lc3<1, 1, 1>(x0, x2, x4);
+    F2 s0 = f2_sum3_for_mul(z1, z3, z5), xs = f2_lc3<1, 1, 1>(x0, x2, x4);
     F2 ms = f2_mul(s0, xs);
     F2 s1 = f2_add(f2_add(f2_add(z1x2, z5x4), f2_add(z1x0, z3x4)), f2_add(z3x0, z5x2));      // lazy, lb 6
     Fq12<F2> r;
