@@ -24,6 +24,10 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_pairing_product": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_g1_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_g2_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_g2_precompute": [_VP, _VP, _VP, _SZ],
+    "bn254_pairing_prepared_batch": [_VP, _VP, _VP, C.c_int, _VP, _SZ],
+    "bn254_g2_precompute_dev": [_VP, _VP, _VP, _SZ, _VP],
+    "bn254_miller_prepared_dev": [_VP, _VP, _VP, C.c_int, _VP, _SZ, _VP],
     "bn254_gt_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_gt_pow_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_gt_mul_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],

@@ -118,6 +118,8 @@ __global__ void __launch_bounds__(BLOCK) bn254_g2_mul_k(const uint32_t *p, const
 // ======================================================================================================== host side
 extern "C" int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, hipStream_t s);      // bn254_kernels_b.hip
 extern "C" int bn254_launch_final_exp_B(const void *f, void *out, size_t n, hipStream_t s);
+extern "C" int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
+extern "C" int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
 extern "C" int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
 extern "C" int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hipStream_t s);
 
@@ -317,6 +319,22 @@ int bn254_g2_mul_batch_dev(bn254_ctx *c, const void *p, const void *k, void *o, 
 int bn254_g1_mul_jacobian_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 1, p, k, o, n, s, 0); }
 int bn254_g2_mul_jacobian_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 2, p, k, o, n, s, 0); }
 
+int bn254_g2_precompute_dev(bn254_ctx *ctx, const void *d_q, void *d_coeffs, size_t n, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_q || !d_coeffs || n > 0x7fffffffu / (102 * 48)) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Scope sc(ctx, (hipStream_t)stream, "g2_precompute");
+    return bn254_launch_g2_precompute_B(d_q, d_coeffs, n, (hipStream_t)stream);
+}
+int bn254_miller_prepared_dev(bn254_ctx *ctx, const void *d_p, const void *d_coeffs, int shared, void *d_f, size_t n, void *stream) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_p || !d_coeffs || !d_f || n > 0x7fffffffu / (102 * 48)) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Scope sc(ctx, (hipStream_t)stream, "miller_prepared");
+    return bn254_launch_miller_prepared_B(d_p, d_coeffs, shared, d_f, n, (hipStream_t)stream);
+}
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream) {
     int rc = get_ctx(ctx); if (rc) return rc;
     if (n == 0) return BN254_OK;
@@ -385,6 +403,36 @@ static int mul_host(bn254_ctx *ctx, int g, const void *p, const bn_fr *k, void *
     HIP_TRY(hipMemcpyAsync(dk.p, k, n * sizeof(bn_fr), hipMemcpyHostToDevice, ctx->stream));
     rc = mul_dev(ctx, g, dp.p, dk.p, dout.p, n, ctx->stream, 1); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, dout.p, n * ps, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, size_t n) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!q || !coeffs) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf dq, dc;
+    size_t cb = n * 102 * sizeof(bn_ell_coeffs);
+    if ((rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dc.alloc(cb))) return rc;
+    HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
+    rc = bn254_g2_precompute_dev(ctx, dq.p, dc.p, n, ctx->stream); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(coeffs, dc.p, cb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_coeffs *coeffs, int shared, bn_gt *out, size_t n) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!p || !coeffs || !out) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf dp, dc, dout;
+    size_t cb = (shared ? 1 : n) * 102 * sizeof(bn_ell_coeffs);
+    if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dc.alloc(cb)) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
+    HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dc.p, coeffs, cb, hipMemcpyHostToDevice, ctx->stream));
+    rc = bn254_miller_prepared_dev(ctx, dp.p, dc.p, shared, dout.p, n, ctx->stream); if (rc) return rc;
+    rc = bn254_final_exp_batch_dev(ctx, dout.p, dout.p, n, ctx->stream); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;
 }

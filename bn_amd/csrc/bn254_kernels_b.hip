@@ -71,6 +71,47 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair));
     if (live) f12_store(f, out + 96u * pair);
 }
+// ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
+constexpr int NCOEFF = 102, COEFF_WORDS = 48;
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_precompute_B(const uint32_t *g2, uint32_t *coeffs, uint32_t n) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;
+    const uint32_t *w2 = g2 + 48u * pair;
+    G2Aff<F2> q = g2_to_affine(f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32));
+    uint32_t *dst = coeffs + (size_t)pair * NCOEFF * COEFF_WORDS;
+    auto sink = [&](int idx, const Line<F2> &l) {
+        if (live) {
+            uint32_t *c = dst + idx * COEFF_WORDS;
+            f2_store(l.ell_0, c); f2_store(l.ell_vw, c + 16); f2_store(l.ell_vv, c + 32);
+        }
+    };
+    precompute_lines(q, sink);
+}
+// f[i] = miller_loop(coeffs, P[i])  (groups/mod.rs:486-519); coeff_stride = 0 shares one coefficient set among all P
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_miller_prepared_B(const uint32_t *g1, const uint32_t *coeffs, uint32_t coeff_stride, uint32_t *f_out, uint32_t n) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;
+    const uint32_t *w1 = g1 + 24u * pair;
+    bool inf = words_all_zero(w1 + 16, 8);
+    Fe zi = fe_inverse(f2_scalar_load((const F2 *)nullptr, w1 + 16)), zi2 = fe_sqr(zi);
+    G1Aff<Fe> p = {fe_mul(f2_scalar_load((const F2 *)nullptr, w1), zi2), fe_mul(f2_scalar_load((const F2 *)nullptr, w1 + 8), fe_mul(zi2, zi))};
+    const uint32_t *src = coeffs + (size_t)pair * coeff_stride;
+    auto source = [&](int idx) {
+        const uint32_t *c = src + idx * COEFF_WORDS;
+        Line<F2> l = {f2_load((const F2 *)nullptr, c), f2_load((const F2 *)nullptr, c + 16), f2_load((const F2 *)nullptr, c + 32)};
+        return l;
+    };
+    Fq12<F2> f = miller_loop_prepared<F2>(p, source);
+    Fq12<F2> one = f12_one<F2>();
+    f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
+    f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);
+    if (live) f12_store(f, f_out + 96u * pair);
+}
+
 // out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
@@ -106,6 +147,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
 }  // namespace
 
 extern "C" {
+int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_g2_precompute_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)q, (uint32_t *)coeffs, (uint32_t)n);
+    return (int)hipGetLastError();
+}
+int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_miller_prepared_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)coeffs,
+                       (uint32_t)(shared ? 0 : NCOEFF * COEFF_WORDS), (uint32_t *)f, (uint32_t)n);
+    return (int)hipGetLastError();
+}
 int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(bn254_gt_mul_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, (uint32_t)n);

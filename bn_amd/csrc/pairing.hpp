@@ -124,6 +124,45 @@ BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q) {
     return miller_loop(p, q, st);
 }
 
+// ---- prepared-G2 mode (the reference's internal G2Precomp: groups/mod.rs:472-483, precompute :557-588, miller_loop :486-519)
+// precompute_lines: the 102 line coefficients of an affine Q, in schedule order, handed to `sink(index, line)`.
+template <class F2, class Sink>
+BN_FN void precompute_lines(const G2Aff<F2> &q, Sink &sink) {
+    G2Proj<F2> r = {q.x, q.y, f2_one(F2P)};
+    G2Aff<F2> base = q;
+    int idx = 0;
+#pragma unroll 1
+    for (int j = 0; j < 66; ++j) {
+        const bool tail = j >= 64;
+        const bool bit = tail ? true : (((k::ATE_LOOP_LOW64 >> (63 - (j & 63))) & 1) != 0);
+        if (j == 64) base = mul_by_q(base);
+        if (j == 65) { base = mul_by_q(base); base.y = f2_neg(base.y); }
+#pragma unroll 1
+        for (int pass = tail ? 1 : 0; pass < (bit ? 2 : 1); ++pass) {
+            Line<F2> l = pass == 0 ? doubling_step(r) : addition_step(r, base);
+            sink(idx++, l);
+        }
+    }
+}
+// miller_loop over stored coefficients: `source(index)` returns line `index` (all three members in standard form)
+template <class F2, class S, class Source>
+BN_FN Fq12<F2> miller_loop_prepared(const G1Aff<S> &p, Source &source) {
+    Fq12<F2> f = f12_one<F2>();
+    int idx = 0;
+#pragma unroll 1
+    for (int j = 0; j < 66; ++j) {
+        const bool tail = j >= 64;
+        const bool bit = tail ? true : (((k::ATE_LOOP_LOW64 >> (63 - (j & 63))) & 1) != 0);
+#pragma unroll 1
+        for (int pass = tail ? 1 : 0; pass < (bit ? 2 : 1); ++pass) {
+            if (pass == 0) f = f12_sqr(f);
+            Line<F2> l = source(idx++);
+            f = apply_line(f, l, p);
+        }
+    }
+    return f;
+}
+
 // fq12.rs:229-246 + 97-101: f^u, then conjugate.  The reference walks the 63 bits of u (62 cyclotomic squarings, 27
 // multiplications).  On the cyclotomic subgroup f^-1 = conj(f) is free, so the same group element is reached through the
 // non-adjacent form of u (weight 24: 23 multiplications); the value - and therefore every output byte - is identical.

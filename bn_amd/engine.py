@@ -77,6 +77,24 @@ class Engine:
         _native.check(self._lib.bn254_g2_mul_batch(self._h, _p(p), _p(k), _p(out), p.shape[0]))
         return out
 
+    def g2_precompute(self, q):
+        """(n,24) G2 -> (n,102,24) line coefficients [ell_0 | ell_vw | ell_vv] (groups/mod.rs:557-588)"""
+        q = _arr(q, G2_WORDS)
+        out = np.empty((q.shape[0], 102, 24), np.uint64)
+        _native.check(self._lib.bn254_g2_precompute(self._h, _p(q), _p(out), q.shape[0]))
+        return out
+
+    def pairing_prepared_batch(self, p, coeffs):
+        """coeffs (102,24): shared by all p;  (n,102,24): one prepared point per p"""
+        p = _arr(p, G1_WORDS)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        shared = coeffs.ndim == 2
+        if coeffs.shape[-2:] != (102, 24) or (not shared and coeffs.shape[0] != p.shape[0]):
+            raise ValueError("coeffs must be (102,24) or (n,102,24)")
+        out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        _native.check(self._lib.bn254_pairing_prepared_batch(self._h, _p(p), _p(coeffs), 1 if shared else 0, _p(out), p.shape[0]))
+        return out
+
     def gt_mul_batch(self, a, b):
         a = _arr(a, GT_WORDS); b = _arr(b, GT_WORDS)
         out = np.empty_like(a)

@@ -18,6 +18,8 @@
  *   bn254_pairing_product  fold(Gt::one(), |acc,(p,q)| acc * pairing(p,q))          shootout/main.rs:11-16, lib.rs:175-179
  *   bn254_g1_mul_batch     out[i] = normalize(p[i] * k[i])                          lib.rs:116-120,88-95, groups/mod.rs:250-270
  *   bn254_g2_mul_batch     same over G2                                             lib.rs:159-163,131-138
+ *   bn254_g2_precompute    coeffs[i][0..102) = q[i].to_affine().precompute().coeffs   groups/mod.rs:557-588 (Q != infinity)
+ *   bn254_pairing_prepared_batch  out[i] = final_exponentiation(prepared.miller_loop(p[i]))   groups/mod.rs:486-519,768
  *   bn254_gt_mul_batch     out[i] = a[i] * b[i]                                     lib.rs:175-179, fields/fq12.rs:295-307
  *   bn254_gt_pow_batch     out[i] = a[i].pow(k[i])                                  lib.rs:171, fields/mod.rs:35-46
  * Outputs are bit-identical to the reference's on the same inputs (pairing values are canonical field elements; scalar
@@ -49,6 +51,11 @@ typedef struct { uint64_t x[4], y[4], z[4]; } bn_g1;        /* 96 B  */
 typedef struct { uint64_t x[8], y[8], z[8]; } bn_g2;        /* 192 B: each coordinate = (c0[4], c1[4]) */
 typedef struct { uint64_t c[48]; } bn_gt;                   /* 384 B: c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1 */
 
+/* one line-function coefficient of a prepared G2 point: the reference's EllCoeffs {ell_0, ell_vw, ell_vv: Fq2}
+   (groups/mod.rs:472-476); a prepared point is 102 of them in schedule order (G2Precomp.coeffs, groups/mod.rs:478-483) */
+typedef struct { uint64_t ell_0[8], ell_vw[8], ell_vv[8]; } bn_ell_coeffs;   /* 192 B */
+#define BN254_PREPARED_COEFFS 102
+
 typedef struct bn254_ctx bn254_ctx;
 
 enum {
@@ -73,6 +80,10 @@ int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *o
 int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out);
 int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n);
 int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n);
+/* prepared-G2 mode: precompute once per Q (must not be infinity), then pair many P against it.  `shared` != 0: ONE coefficient
+   set (102 entries) is used for every p[i]; otherwise coeffs holds n sets, set i for p[i]. */
+int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, size_t n);
+int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_coeffs *coeffs, int shared, bn_gt *out, size_t n);
 int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n);
 int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n);
 
@@ -86,6 +97,8 @@ int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream);
 /* local part of a sharded multi-pairing: un-exponentiated product of the Miller values of n pairs -> one Fq12 */
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream);
+int bn254_g2_precompute_dev(bn254_ctx *ctx, const void *d_q, void *d_coeffs, size_t n, void *stream);
+int bn254_miller_prepared_dev(bn254_ctx *ctx, const void *d_p, const void *d_coeffs, int shared, void *d_f, size_t n, void *stream);
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
 int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream);
 int bn254_g1_mul_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
@@ -100,7 +113,7 @@ int bn254_g2_mul_jacobian_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, 
    accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
 int bn254_profile_enable(bn254_ctx *ctx, int on);
 int bn254_profile_reset(bn254_ctx *ctx);
-/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul", "gt_mul", "gt_pow".  Synchronises the recorded events. */
+/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared".  Synchronises the recorded events. */
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 
 #ifdef __cplusplus

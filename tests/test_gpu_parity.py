@@ -220,3 +220,28 @@ def test_gt_mul_and_pow_match_oracle(oracle, eng):
     assert a == bn_amd.pairing(p * sc, q) == bn_amd.pairing(p, q * sc)
     assert a != bn_amd.Gt.one()
     assert a.pow(-bn_amd.Fr.one()) * a == bn_amd.Gt.one()
+
+
+def test_prepared_g2_mode(oracle, kats, eng):
+    """groups/mod.rs:637-762 (test_prepared_g2): all 102 line coefficients computed ON THE GPU equal the reference's known
+    answers; then pairing through the prepared coefficients (shared and per-pair) equals pairing()"""
+    k2 = oracle.fp_from_decimal(FR, kats["test_prepared_g2"]["k2"])
+    Q = oracle.g2_mul(oracle.g2_one(), k2)
+    co = eng.g2_precompute(Q)[0]
+    assert co.shape == (102, 24)
+    for got, exp in zip(co, kats["test_prepared_g2"]["coeffs"]):
+        for slot, name in enumerate(("ell_0", "ell_vw", "ell_vv")):
+            assert [oracle.fp_to_int(FQ, got[8 * slot + 4 * i:8 * slot + 4 * i + 4]) for i in range(2)] == [int(x) for x in exp[name]]
+    rng = np.random.default_rng(109)
+    n = 37
+    P, Qs = _points(oracle, rng, n)
+    P[4] = oracle.g1_zero()
+    # shared Q
+    got = eng.pairing_prepared_batch(P, co)
+    want = oracle.pairing_batch(P, np.tile(Q, (n, 1)))
+    assert np.array_equal(got, want)
+    # one prepared point per pair; coefficients equal the oracle's precompute
+    cos = eng.g2_precompute(Qs)
+    for i in (0, n - 1):
+        assert np.array_equal(cos[i].reshape(102, 3, 8), oracle.g2_precompute(oracle.g2_to_affine(Qs[i])))
+    assert np.array_equal(eng.pairing_prepared_batch(P, cos), oracle.pairing_batch(P, Qs))
