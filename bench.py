@@ -84,6 +84,35 @@ def bench_g1mul(args, eng, dev, world, rank, local_rank):
         dist.destroy_process_group()
 
 
+def bench_prepared(args, eng, dev, world, rank, local_rank):
+    """side metric: prepared-G2 mode - 2^16 pairings of random P against ONE precomputed Q per GPU per step"""
+    import torch
+    from bn_amd import distributed as D
+    n = args.batch
+    P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
+    coeffs = eng.empty(102, 24)
+    eng.e.g2_precompute_dev(Q.data_ptr(), coeffs.data_ptr(), 1, eng._stream())
+    out = eng.empty(n, 48)
+    def step():
+        eng.e.miller_prepared_dev(P.data_ptr(), coeffs.data_ptr(), True, out.data_ptr(), n, eng._stream())
+        eng.e.final_exp_batch_dev(out.data_ptr(), out.data_ptr(), n, eng._stream())
+    for _ in range(args.warmup):
+        step()
+    eng.e.profile(True); eng.e.profile_reset()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        st = {k: eng.e.kernel_stats(k) for k in ("miller_prepared", "final_exp")}
+        print(json.dumps({"metric": "BN254 pairings/sec against one prepared G2 point (bit-exact vs ref)", "value": world * n * args.steps / elapsed,
+                          "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "data": "synthetic", "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in st.items()},
+                          "config": {"workload": f"{n} random P against one precomputed Q (102 x 192 B coefficients shared by all lanes)"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,7 +121,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="pairings per GPU per step")
     ap.add_argument("--mapping", type=int, default=None, help="0: one lane per pairing, 1: lane pair per pairing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["pairing", "g1mul"], default="pairing",
+    ap.add_argument("--workload", choices=["pairing", "g1mul", "prepared"], default="pairing",
                     help="pairing: the headline metric (default); g1mul: BASELINE.json configs[4], 2^20 G1 scalar muls (side metric)")
     args = ap.parse_args()
 
@@ -118,6 +147,8 @@ def main():
     eng = D.TorchEngine(bn_amd.Engine(local_rank, mapping=args.mapping), dev)
     if args.workload == "g1mul":
         return bench_g1mul(args, eng, dev, world, rank, local_rank)
+    if args.workload == "prepared":
+        return bench_prepared(args, eng, dev, world, rank, local_rank)
     n = args.batch
     lo = rank * n
     P, Q = D.synthetic_points(eng, lo, lo + n)              # untimed: inputs resident in HBM before the clock starts

@@ -123,6 +123,12 @@ class Engine:
     def miller_product_dev(self, d_p, d_q, n, d_partial, stream=0):
         _native.check(self._lib.bn254_miller_product_dev(self._h, d_p, d_q, n, d_partial, stream))
 
+    def g2_precompute_dev(self, d_q, d_coeffs, n, stream=0):
+        _native.check(self._lib.bn254_g2_precompute_dev(self._h, d_q, d_coeffs, n, stream))
+
+    def miller_prepared_dev(self, d_p, d_coeffs, shared, d_f, n, stream=0):
+        _native.check(self._lib.bn254_miller_prepared_dev(self._h, d_p, d_coeffs, 1 if shared else 0, d_f, n, stream))
+
     def g1_mul_dev(self, d_p, d_k, d_out, n, stream=0, normalize=True):
         f = self._lib.bn254_g1_mul_batch_dev if normalize else self._lib.bn254_g1_mul_jacobian_dev
         _native.check(f(self._h, d_p, d_k, d_out, n, stream))
