@@ -84,6 +84,37 @@ def bench_g1mul(args, eng, dev, world, rank, local_rank):
         dist.destroy_process_group()
 
 
+def bench_product(args, eng, dev, world, rank, local_rank):
+    """side metric: BASELINE.json configs[3] - multi-pairing product of 2^15 pairs per GPU -> ONE Gt; the only workload with an
+    exchange step: one RCCL all-gather of 384 B per rank, then world-1 Fq12 products and a single final exponentiation"""
+    import torch
+    import torch.distributed as dist
+    from bn_amd import distributed as D
+    n = 1 << 15
+    P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
+    for _ in range(args.warmup):
+        gt = D.pairing_product_sharded(eng, P, Q)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank]); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gt = D.pairing_product_sharded(eng, P, Q)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank]); torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "BN254 pairs/sec folded into one multi-pairing product (bit-exact vs ref)", "value": world * n * args.steps / elapsed,
+                          "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "data": "synthetic",
+                          "config": {"workload": f"product of {n} pairs per GPU -> 1 Gt (BASELINE.json configs[3]); all_gather of 384 B per rank"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_prepared(args, eng, dev, world, rank, local_rank):
     """side metric: prepared-G2 mode - 2^16 pairings of random P against ONE precomputed Q per GPU per step"""
     import torch
@@ -121,7 +152,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="pairings per GPU per step")
     ap.add_argument("--mapping", type=int, default=None, help="0: one lane per pairing, 1: lane pair per pairing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["pairing", "g1mul", "prepared"], default="pairing",
+    ap.add_argument("--workload", choices=["pairing", "g1mul", "prepared", "product"], default="pairing",
                     help="pairing: the headline metric (default); g1mul: BASELINE.json configs[4], 2^20 G1 scalar muls (side metric)")
     args = ap.parse_args()
 
@@ -149,6 +180,8 @@ def main():
         return bench_g1mul(args, eng, dev, world, rank, local_rank)
     if args.workload == "prepared":
         return bench_prepared(args, eng, dev, world, rank, local_rank)
+    if args.workload == "product":
+        return bench_product(args, eng, dev, world, rank, local_rank)
     n = args.batch
     lo = rank * n
     P, Q = D.synthetic_points(eng, lo, lo + n)              # untimed: inputs resident in HBM before the clock starts

@@ -120,6 +120,7 @@ extern "C" int bn254_launch_miller_B(const void *p, const void *q, void *f, size
 extern "C" int bn254_launch_final_exp_B(const void *f, void *out, size_t n, hipStream_t s);
 extern "C" int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
 extern "C" int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
+extern "C" int bn254_launch_gt_product_B(const void *in, void *out, size_t n, unsigned chunk, hipStream_t s);
 extern "C" int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
 extern "C" int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hipStream_t s);
 
@@ -187,9 +188,9 @@ int launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream
     hipLaunchKernelGGL(bn254_final_exp_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
-// reduces n Fq12 values at `in` to one at `out` using ping-pong space `tmp` (>= 2 * ceil(n/64) * 384 B)
+// reduces n Fq12 values at `in` to one at `out` using ping-pong space `tmp` (>= 2 * ceil(n/4) * 384 B)
 int launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s) {
-    const uint32_t chunk = 64;
+    const uint32_t chunk = 4;
     const uint32_t *src = (const uint32_t *)in;
     size_t level_cap = (n + chunk - 1) / chunk;
     uint32_t *bufA = (uint32_t *)tmp, *bufB = (uint32_t *)tmp + 96 * level_cap;
@@ -197,18 +198,23 @@ int launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp,
     while (true) {
         size_t m = (n + chunk - 1) / chunk;
         uint32_t *dst = (m == 1) ? (uint32_t *)out : (useA ? bufA : bufB);
+        int rc;
         {
             Scope sc(c, s, "gt_product");
-            hipLaunchKernelGGL(bn254_gt_product_A, dim3(grid_for(m)), dim3(BLOCK), 0, s, src, dst, (uint32_t)n, chunk);
+            if (c->mapping == 1) {
+                rc = bn254_launch_gt_product_B(src, dst, n, chunk, s);
+            } else {
+                hipLaunchKernelGGL(bn254_gt_product_A, dim3(grid_for(m)), dim3(BLOCK), 0, s, src, dst, (uint32_t)n, chunk);
+                rc = (int)hipGetLastError();
+            }
         }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
+        if (rc) return rc;
         if (m == 1) break;
         src = dst; n = m; useA = !useA;
     }
     return BN254_OK;
 }
-size_t product_tmp_bytes(size_t n) { return 2 * ((n + 63) / 64) * 384 + 384; }
+size_t product_tmp_bytes(size_t n) { return 2 * ((n + 3) / 4) * 384 + 384; }
 
 }  // namespace
 
