@@ -130,6 +130,8 @@ struct bn254_ctx {
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
     void *ws = nullptr;                 // workspace (Miller values, product-tree levels)
     size_t ws_bytes = 0;
+    void *stage[3] = {nullptr, nullptr, nullptr};   // device staging of the host-buffer entry points (grow-only, reused)
+    size_t stage_bytes[3] = {0, 0, 0};
     bool profile = false;
     struct Rec { std::string name; hipEvent_t a, b; };
     std::vector<Rec> recs;
@@ -242,6 +244,7 @@ void bn254_ctx_destroy(bn254_ctx *c) {
     hipSetDevice(c->device);
     for (auto &r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->ws) hipFree(c->ws);
+    for (int i = 0; i < 3; ++i) if (c->stage[i]) hipFree(c->stage[i]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -360,10 +363,20 @@ int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, voi
 
 // ---------------------------------------------------------------------------------------------- host-buffer API
 namespace {
+// a slot of the context's staging memory: allocated once, grown when a larger batch arrives, freed with the context
 struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? BN254_OK : BN254_E_ALLOC; }
+    bn254_ctx *c; int slot; void *p = nullptr;
+    DevBuf(bn254_ctx *c_, int slot_) : c(c_), slot(slot_) {}
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 1;
+        if (c->stage_bytes[slot] < bytes) {
+            if (c->stage[slot]) { hipFree(c->stage[slot]); c->stage[slot] = nullptr; c->stage_bytes[slot] = 0; }
+            if (hipMalloc(&c->stage[slot], bytes) != hipSuccess) return BN254_E_ALLOC;
+            c->stage_bytes[slot] = bytes;
+        }
+        p = c->stage[slot];
+        return BN254_OK;
+    }
 };
 }
 int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
@@ -371,7 +384,7 @@ int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *o
     if (n == 0) return BN254_OK;
     if (!p || !q || !out) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dp, dq, dout;
+    DevBuf dp(ctx, 0), dq(ctx, 1), dout(ctx, 2);
     if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
     HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
@@ -384,7 +397,7 @@ int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t
     int rc = get_ctx(ctx); if (rc) return rc;
     if (!out || (n && (!p || !q))) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dp, dq, dpart;
+    DevBuf dp(ctx, 0), dq(ctx, 1), dpart(ctx, 2);
     if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dpart.alloc(sizeof(bn_gt)))) return rc;
     if (n) {
         HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
@@ -403,7 +416,7 @@ static int mul_host(bn254_ctx *ctx, int g, const void *p, const bn_fr *k, void *
     if (!p || !k || !out) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
-    DevBuf dp, dk, dout;
+    DevBuf dp(ctx, 0), dk(ctx, 1), dout(ctx, 2);
     if ((rc = dp.alloc(n * ps)) || (rc = dk.alloc(n * sizeof(bn_fr))) || (rc = dout.alloc(n * ps))) return rc;
     HIP_TRY(hipMemcpyAsync(dp.p, p, n * ps, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dk.p, k, n * sizeof(bn_fr), hipMemcpyHostToDevice, ctx->stream));
@@ -417,7 +430,7 @@ int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, s
     if (n == 0) return BN254_OK;
     if (!q || !coeffs) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dq, dc;
+    DevBuf dq(ctx, 0), dc(ctx, 1);
     size_t cb = n * 102 * sizeof(bn_ell_coeffs);
     if ((rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dc.alloc(cb))) return rc;
     HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
@@ -431,7 +444,7 @@ int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_co
     if (n == 0) return BN254_OK;
     if (!p || !coeffs || !out) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dp, dc, dout;
+    DevBuf dp(ctx, 0), dc(ctx, 1), dout(ctx, 2);
     size_t cb = (shared ? 1 : n) * 102 * sizeof(bn_ell_coeffs);
     if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dc.alloc(cb)) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
     HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
@@ -447,7 +460,7 @@ static int gt_binop_host(bn254_ctx *ctx, int op, const bn_gt *a, const void *b, 
     if (n == 0) return BN254_OK;
     if (!a || !b || !out) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf da, db, dout;
+    DevBuf da(ctx, 0), db(ctx, 1), dout(ctx, 2);
     if ((rc = da.alloc(n * sizeof(bn_gt))) || (rc = db.alloc(n * bsize)) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
     HIP_TRY(hipMemcpyAsync(da.p, a, n * sizeof(bn_gt), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(db.p, b, n * bsize, hipMemcpyHostToDevice, ctx->stream));

@@ -19,4 +19,4 @@ for _ in range(reps):
     out = e.pairing_batch(Pn, Qn)
 dt = (time.perf_counter() - t0) / reps
 print(f"bn254_pairing_batch host buffers, n = {n}: {dt*1e3:.2f} ms per call = {n/dt/1e6:.3f} M pairings/s "
-      f"(H2D {n*288/1e6:.1f} MB + hipMalloc/hipFree + kernels + D2H {n*384/1e6:.1f} MB, pageable memory)")
+      f"(H2D {n*288/1e6:.1f} MB + kernels + D2H {n*384/1e6:.1f} MB, pageable host memory, context-owned staging buffers)")
