@@ -7,6 +7,9 @@
 // This translation unit is compiled with the Fq6/Fq12-sized steps INLINED (BN_COARSE), so that values stay in VGPRs across
 // them; only the multiplier-sized leaves and the rarely executed outer steps are calls.
 #define BN_COARSE __device__ __forceinline__
+#ifndef BN_WAVES
+#define BN_WAVES 2          // resident waves per SIMD the kernels are compiled for (256 VGPRs each)
+#endif
 #ifdef BN_B_INLINE_REDUCTIONS
 #define BN_INLINE_REDUCTIONS 1
 #endif
@@ -43,7 +46,7 @@ struct MillerStateLds {
     __device__ __forceinline__ G1Aff<Fe> get_p() const { return {ld_fe(5), ld_fe(6)}; }
 };
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_miller_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -63,7 +66,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
     if (live) f12_store(f, f_out + 96u * pair);
 }
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 // ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
 constexpr int NCOEFF = 102, COEFF_WORDS = 48;
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_precompute_B(const uint32_t *g2, uint32_t *coeffs, uint32_t n) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_g2_precompute_B(const uint32_t *g2, uint32_t *coeffs, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -90,7 +93,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
     precompute_lines(q, sink);
 }
 // f[i] = miller_loop(coeffs, P[i])  (groups/mod.rs:486-519); coeff_stride = 0 shares one coefficient set among all P
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_miller_prepared_B(const uint32_t *g1, const uint32_t *coeffs, uint32_t coeff_stride, uint32_t *f_out, uint32_t n) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_prepared_B(const uint32_t *g1, const uint32_t *coeffs, uint32_t coeff_stride, uint32_t *f_out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
 
 // out[t] = product of in[t*chunk .. min(n, (t+1)*chunk))   (product tree of the multi-pairing; chunk is small so that every
 // level keeps many lane pairs busy: 2^15 values -> 1 in 8 levels of 3 multiplications instead of 3 levels of 63)
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_gt_product_B(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t chunk) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_product_B(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t chunk) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     uint32_t groups = (n + chunk - 1) / chunk;
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 // out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 // out[i] = a[i] ^ k[i]   (Gt::pow, lib.rs:171 -> fields/mod.rs:35-46: 256 x { res = res^2; if bit { res = a * res } } on the scalar
 // taken out of Montgomery form).  Exponent bits differ per element, so the conditional product is a per-pair select.
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
