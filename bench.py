@@ -78,7 +78,7 @@ def bench_g1mul(args, eng, dev, world, rank, local_rank):
     if rank == 0:
         print(json.dumps({"metric": "BN254 G1 scalar multiplications/sec (normalized output, bit-exact vs ref)", "value": world * n * args.steps / elapsed,
                           "unit": "scalar muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit Montgomery, exact integer)",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
                           "data": "synthetic", "config": {"workload": "2^20 G1 scalar muls by random Fr per GPU per step (BASELINE.json configs[4])"}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -222,10 +222,11 @@ def main():
         line = {
             "metric": "BN254 optimal-ate pairings/sec (bit-exact vs ref)", "value": value, "unit": "pairings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit Montgomery, exact integer)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"{n} independent pairings per GPU per step, inputs r*G1 / s*G2 (Jacobian, z != 1) resident in HBM "
                                    "(BASELINE.json configs[1])", "pairings_per_gpu": n, "parallelism": f"dp{world} (sharded, no collective)",
+                       "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
                        "mapping": args.mapping},
             "roofline": {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": achieved,
                          "peak": PEAK_TMAC32, "unit": "TMAC32/s", "frac": achieved / PEAK_TMAC32, "traffic": traffic,
