@@ -11,7 +11,7 @@
 // Representation invariants (tracked and ENFORCED at run time in the host simulation build, -DBN_BOUNDS; the control flow
 // of the engine is data independent, so one simulated run exercises every bound):
 //   limb bound  lb : l[i] <= lb * (2^29 - 1)  for i < 8      (lb = 1: "normalized")
-//   value bound vb : value < vb * q                            (the top limb l[8] holds everything above 2^232)
+//   value bound vb : value <= vb * q                           (the top limb l[8] holds everything above 2^232)
 // Montgomery products return (lb, vb) = (1, 2).  Values are only made canonical (< q) when they leave the engine
 // (fe_to_u32x8), where they are converted back to the reference's radix-2^256 image, so the bytes at the C ABI are
 // exactly the reference's.
@@ -78,6 +78,40 @@ struct Fe {
     bool sg = false;      // "signed lazy": limbs are int32 in two's complement, the value may be negative (only fe_lc3 takes these)
 #endif
 };
+
+#if defined(BN_BOUNDS)
+// Host-simulation soundness check: the bounds an operation CLAIMS for its result (lb, vb, sg) are compared with the limbs it
+// actually produced, so an error in the bound analysis (not just in the arithmetic) aborts the simulated run.
+inline void bn_verify_actual(const Fe &f, const char *where) {
+    // limbs
+    for (int i = 0; i < 8; ++i) {
+        int64_t v = f.sg ? (int64_t)(int32_t)f.l[i] : (int64_t)f.l[i];
+        int64_t lim = (int64_t)f.lb * (int64_t)(MASK29);
+        if (v > lim || v < (f.sg ? -lim : 0)) { std::fprintf(stderr, "BN_BOUNDS: limb %d = %lld exceeds claimed lb %u in %s\n", i, (long long)v, f.lb, where); std::abort(); }
+    }
+    // value: normalise sum l_i 2^(29 i) into 29-bit digits with a signed carry
+    int64_t d[10]; int64_t c = 0;
+    for (int i = 0; i < 9; ++i) { int64_t t = (f.sg ? (int64_t)(int32_t)f.l[i] : (int64_t)f.l[i]) + c; if (i < 8) { d[i] = t & MASK29; c = t >> 29; } else { d[8] = t; } }
+    bool neg = d[8] < 0;
+    if (neg && !f.sg) { std::fprintf(stderr, "BN_BOUNDS: negative value in an unsigned form in %s\n", where); std::abort(); }
+    if (neg) {          // magnitude: negate the digit string
+        int64_t b = 0;
+        for (int i = 0; i < 8; ++i) { int64_t t = -d[i] + b; d[i] = t & MASK29; b = t >> 29; }
+        d[8] = -d[8] + b;
+    }
+    // compare with vb * q
+    int64_t q[9]; uint64_t cy = 0;
+    for (int i = 0; i < 9; ++i) { uint64_t t = (uint64_t)k::Q[i] * f.vb + cy; if (i < 8) { q[i] = (int64_t)(t & MASK29); cy = t >> 29; } else { q[8] = (int64_t)t; } }
+    for (int i = 8; i >= 0; --i) {
+        if (d[i] < q[i]) return;
+        if (d[i] > q[i]) { std::fprintf(stderr, "BN_BOUNDS: |value| exceeds claimed vb %u (x q) in %s\n", f.vb, where); std::abort(); }
+    }
+    // |value| == vb*q exactly is allowed (e.g. K*q - 0): every bound argument in this file holds with <= as well
+}
+#define BN_VERIFY(x, where) bn_verify_actual((x), where)
+#else
+#define BN_VERIFY(x, where) ((void)0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Leaf calling convention.  A struct argument larger than the 16 registers clang's AMDGPU ABI grants to ALL aggregate
@@ -172,6 +206,7 @@ BN_FN Fe fe_add(const Fe &a, const Fe &b) {
     BN_IFB(bool sg_ = a.sg || b.sg;)
     BN_SETB(r, a.lb + b.lb, a.vb + b.vb);
     BN_IFB(r.sg = sg_;)
+    BN_VERIFY(r, "fe_add");
     return r;
 }
 BN_FN Fe fe_dbl(const Fe &a) { return fe_add(a, a); }
@@ -186,6 +221,7 @@ BN_FN Fe fe_ssub(const Fe &a, const Fe &b) {
     for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i];
     BN_SETB(r, a.lb + b.lb, a.vb + b.vb);
     BN_IFB(r.sg = true;)
+    BN_VERIFY(r, "fe_ssub");
     return r;
 }
 
@@ -203,6 +239,7 @@ BN_FN Fe fe_sub(const Fe &a, const Fe &b) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + B.c[i] - b.l[i];
     BN_SETB(r, a.lb + LB + 1, a.vb + K);
+    BN_VERIFY(r, "fe_sub");
     return r;
 }
 template <int LB, int K>
@@ -216,6 +253,7 @@ BN_FN Fe fe_neg(const Fe &b) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = B.c[i] - b.l[i];
     BN_SETB(r, LB + 1, K);
+    BN_VERIFY(r, "fe_neg");
     return r;
 }
 
@@ -233,6 +271,7 @@ BN_FN Fe fe_norm(const Fe &a) {
     }
     r.l[8] = a.l[8] + c;
     BN_SETB(r, 1, a.vb);
+    BN_VERIFY(r, "fe_norm");
     return r;
 }
 
@@ -254,6 +293,7 @@ BN_FN Fe fe_reduce(const Fe &a) {
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
     BN_SETB(r, 1, 2);
+    BN_VERIFY(r, "fe_reduce");
     return r;
 }
 
@@ -305,6 +345,7 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
     BN_SETB(r, 1, 3);
+    BN_VERIFY(r, "fe_lc4_core");
     return r;
 }
 template <int C1, int C2, int C3>
@@ -333,6 +374,7 @@ BN_FN Fe fe_lc3w_body(const Fe &x, const Fe &y, const Fe &z) {
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
     BN_SETB(r, 1, 3);
+    BN_VERIFY(r, "fe_lc3w_body");
     return r;
 }
 BN_LEAF3T(fe_lc3w, fe_lc3w_body)
@@ -375,6 +417,7 @@ BN_FN Fe fe_mul_body(const Fe &a, const Fe &b) {
     }
     r.l[8] = (uint32_t)acc;
     BN_SETB(r, 1, 2);
+    BN_VERIFY(r, "fe_mul_body");
     return r;
 }
 BN_LEAF2(fe_mul, fe_mul_body)
@@ -416,6 +459,7 @@ BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
     }
     r.l[8] = (uint32_t)acc;
     BN_SETB(r, 1, 2);
+    BN_VERIFY(r, "fe_mul2");
     return r;
 }
 
@@ -460,6 +504,7 @@ BN_FN Fe fe_canonical(const Fe &t) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = borrow ? t.l[i] : d.l[i];
     BN_SETB(r, 1, 1);
+    BN_VERIFY(r, "fe_canonical");
     return r;
 }
 // internal -> reference image, exact (this is where "bit-exact vs the reference" is decided)

@@ -174,3 +174,17 @@ def test_scalar_mul_reference_chain(oracle, hs):
             assert np.array_equal(hs.call(fn, base, k, 0, out_words=2 * w), want)
             assert np.array_equal(hs.call(fn, base, k, 1, out_words=2 * w), canon_infinity(on(want)))
             assert np.array_equal(hs.call(fn, base, k, 2, out_words=2 * w), canon_infinity(on(want)))   # windowed algorithm, normalized
+
+
+def test_many_random_pairings_with_bound_verification(oracle, hs):
+    """200 random pairings through BOTH lane mappings of the device code on the CPU, every operation checked against its claimed
+    limb/value bounds (actual limbs, not just worst cases) and every result against the oracle"""
+    rng = np.random.default_rng(19)
+    n = 100
+    k1 = np.stack([_fr(oracle, rng) for _ in range(n)]); k2 = np.stack([_fr(oracle, rng) for _ in range(n)])
+    P = oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (n, 1)), k1, 1)
+    Q = oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (n, 1)), k2, 1)
+    want = oracle.pairing_batch(P, Q, 1)
+    for i in range(n):
+        assert np.array_equal(hs.call("hs_pairing", P[i], Q[i], out_words=96), want[i])
+        assert np.array_equal(hs.call("hsb_pairing", P[i], Q[i], out_words=96), want[i])
