@@ -33,19 +33,24 @@ template <class F2> BN_FN Fq6<F2> f6_neg(const Fq6<F2> &a) { return f6_lc3<-1, 0
 // v * x   (fq6.rs:59-65)
 template <class F2> BN_FN Fq6<F2> f6_mul_by_v(const Fq6<F2> &a) { return {f2_mul_xi(a.c2), a.c0, a.c1}; }
 
-// fq6.rs:144-158: 6 Fq2 products (Karatsuba), the two xi-multiplications folded into the final reductions
+// fq6.rs:144-158: 6 Fq2 products (Karatsuba), the two xi-multiplications folded into the final reductions; each output
+// coefficient is finished as soon as its products exist (short live ranges: see f12_mul_by_024)
 template <class F2>
 BN_COARSE Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
     F2 aa = f2_mul(a.c0, b.c0), bb = f2_mul(a.c1, b.c1), cc = f2_mul(a.c2, b.c2);
-    F2 t0 = f2_mul(f2_add(a.c1, a.c2), f2_norm(f2_add(b.c1, b.c2)));
-    F2 t1 = f2_mul(f2_add(a.c0, a.c1), f2_norm(f2_add(b.c0, b.c1)));
-    F2 t2 = f2_mul(f2_add(a.c0, a.c2), f2_norm(f2_add(b.c0, b.c2)));
-    F2 x0 = f2_ssub(f2_ssub(t0, bb), cc);            // a1 b2 + a2 b1, lazy
-    F2 y1 = f2_ssub(f2_ssub(t1, aa), bb);            // a0 b1 + a1 b0, lazy
     Fq6<F2> r;
-    r.c0 = f2_lc_xi<1, 1>(x0, aa);
-    r.c1 = f2_lc_xi<1, 1>(cc, y1);
-    r.c2 = f2_lc3<1, -1, -1>(f2_add(t2, bb), aa, cc);
+    {
+        F2 t0 = f2_mul(f2_add(a.c1, a.c2), f2_norm(f2_add(b.c1, b.c2)));
+        r.c0 = f2_lc_xi<1, 1>(f2_ssub(f2_ssub(t0, bb), cc), aa);          // xi (a1 b2 + a2 b1) + a0 b0
+    }
+    {
+        F2 t1 = f2_mul(f2_add(a.c0, a.c1), f2_norm(f2_add(b.c0, b.c1)));
+        r.c1 = f2_lc_xi<1, 1>(cc, f2_ssub(f2_ssub(t1, aa), bb));          // xi a2 b2 + a0 b1 + a1 b0
+    }
+    {
+        F2 t2 = f2_mul(f2_add(a.c0, a.c2), f2_norm(f2_add(b.c0, b.c2)));
+        r.c2 = f2_lc3<1, -1, -1>(f2_add(t2, bb), aa, cc);                // a0 b2 + a2 b0 + a1 b1
+    }
     return r;
 }
 // fq6.rs:113-127 (CH-SQR2)
@@ -84,18 +89,30 @@ BN_OUTER Fq6<F2> f6_inverse(const Fq6<F2> &a) {
 
 // ------------------------------------------------------------------------------------------------------------- Fq12
 template <class F2> BN_FN Fq12<F2> f12_one() { return {f6_one<F2>(), f6_zero<F2>()}; }
-// fq12.rs:295-307
+// fq12.rs:295-307.  `b` is read through a source object (b.c0(), b.c1() hand out its halves on demand) so that a multiplier
+// that stays constant across a loop can live in LDS instead of 54 VGPRs; `conj_b` multiplies by the conjugate (c0, -c1).
 template <class F2>
-BN_COARSE Fq12<F2> f12_mul(const Fq12<F2> &a, const Fq12<F2> &b) {
-    Fq6<F2> aa = f6_mul(a.c0, b.c0), bb = f6_mul(a.c1, b.c1);
-    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add(b.c0, b.c1));
+struct Fq12Ref {
+    const Fq12<F2> &x;
+    BN_FN Fq6<F2> c0() const { return x.c0; }
+    BN_FN Fq6<F2> c1() const { return x.c1; }
+};
+template <class F2, class BSrc>
+BN_FN Fq12<F2> f12_mul_src(const Fq12<F2> &a, const BSrc &b, bool conj_b) {
+    Fq6<F2> aa = f6_mul(a.c0, b.c0());
+    Fq6<F2> b1 = b.c1();
+    if (conj_b) b1 = f6_neg(b1);
+    Fq6<F2> bb = f6_mul(a.c1, b1);
     Fq12<F2> r;
     r.c0.c0 = f2_lc_xi<1, 1>(bb.c2, aa.c0);                  // aa + v*bb
     r.c0.c1 = f2_lc3<1, 1, 0>(aa.c1, bb.c0, bb.c0);
     r.c0.c2 = f2_lc3<1, 1, 0>(aa.c2, bb.c1, bb.c1);
+    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add(b.c0(), b1));
     r.c1 = f6_lc3<1, -1, -1>(t, aa, bb);
     return r;
 }
+template <class F2>
+BN_COARSE Fq12<F2> f12_mul(const Fq12<F2> &a, const Fq12<F2> &b) { return f12_mul_src(a, Fq12Ref<F2>{b}, false); }
 // fq12.rs:275-282 (complex squaring over Fq6)
 template <class F2>
 BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
@@ -134,33 +151,44 @@ BN_OUTER Fq12<F2> f12_frobenius(const Fq12<F2> &a) {
     return {f6_frobenius<P>(a.c0), f6_scale(c1, g)};
 }
 
-// fq12.rs:107-176: f * (x0 + x2 v^2 + x4 v w), 13 Fq2 products; (ell_0, ell_vw, ell_vv) -> (x0, x4, x2) as in the reference
+// fq12.rs:107-176: f * (x0 + x2 v^2 + x4 v w), 13 Fq2 products; (ell_0, ell_vw, ell_vv) -> (x0, x4, x2) as in the reference.
+// Same 13 products and the same sums as the reference, but ordered so that every product dies as early as possible (each
+// output coefficient is finished as soon as its inputs exist): the live set stays inside the 256-VGPR budget of a wave that
+// shares its SIMD, instead of parking a dozen 9-register products in private memory.
 template <class F2>
 BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &ell_vw, const F2 &ell_vv) {
     const F2 &z0 = f.c0.c0, &z1 = f.c0.c1, &z2 = f.c0.c2, &z3 = f.c1.c0, &z4 = f.c1.c1, &z5 = f.c1.c2;
     const F2 &x0 = ell_0, &x2 = ell_vv, &x4 = ell_vw;
-    F2 d0 = f2_mul(z0, x0), d2 = f2_mul(z2, x2), d4 = f2_mul(z4, x4);
-    F2 z1x2 = f2_mul(z1, x2), z5x4 = f2_mul(z5, x4), z1x0 = f2_mul(z1, x0);
-    F2 z3x4 = f2_mul(z3, x4), z3x0 = f2_mul(z3, x0), z5x2 = f2_mul(z5, x2);
-    F2 x02 = f2_norm(f2_add(x0, x2)), x24 = f2_norm(f2_add(x2, x4)), x04 = f2_norm(f2_add(x0, x4));
-    F2 m02 = f2_mul(f2_add(z0, z2), x02);                   // (z0+z2)(x0+x2)
-    F2 m24 = f2_mul(f2_add(z2, z4), x24);                   // (z2+z4)(x2+x4)
-    F2 m04 = f2_mul(f2_add(z0, z4), x04);                   // (z0+z4)(x0+x4)
-    F2 s0 = f2_sum3_for_mul(z1, z3, z5), xs = f2_lc3<1, 1, 1>(x0, x2, x4);
-    F2 ms = f2_mul(s0, xs);
-    F2 s1 = f2_add(f2_add(f2_add(z1x2, z5x4), f2_add(z1x0, z3x4)), f2_add(z3x0, z5x2));      // lazy, lb 6
     Fq12<F2> r;
-    r.c0.c0 = f2_lc_xi<1, 1>(f2_add(z1x2, d4), d0);
-    r.c0.c1 = f2_lc_xi<1, 1>(f2_add(z5x4, d2), z1x0);
-    r.c0.c2 = f2_lc3<1, -1, -1>(f2_add(m02, z3x4), d0, d2);
-    r.c1.c0 = f2_lc_xi<1, 1>(f2_ssub(f2_ssub(m24, d2), d4), z3x0);
-    r.c1.c1 = f2_lc_xi<1, 1>(z5x2, f2_ssub(f2_ssub(m04, d0), d4));
-    r.c1.c2 = f2_lc3w<1, -1, 0>(ms, s1, s1);
+    F2 d0 = f2_mul(z0, x0), d4 = f2_mul(z4, x4);
+    F2 s1 = f2_mul(z1, x2);                                              // running sum of the six cross products (lazy)
+    r.c0.c0 = f2_lc_xi<1, 1>(f2_add(s1, d4), d0);                        // xi (z1 x2 + z4 x4) + z0 x0
+    F2 d2 = f2_mul(z2, x2);
+    {
+        F2 z5x4 = f2_mul(z5, x4), z1x0 = f2_mul(z1, x0);
+        r.c0.c1 = f2_lc_xi<1, 1>(f2_add(z5x4, d2), z1x0);                // xi (z5 x4 + z2 x2) + z1 x0
+        s1 = f2_add(f2_add(s1, z5x4), z1x0);
+    }
+    {
+        F2 m02 = f2_mul(f2_add(z0, z2), f2_norm(f2_add(x0, x2))), z3x4 = f2_mul(z3, x4);
+        r.c0.c2 = f2_lc3<1, -1, -1>(f2_add(m02, z3x4), d0, d2);          // (z0+z2)(x0+x2) - d0 - d2 + z3 x4
+        s1 = f2_add(s1, z3x4);
+    }
+    {
+        F2 m24 = f2_mul(f2_add(z2, z4), f2_norm(f2_add(x2, x4))), z3x0 = f2_mul(z3, x0);
+        r.c1.c0 = f2_lc_xi<1, 1>(f2_ssub(f2_ssub(m24, d2), d4), z3x0);   // xi ((z2+z4)(x2+x4) - d2 - d4) + z3 x0
+        s1 = f2_add(s1, z3x0);
+    }
+    {
+        F2 z5x2 = f2_mul(z5, x2), m04 = f2_mul(f2_add(z0, z4), f2_norm(f2_add(x0, x4)));
+        r.c1.c1 = f2_lc_xi<1, 1>(z5x2, f2_ssub(f2_ssub(m04, d0), d4));   // xi z5 x2 + (z0+z4)(x0+x4) - d0 - d4
+        s1 = f2_add(s1, z5x2);
+    }
+    F2 ms = f2_mul(f2_sum3_for_mul(z1, z3, z5), f2_lc3<1, 1, 1>(x0, x2, x4));
+    r.c1.c2 = f2_lc3w<1, -1, 0>(ms, s1, s1);                              // (z1+z3+z5)(x0+x2+x4) - s1
     return r;
 }
 
-// fq12.rs:178-227 (Granger-Scott squaring; equals f*f only on the cyclotomic subgroup - the KAT of fields/mod.rs:171-201
-// feeds it an element OFF the subgroup, so the formula itself is part of the contract)
 // one Fp4 squaring of Granger-Scott, fused with the "times three, plus/minus twice the old coefficient" that follows it:
 //   tmp = a b,  t_even = (a + b)(a + xi b) - tmp - xi tmp = a^2 + xi b^2
 //   out_even = 3 t_even - 2 z_even          (ONE reduction: 3 m - 3 tmp - 3 xi tmp - 2 z_even)
