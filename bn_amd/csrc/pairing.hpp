@@ -174,8 +174,7 @@ BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
     for (int i = k::BN_U_NAF_LEN - 2; i >= 0; --i) {
         res = f12_cyclotomic_sqr(res);
         const int d = k::BN_U_NAF[i];
-        if (d > 0) res = f12_mul(res, f);
-        if (d < 0) res = f12_mul(res, f12_conj(f));
+        if (d != 0) res = f12_mul_src(res, Fq12Ref<F2>{f}, d < 0);      // one copy of the product in the instruction stream
     }
     return f12_conj(res);
 }

@@ -204,12 +204,18 @@ template <class F2>
 BN_COARSE Fq12<F2> f12_cyclotomic_sqr(const Fq12<F2> &f) {
     const F2 &z0 = f.c0.c0, &z4 = f.c0.c1, &z3 = f.c0.c2, &z2 = f.c1.c0, &z1 = f.c1.c1, &z5 = f.c1.c2;
     Fq12<F2> r;
-    F2 p01 = f4_sq_fused(z0, z1, z0, r.c0.c0);               // z0' = 2(t0 - z0) + t0
-    F2 p23 = f4_sq_fused(z2, z3, z4, r.c0.c1);               // z4' = 2(t2 - z4) + t2
-    F2 p45 = f4_sq_fused(z4, z5, z3, r.c0.c2);               // z3' = 2(t4 - z3) + t4
-    r.c1.c1 = f2_lc3<6, 2, 0>(p01, z1, z1);                   // z1' = 2(t1 + z1) + t1,  t1 = 2 p01
-    r.c1.c0 = f2_lc_xi<6, 2>(p45, z2);                        // z2' = 2(xi t5 + z2) + xi t5
-    r.c1.c2 = f2_lc3<6, 2, 0>(p23, z5, z5);                   // z5' = 2(t3 + z5) + t3
+    {
+        F2 p01 = f4_sq_fused(z0, z1, z0, r.c0.c0);           // z0' = 2(t0 - z0) + t0
+        r.c1.c1 = f2_lc3<6, 2, 0>(p01, z1, z1);               // z1' = 2(t1 + z1) + t1,  t1 = 2 p01
+    }
+    {
+        F2 p23 = f4_sq_fused(z2, z3, z4, r.c0.c1);           // z4' = 2(t2 - z4) + t2
+        r.c1.c2 = f2_lc3<6, 2, 0>(p23, z5, z5);               // z5' = 2(t3 + z5) + t3
+    }
+    {
+        F2 p45 = f4_sq_fused(z4, z5, z3, r.c0.c2);           // z3' = 2(t4 - z3) + t4
+        r.c1.c0 = f2_lc_xi<6, 2>(p45, z2);                    // z2' = 2(xi t5 + z2) + xi t5
+    }
     return r;
 }
 
