@@ -18,6 +18,7 @@
 #include "../../include/bn254_hip.h"
 #include "curve.hpp"
 #include "io.hpp"
+#include "io_wire.hpp"
 
 using namespace bn254;
 
@@ -111,6 +112,36 @@ __global__ void __launch_bounds__(BLOCK) bn254_g2_mul_k(const uint32_t *p, const
     if (idx >= n) return;
     mul_body<Fq2Field<Fq2A>, 16>(p + 48u * idx, k + 8u * idx, out + 48u * idx, normalize,
                                  [](const uint32_t *w) { return f2_load((const Fq2A *)nullptr, w); }, [](const Fq2A &a, uint32_t *w) { f2_store(a, w); });
+}
+
+// wire format (io_wire.hpp): one record per lane; byte-granular global accesses (65/129-byte strides), not a hot path
+__global__ void __launch_bounds__(BLOCK) bn254_g1_encode_k(const uint32_t *p, uint8_t *out, uint32_t n) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    uint32_t w[24];
+    for (int i = 0; i < 24; ++i) w[i] = p[24u * idx + i];
+    g1_encode_record(w, out + 65u * idx);
+}
+__global__ void __launch_bounds__(BLOCK) bn254_g2_encode_k(const uint32_t *p, uint8_t *out, uint32_t n) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    uint32_t w[48];
+    for (int i = 0; i < 48; ++i) w[i] = p[48u * idx + i];
+    g2_encode_record(w, out + 129u * idx);
+}
+__global__ void __launch_bounds__(BLOCK) bn254_g1_decode_k(const uint8_t *in, uint32_t *out, int32_t *status, uint32_t n) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    uint8_t b[65];
+    for (int i = 0; i < 65; ++i) b[i] = in[65u * idx + i];
+    status[idx] = g1_decode_record(b, out + 24u * idx);
+}
+__global__ void __launch_bounds__(BLOCK) bn254_g2_decode_k(const uint8_t *in, uint32_t *out, int32_t *status, uint32_t n) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    uint8_t b[129];
+    for (int i = 0; i < 129; ++i) b[i] = in[129u * idx + i];
+    status[idx] = g2_decode_record(b, out + 48u * idx);
 }
 
 }  // namespace
@@ -455,6 +486,35 @@ int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_co
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;
 }
+// wire format: host buffers in, host buffers out
+static int wire_host(bn254_ctx *ctx, int g, int decode, const void *in, void *out, int32_t *status, size_t n) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!in || !out || (decode && !status) || n > 0x7fffffffu / 129) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2), rs = g == 1 ? BN254_G1_WIRE_BYTES : BN254_G2_WIRE_BYTES;
+    size_t in_b = n * (decode ? rs : ps), out_b = n * (decode ? ps : rs);
+    DevBuf din(ctx, 0), dout(ctx, 1), dst(ctx, 2);
+    if ((rc = din.alloc(in_b)) || (rc = dout.alloc(out_b)) || (rc = dst.alloc(n * sizeof(int32_t)))) return rc;
+    HIP_TRY(hipMemcpyAsync(din.p, in, in_b, hipMemcpyHostToDevice, ctx->stream));
+    {
+        Scope sc(ctx, ctx->stream, decode ? "wire_decode" : "wire_encode");
+        dim3 grid(grid_for(n)), block(BLOCK);
+        if (g == 1 && !decode) hipLaunchKernelGGL(bn254_g1_encode_k, grid, block, 0, ctx->stream, (const uint32_t *)din.p, (uint8_t *)dout.p, (uint32_t)n);
+        if (g == 2 && !decode) hipLaunchKernelGGL(bn254_g2_encode_k, grid, block, 0, ctx->stream, (const uint32_t *)din.p, (uint8_t *)dout.p, (uint32_t)n);
+        if (g == 1 && decode) hipLaunchKernelGGL(bn254_g1_decode_k, grid, block, 0, ctx->stream, (const uint8_t *)din.p, (uint32_t *)dout.p, (int32_t *)dst.p, (uint32_t)n);
+        if (g == 2 && decode) hipLaunchKernelGGL(bn254_g2_decode_k, grid, block, 0, ctx->stream, (const uint8_t *)din.p, (uint32_t *)dout.p, (int32_t *)dst.p, (uint32_t)n);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, dout.p, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (decode) HIP_TRY(hipMemcpyAsync(status, dst.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_g1_encode_batch(bn254_ctx *ctx, const bn_g1 *p, uint8_t *out, size_t n) { return wire_host(ctx, 1, 0, p, out, nullptr, n); }
+int bn254_g2_encode_batch(bn254_ctx *ctx, const bn_g2 *p, uint8_t *out, size_t n) { return wire_host(ctx, 2, 0, p, out, nullptr, n); }
+int bn254_g1_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g1 *out, int32_t *status, size_t n) { return wire_host(ctx, 1, 1, in, out, status, n); }
+int bn254_g2_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g2 *out, int32_t *status, size_t n) { return wire_host(ctx, 2, 1, in, out, status, n); }
 static int gt_binop_host(bn254_ctx *ctx, int op, const bn_gt *a, const void *b, size_t bsize, bn_gt *out, size_t n) {
     int rc = get_ctx(ctx); if (rc) return rc;
     if (n == 0) return BN254_OK;

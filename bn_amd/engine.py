@@ -95,6 +95,25 @@ class Engine:
         _native.check(self._lib.bn254_pairing_prepared_batch(self._h, _p(p), _p(coeffs), 1 if shared else 0, _p(out), p.shape[0]))
         return out
 
+    # ---- wire format (fixed-size records: G1 65 bytes, G2 129 bytes)
+    def g1_encode_batch(self, p):
+        p = _arr(p, G1_WORDS); out = np.empty((p.shape[0], 65), np.uint8)
+        _native.check(self._lib.bn254_g1_encode_batch(self._h, _p(p), _p(out), p.shape[0])); return out
+
+    def g2_encode_batch(self, p):
+        p = _arr(p, G2_WORDS); out = np.empty((p.shape[0], 129), np.uint8)
+        _native.check(self._lib.bn254_g2_encode_batch(self._h, _p(p), _p(out), p.shape[0])); return out
+
+    def g1_decode_batch(self, b):
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 65); n = b.shape[0]
+        out = np.empty((n, G1_WORDS), np.uint64); st = np.empty(n, np.int32)
+        _native.check(self._lib.bn254_g1_decode_batch(self._h, _p(b), _p(out), _p(st), n)); return out, st
+
+    def g2_decode_batch(self, b):
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 129); n = b.shape[0]
+        out = np.empty((n, G2_WORDS), np.uint64); st = np.empty(n, np.int32)
+        _native.check(self._lib.bn254_g2_decode_batch(self._h, _p(b), _p(out), _p(st), n)); return out, st
+
     def gt_mul_batch(self, a, b):
         a = _arr(a, GT_WORDS); b = _arr(b, GT_WORDS)
         out = np.empty_like(a)

@@ -87,6 +87,19 @@ int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_co
 int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n);
 int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n);
 
+/* wire format of the crate's Encodable/Decodable impls for G1/G2 (groups/mod.rs:143-205, fields/fp.rs:24-36, fields/fq2.rs:31-53,
+   arith.rs:100-159), as fixed-size batch records: [tag][x][y] with tag 4 and big-endian canonical coordinates (Fq2 = the 512-bit
+   integer c1*q + c0); infinity is tag 0 followed by zero padding (the crate's stream emits the lone byte 0).  Decoding validates
+   what the crate validates, in its order, and reports per record: 0 ok, 1 "integer is not less than modulus", 2 "integer not
+   less than modulus squared", 3 "invalid leading byte", 4 "point is not on the curve", 5 "point is not in the subgroup" (G2
+   only).  A rejected record decodes to G::zero(). */
+#define BN254_G1_WIRE_BYTES 65
+#define BN254_G2_WIRE_BYTES 129
+int bn254_g1_encode_batch(bn254_ctx *ctx, const bn_g1 *p, uint8_t *out, size_t n);
+int bn254_g2_encode_batch(bn254_ctx *ctx, const bn_g2 *p, uint8_t *out, size_t n);
+int bn254_g1_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g1 *out, int32_t *status, size_t n);
+int bn254_g2_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g2 *out, int32_t *status, size_t n);
+
 /* ---- device-resident entry points (inputs/outputs already in HBM; `stream` is a hipStream_t or NULL) ------------------ */
 /* Same layouts (array of structs) in device memory.  Asynchronous on `stream`; the caller synchronises. */
 int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_out, size_t n, void *stream);
@@ -113,7 +126,7 @@ int bn254_g2_mul_jacobian_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, 
    accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
 int bn254_profile_enable(bn254_ctx *ctx, int on);
 int bn254_profile_reset(bn254_ctx *ctx);
-/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared".  Synchronises the recorded events. */
+/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "wire_encode", "wire_decode".  Synchronises the recorded events. */
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 
 #ifdef __cplusplus

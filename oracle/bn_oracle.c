@@ -651,3 +651,112 @@ EXPORT void bno_pairing_product(const u64 *p, const u64 *q, size_t n, u64 *out) 
     for (size_t i = 0; i < n; ++i) { LD(g1, x, p + 12 * i); LD(g2, y, q + 24 * i); acc = fq12_mul(acc, pairing(&x, &y)); }
     ST(out, acc);
 }
+
+/* ================================================================ wire format
+ * Restated from the code only - the reference's tests/serialization.rs is absent from the mount, so there is no known-answer
+ * vector for this part ("parity pinned by code reading only").
+ *   U256 / U512: big-endian bytes, most significant limb first          arith.rs:100-159
+ *   Fq, Fr: the value taken OUT of Montgomery form, 32 bytes            fp.rs:24-36 ; decode rejects >= modulus (fp.rs:34)
+ *   Fq2: the 512-bit integer c1*q + c0, 64 bytes                        fq2.rs:31-53, arith.rs:21-44 ; decode = divrem by q
+ *   G: tag 0 (infinity) | tag 4 + affine x + affine y                   groups/mod.rs:143-176
+ *   decode checks y^2 = x^3 + b, and for G2 p*(-1) + p == 0             groups/mod.rs:178-205
+ * error codes (first failing check, in the reference's order): */
+enum { BNO_OK = 0, BNO_E_NOT_LESS_THAN_MODULUS = 1, BNO_E_NOT_LESS_THAN_MODULUS_SQUARED = 2, BNO_E_INVALID_LEADING_BYTE = 3,
+       BNO_E_NOT_ON_CURVE = 4, BNO_E_NOT_IN_SUBGROUP = 5 };
+
+static void u256_encode_be(const u256 *a, uint8_t *out) {                /* arith.rs:128-142 */
+    for (int l = 3, i = 0; l >= 0; --l, i += 8)
+        for (int b = 0; b < 8; ++b) out[i + b] = (uint8_t)(a->l[l] >> (56 - 8 * b));
+}
+static void u256_decode_be(const uint8_t *in, u256 *a) {                 /* arith.rs:144-159 */
+    for (int l = 3, i = 0; l >= 0; --l, i += 8) {
+        u64 v = 0;
+        for (int b = 0; b < 8; ++b) v = (v << 8) | in[i + b];
+        a->l[l] = v;
+    }
+}
+typedef struct { u64 l[8]; } u512;
+static u512 u512_from(const u256 *c1, const u256 *c0, const u256 *m) {    /* arith.rs:21-44: c1 * m + c0 */
+    u512 r; memset(&r, 0, sizeof r);
+    for (int i = 0; i < 4; ++i) mac_digit(r.l + i, 8 - i, m->l, c1->l[i]);
+    u64 carry = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (i < 4) r.l[i] = adc64(r.l[i], c0->l[i], &carry);
+        else if (carry) r.l[i] = adc64(r.l[i], 0, &carry);
+        else break;
+    }
+    return r;
+}
+static inline void mul2_256(u256 *a) {                                    /* arith.rs:374-384 */
+    u64 last = 0;
+    for (int i = 0; i < 4; ++i) { u64 t = a->l[i] >> 63; a->l[i] = (a->l[i] << 1) | last; last = t; }
+}
+/* arith.rs:65-88: bit-serial long division; returns 1 and the quotient when it is < modulo, else 0 */
+static int u512_divrem(const u512 *x, const u256 *m, u256 *q_out, u256 *r_out) {
+    u256 q = {{0, 0, 0, 0}}, r = {{0, 0, 0, 0}};
+    int q_some = 1;
+    for (int i = 511; i >= 0; --i) {
+        mul2_256(&r);
+        r.l[0] |= (x->l[i >> 6] >> (i & 63)) & 1;
+        if (u256_cmp(&r, m) >= 0) {
+            sub_noborrow(&r, m);
+            if (q_some) { if (i >= 256) q_some = 0; else q.l[i >> 6] |= 1ULL << (i & 63); }
+        }
+    }
+    *r_out = r;
+    if (q_some && u256_cmp(&q, m) >= 0) return 0;
+    *q_out = q;
+    return q_some;
+}
+static void fq_encode(fq a, uint8_t *out) { u256 one = {{1, 0, 0, 0}}; u256_mul(&a, &one, &FQ_MOD, FQ_INV); u256_encode_be(&a, out); }
+static int fq_decode(const uint8_t *in, fq *out) {                        /* fp.rs:30-36 */
+    u256 a; u256_decode_be(in, &a);
+    if (u256_cmp(&a, &FQ_MOD) >= 0) return BNO_E_NOT_LESS_THAN_MODULUS;
+    u256_mul(&a, &FQ_R2, &FQ_MOD, FQ_INV); *out = a; return BNO_OK;
+}
+static void fq2_encode(fq2 a, uint8_t *out) {                             /* fq2.rs:31-38 */
+    u256 one = {{1, 0, 0, 0}}, c0 = a.c0, c1 = a.c1;
+    u256_mul(&c0, &one, &FQ_MOD, FQ_INV); u256_mul(&c1, &one, &FQ_MOD, FQ_INV);
+    u512 v = u512_from(&c1, &c0, &FQ_MOD);
+    for (int l = 7, i = 0; l >= 0; --l, i += 8)
+        for (int b = 0; b < 8; ++b) out[i + b] = (uint8_t)(v.l[l] >> (56 - 8 * b));
+}
+static int fq2_decode(const uint8_t *in, fq2 *out) {                      /* fq2.rs:40-53 */
+    u512 v;
+    for (int l = 7, i = 0; l >= 0; --l, i += 8) { u64 w = 0; for (int b = 0; b < 8; ++b) w = (w << 8) | in[i + b]; v.l[l] = w; }
+    u256 c1, c0;
+    if (!u512_divrem(&v, &FQ_MOD, &c1, &c0)) return BNO_E_NOT_LESS_THAN_MODULUS_SQUARED;
+    u256_mul(&c0, &FQ_R2, &FQ_MOD, FQ_INV); u256_mul(&c1, &FQ_R2, &FQ_MOD, FQ_INV);
+    out->c0 = c0; out->c1 = c1; return BNO_OK;
+}
+/* fixed-size batch records: G1 65 bytes, G2 129 bytes; infinity = tag 0 followed by zero padding (the reference's variable
+ * length stream emits the single byte 0 there; a batch needs fixed strides) */
+EXPORT void bno_g1_encode(const u64 *p, uint8_t *out) {                   /* groups/mod.rs:143-164 */
+    LD(g1, x, p); memset(out, 0, 65);
+    g1aff a; if (!g1_to_affine(x, &a)) return;
+    out[0] = 4; fq_encode(a.x, out + 1); fq_encode(a.y, out + 33);
+}
+EXPORT void bno_g2_encode(const u64 *p, uint8_t *out) {
+    LD(g2, x, p); memset(out, 0, 129);
+    g2aff a; if (!g2_to_affine(x, &a)) return;
+    out[0] = 4; fq2_encode(a.x, out + 1); fq2_encode(a.y, out + 65);
+}
+EXPORT int bno_g1_decode(const uint8_t *in, u64 *out) {                   /* groups/mod.rs:166-205 */
+    if (in[0] == 0) { g1 z = g1_zero(); ST(out, z); return BNO_OK; }
+    if (in[0] != 4) return BNO_E_INVALID_LEADING_BYTE;
+    fq x, y; int rc;
+    if ((rc = fq_decode(in + 1, &x)) || (rc = fq_decode(in + 33, &y))) return rc;
+    if (!fq_eq(fq_sqr(y), fq_add(fq_mul(fq_sqr(x), x), G1_COEFF_B))) return BNO_E_NOT_ON_CURVE;
+    g1 r = {x, y, FQ_ONE}; ST(out, r); return BNO_OK;
+}
+EXPORT int bno_g2_decode(const uint8_t *in, u64 *out) {
+    if (in[0] == 0) { g2 z = g2_zero(); ST(out, z); return BNO_OK; }
+    if (in[0] != 4) return BNO_E_INVALID_LEADING_BYTE;
+    fq2 x, y; int rc;
+    if ((rc = fq2_decode(in + 1, &x)) || (rc = fq2_decode(in + 65, &y))) return rc;
+    if (!fq2_eq(fq2_sqr(y), fq2_add(fq2_mul(fq2_sqr(x), x), G2_COEFF_B))) return BNO_E_NOT_ON_CURVE;
+    g2 p = {x, y, fq2_one()};
+    u256 minus_one = FR_ONE; u256_neg(&minus_one, &FR_MOD);               /* -Fr::one() */
+    if (!g2_is_zero(g2_add(g2_mul(p, minus_one), p))) return BNO_E_NOT_IN_SUBGROUP;
+    ST(out, p); return BNO_OK;
+}

@@ -165,6 +165,18 @@ class Oracle:
     def g1_mul_batch_jacobian(self, p, k, nthreads=None): return self._mulb("bno_g1_mul_batch_jacobian", 12, p, k, nthreads)
     def g2_mul_batch_jacobian(self, p, k, nthreads=None): return self._mulb("bno_g2_mul_batch_jacobian", 24, p, k, nthreads)
 
+    # ---- wire format (fixed-size batch records: G1 65 bytes, G2 129 bytes)
+    def g1_encode(self, p):
+        o = np.zeros(65, np.uint8); self.lib.bno_g1_encode(_p(_u64(p, 12)), o.ctypes.data_as(C.c_void_p)); return o
+    def g2_encode(self, p):
+        o = np.zeros(129, np.uint8); self.lib.bno_g2_encode(_p(_u64(p, 24)), o.ctypes.data_as(C.c_void_p)); return o
+    def g1_decode(self, b):
+        b = np.ascontiguousarray(b, np.uint8); o = np.zeros(12, np.uint64)
+        rc = self.lib.bno_g1_decode(b.ctypes.data_as(C.c_void_p), _p(o)); return rc, o
+    def g2_decode(self, b):
+        b = np.ascontiguousarray(b, np.uint8); o = np.zeros(24, np.uint64)
+        rc = self.lib.bno_g2_decode(b.ctypes.data_as(C.c_void_p), _p(o)); return rc, o
+
     # ---- conveniences
     def fq12_from_ints(self, v): return np.concatenate([self.fp_from_int(FQ, int(x)) for x in v])
     def fq12_to_ints(self, a): return [self.fp_to_int(FQ, a[4 * i:4 * i + 4]) for i in range(12)]

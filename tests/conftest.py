@@ -46,3 +46,40 @@ def canon_infinity(points):
             row[:] = 0
             row[w:w + 4] = one
     return pts
+
+
+def g2_point_outside_subgroup():
+    """a point on the twist y^2 = x^3 + 3/xi over Fq2 that is NOT in the order-r subgroup (the twist has a large cofactor),
+    as the 129-byte wire record; built with the big-integer model (Fq2 square root by the complex method, q = 3 mod 4)"""
+    import numpy as np
+    import bn_model as M
+    def fq_sqrt(a):
+        r = pow(a, (M.Q + 1) // 4, M.Q)
+        return r if r * r % M.Q == a % M.Q else None
+    def f2_sqrt(a):
+        if a[1] == 0:
+            r = fq_sqrt(a[0])
+            return (r, 0) if r is not None else None
+        n = fq_sqrt((a[0] * a[0] + a[1] * a[1]) % M.Q)
+        if n is None:
+            return None
+        for s in (n, (-n) % M.Q):
+            x0 = fq_sqrt((a[0] + s) * pow(2, -1, M.Q) % M.Q)
+            if x0:
+                x1 = a[1] * pow(2 * x0, -1, M.Q) % M.Q
+                if M.f2_sqr((x0, x1)) == (a[0] % M.Q, a[1] % M.Q):
+                    return (x0, x1)
+        return None
+    x = (5, 1)
+    while True:
+        y = f2_sqrt(M.f2_add(M.f2_mul(M.f2_sqr(x), x), M.G2_B))
+        if y is not None:
+            p = (x, y, M.F2_ONE)
+            if not M.g_is_zero(M.FQ2_OPS, M.g_mul(M.FQ2_OPS, p, M.R_ORD)):
+                break
+        x = (x[0] + 1, x[1])
+    rec = np.zeros(129, np.uint8)
+    rec[0] = 4
+    rec[1:65] = np.frombuffer((x[1] * M.Q + x[0]).to_bytes(64, "big"), np.uint8)
+    rec[65:] = np.frombuffer((y[1] * M.Q + y[0]).to_bytes(64, "big"), np.uint8)
+    return rec

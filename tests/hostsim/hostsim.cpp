@@ -7,6 +7,7 @@
 #include "lanepair.hpp"
 #include "../../bn_amd/csrc/io.hpp"
 #include "../../bn_amd/csrc/curve.hpp"
+#include "../../bn_amd/csrc/io_wire.hpp"
 #include <cstring>
 
 using namespace bn254;
@@ -141,3 +142,9 @@ EXPORT void hsb_miller_only(const uint32_t *g1, const uint32_t *g2, uint32_t *o)
     f12_store(miller_loop(p, q), o);
 }
 #endif
+
+// wire format through the engine code
+EXPORT void hs_g1_encode(const uint32_t *p, uint8_t *o) { g1_encode_record(p, o); }
+EXPORT void hs_g2_encode(const uint32_t *p, uint8_t *o) { g2_encode_record(p, o); }
+EXPORT int hs_g1_decode(const uint8_t *in, uint32_t *o) { return g1_decode_record(in, o); }
+EXPORT int hs_g2_decode(const uint8_t *in, uint32_t *o) { return g2_decode_record(in, o); }

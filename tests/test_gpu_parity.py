@@ -245,3 +245,27 @@ def test_prepared_g2_mode(oracle, kats, eng):
     for i in (0, n - 1):
         assert np.array_equal(cos[i].reshape(102, 3, 8), oracle.g2_precompute(oracle.g2_to_affine(Qs[i])))
     assert np.array_equal(eng.pairing_prepared_batch(P, cos), oracle.pairing_batch(P, Qs))
+
+
+def test_wire_format_on_gpu(oracle, eng):
+    """SURVEY 8f-3 on the GPU: batch encode/decode of G1/G2 records incl. every validation outcome vs the code-derived oracle"""
+    from conftest import g2_point_outside_subgroup
+    rng = np.random.default_rng(110)
+    n = 70
+    P, Q = _points(oracle, rng, n)
+    P[3] = oracle.g1_zero(); Q[4] = oracle.g2_zero(); P[5] = oracle.g1_one(); Q[5] = oracle.g2_one()
+    e1 = eng.g1_encode_batch(P); e2 = eng.g2_encode_batch(Q)
+    for i in range(n):
+        assert np.array_equal(e1[i], oracle.g1_encode(P[i])) and np.array_equal(e2[i], oracle.g2_encode(Q[i]))
+    # corrupt some records: bad tag, coordinate >= q, >= q^2, off-curve, outside the subgroup
+    b1 = e1.copy(); b2 = e2.copy()
+    b1[10, 0] = 9; b1[11, 1:33] = 255; b1[12, 40] ^= 1
+    b2[10, 0] = 1; b2[11, 1:65] = 255; b2[12, 100] ^= 1; b2[13] = g2_point_outside_subgroup()
+    d1, s1 = eng.g1_decode_batch(b1); d2, s2 = eng.g2_decode_batch(b2)
+    for i in range(n):
+        rc, want = oracle.g1_decode(b1[i]); assert s1[i] == rc
+        assert np.array_equal(d1[i], want if rc == 0 else oracle.g1_zero())
+        rc, want = oracle.g2_decode(b2[i]); assert s2[i] == rc
+        assert np.array_equal(d2[i], want if rc == 0 else oracle.g2_zero())
+    assert list(s1[10:13]) == [3, 1, 4] and list(s2[10:14]) == [3, 2, 4, 5]
+    assert np.array_equal(d1[7], oracle.g1_normalize(P[7])) and np.array_equal(d2[7], oracle.g2_normalize(Q[7]))

@@ -188,3 +188,35 @@ def test_many_random_pairings_with_bound_verification(oracle, hs):
     for i in range(n):
         assert np.array_equal(hs.call("hs_pairing", P[i], Q[i], out_words=96), want[i])
         assert np.array_equal(hs.call("hsb_pairing", P[i], Q[i], out_words=96), want[i])
+
+
+def test_wire_format_through_engine_code(oracle, hs):
+    """encode/decode records and every validation outcome, device code on the CPU vs the code-derived oracle"""
+    import ctypes as C
+    from conftest import g2_point_outside_subgroup
+    def enc(fn, p, n):
+        out = np.zeros(n, np.uint8); p = np.ascontiguousarray(p, np.uint64)
+        getattr(hs.lib, fn)(p.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)); return out
+    def dec(fn, b, w):
+        out = np.zeros(w, np.uint64); b = np.ascontiguousarray(b, np.uint8)
+        rc = getattr(hs.lib, fn)(b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)); return rc, out
+    rng = np.random.default_rng(23)
+    for _ in range(4):
+        k = _fr(oracle, rng)
+        P = oracle.g1_mul(oracle.g1_one(), k); Q = oracle.g2_mul(oracle.g2_one(), k)
+        e1 = enc("hs_g1_encode", P, 65); e2 = enc("hs_g2_encode", Q, 129)
+        assert np.array_equal(e1, oracle.g1_encode(P)) and np.array_equal(e2, oracle.g2_encode(Q))
+        rc, d = dec("hs_g1_decode", e1, 12); assert rc == 0 and np.array_equal(d, oracle.g1_normalize(P))
+        rc, d = dec("hs_g2_decode", e2, 24); assert rc == 0 and np.array_equal(d, oracle.g2_normalize(Q))
+        for pos in (0, 5, 40):
+            b = e1.copy(); b[pos] ^= 0x55
+            assert dec("hs_g1_decode", b, 12)[0] == oracle.g1_decode(b)[0] != 0
+        for pos in (0, 5, 70, 128):
+            b = e2.copy(); b[pos] ^= 0x55
+            assert dec("hs_g2_decode", b, 24)[0] == oracle.g2_decode(b)[0] != 0
+    assert np.array_equal(enc("hs_g1_encode", oracle.g1_zero(), 65), oracle.g1_encode(oracle.g1_zero()))
+    rc, d = dec("hs_g2_decode", oracle.g2_encode(oracle.g2_zero()), 24); assert rc == 0 and np.array_equal(d, oracle.g2_zero())
+    b = oracle.g1_encode(P).copy(); b[1:33] = 255; assert dec("hs_g1_decode", b, 12)[0] == oracle.g1_decode(b)[0] == 1
+    b = oracle.g2_encode(Q).copy(); b[1:65] = 255; assert dec("hs_g2_decode", b, 24)[0] == oracle.g2_decode(b)[0] == 2
+    bad = g2_point_outside_subgroup()
+    assert oracle.g2_decode(bad)[0] == 5 and dec("hs_g2_decode", bad, 24)[0] == 5

@@ -138,3 +138,22 @@ def test_model_matches_limb_oracle(oracle, kats):
         Qp = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_int(FR, s2))
         want = M.pairing(M.g_mul(M.FQ_OPS, M.G1_ONE, s1), M.g_mul(M.FQ2_OPS, M.G2_ONE, s2))
         assert chk(oracle.pairing(P, Qp), want)
+
+
+def test_wire_format_against_big_integer_model(oracle):
+    """groups/mod.rs:143-205, fields/fq2.rs:31-53: [4][x][y] big-endian, Fq2 as the 512-bit integer c1*q + c0.  The reference
+    holds no byte-level vectors for this format (benches/api.rs only times it), so this pins the C restatement against the
+    independent big-integer model and the round trip; parity with the crate rests on code reading."""
+    rng = np.random.default_rng(31)
+    for _ in range(3):
+        s = int.from_bytes(rng.bytes(32), "little") % M.R_ORD
+        k = oracle.fp_from_int(FR, s)
+        P = oracle.g1_mul(oracle.g1_one(), k); Q = oracle.g2_mul(oracle.g2_one(), k)
+        x, y = M.g_to_affine(M.FQ_OPS, M.g_mul(M.FQ_OPS, M.G1_ONE, s))
+        assert bytes(oracle.g1_encode(P)) == b"\x04" + x.to_bytes(32, "big") + y.to_bytes(32, "big")
+        x, y = M.g_to_affine(M.FQ2_OPS, M.g_mul(M.FQ2_OPS, M.G2_ONE, s))
+        assert bytes(oracle.g2_encode(Q)) == b"\x04" + (x[1] * M.Q + x[0]).to_bytes(64, "big") + (y[1] * M.Q + y[0]).to_bytes(64, "big")
+        rc, d = oracle.g1_decode(oracle.g1_encode(P)); assert rc == 0 and np.array_equal(d, oracle.g1_normalize(P))
+        rc, d = oracle.g2_decode(oracle.g2_encode(Q)); assert rc == 0 and np.array_equal(d, oracle.g2_normalize(Q))
+    assert bytes(oracle.g1_encode(oracle.g1_zero())) == bytes(65)
+    assert oracle.g1_decode(np.zeros(65, np.uint8))[0] == 0
