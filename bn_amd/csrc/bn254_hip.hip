@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(BLOCK) bn254_g2_decode_k(const uint8_t *in, ui
 }  // namespace
 
 // ======================================================================================================== host side
-extern "C" int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, hipStream_t s);      // bn254_kernels_b.hip
+extern "C" int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s);      // bn254_kernels_b.hip
 extern "C" int bn254_launch_final_exp_B(const void *f, void *out, size_t n, hipStream_t s);
 extern "C" int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
 extern "C" int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
@@ -209,9 +209,10 @@ struct Scope {      // brackets one kernel launch with events when profiling is 
 };
 inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
-int launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s) {
+// naf: the value is only consumed by a final exponentiation, so the shorter NAF schedule may be used (pairing.hpp)
+int launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf = false) {
     Scope sc(c, s, "miller");
-    if (c->mapping == 1) return bn254_launch_miller_B(p, q, f, n, s);
+    if (c->mapping == 1) return bn254_launch_miller_B(p, q, f, n, naf ? 1 : 0, s);
     hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
@@ -315,7 +316,7 @@ int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, vo
     if (!d_p || !d_q || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     // the Miller values are written to d_out and exponentiated in place (same 384-byte slots)
-    rc = launch_miller(ctx, d_p, d_q, d_out, n, (hipStream_t)stream); if (rc) return rc;
+    rc = launch_miller(ctx, d_p, d_q, d_out, n, (hipStream_t)stream, true); if (rc) return rc;
     return launch_final_exp(ctx, d_out, d_out, n, (hipStream_t)stream);
 }
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream) {
@@ -339,7 +340,7 @@ int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, s
     HIP_TRY(hipSetDevice(ctx->device));
     size_t fbytes = n * 384;
     rc = ensure_ws(ctx, fbytes + product_tmp_bytes(n)); if (rc) return rc;
-    rc = launch_miller(ctx, d_p, d_q, ctx->ws, n, (hipStream_t)stream); if (rc) return rc;
+    rc = launch_miller(ctx, d_p, d_q, ctx->ws, n, (hipStream_t)stream, true); if (rc) return rc;
     return launch_product(ctx, ctx->ws, n, d_partial, (char *)ctx->ws + fbytes, (hipStream_t)stream);
 }
 static int mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream, int normalize) {

@@ -46,7 +46,8 @@ struct MillerStateLds {
     __device__ __forceinline__ G1Aff<Fe> get_p() const { return {ld_fe(5), ld_fe(6)}; }
 };
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+template <bool NAF>
+__device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -59,11 +60,20 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
                       f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32), p, q);
     __shared__ uint32_t park[PARK_DWORDS * BLOCK];
     MillerStateLds st = {park + threadIdx.x};
-    Fq12<F2> f = miller_loop(p, q, st);
+    Fq12<F2> f = miller_loop_sched<NAF>(p, q, st);
     Fq12<F2> one = f12_one<F2>();
     f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
     f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);
     if (live) f12_store(f, f_out + 96u * pair);
+}
+
+// reference schedule: the Miller VALUES equal the reference's (bn254_miller_batch_dev, prepared-mode cross checks)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+    miller_B_body<false>(g1, g2, f_out, n);
+}
+// NAF schedule (pairing.hpp miller_loop_sched<true>): used wherever a final exponentiation follows
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_naf_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+    miller_B_body<true>(g1, g2, f_out, n);
 }
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n) {
@@ -192,9 +202,9 @@ int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hip
     hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
-int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, hipStream_t s) {
+int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_miller_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
+    hipLaunchKernelGGL(naf ? bn254_miller_naf_B : bn254_miller_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
 int bn254_launch_final_exp_B(const void *f, void *out, size_t n, hipStream_t s) {

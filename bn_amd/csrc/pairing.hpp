@@ -83,10 +83,14 @@ struct MillerStateVars {
 
 // groups/mod.rs:486-519 fused with :557-588.  The schedule (6u+2 with the top bit skipped: 64 doublings, an addition of Q
 // after every set bit, then the additions of pi(Q) and -pi^2(Q)) is a compile-time constant, so every branch below is
-// wave-uniform.  Written as ONE loop of 66 steps x up to 2 passes so that each of f^2, the two line functions and the
+// wave-uniform.  Written as ONE loop of steps x up to 2 passes so that each of f^2, the two line functions and the
 // sparse multiplication exists exactly once in the instruction stream.
-template <class F2, class S, class Store>
-BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q, Store &st) {
+//   NAF = false: the reference's schedule; the returned Miller value equals the reference's miller_loop limb for limb.
+//   NAF = true : 6u+2 in non-adjacent form (65 doublings, 21 additions of +-Q instead of 64 + 36).  The Miller value differs
+//                from the reference's by a factor that the final exponentiation kills (different line scalings / omitted
+//                verticals, all in proper subfields), so pairing() - the only observable of this path - is bit-identical.
+template <bool NAF, class F2, class S, class Store>
+BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p, const G2Aff<F2> &q, Store &st) {
     {
         G2Proj<F2> r0 = {q.x, q.y, f2_one(F2P)};
         st.put_r(r0);
@@ -94,23 +98,30 @@ BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q, Store &st) {
         st.put_p(p);
     }
     Fq12<F2> f = f12_one<F2>();
+    constexpr int ND = NAF ? k::ATE_NAF_LEN - 1 : 64;                                // doublings
 #pragma unroll 1
-    for (int j = 0; j < 66; ++j) {
-        const bool tail = j >= 64;
-        const bool bit = tail ? true : (((k::ATE_LOOP_LOW64 >> (63 - (j & 63))) & 1) != 0);
-        if (j == 64) st.put_base(mul_by_q(st.get_base()));                          // pi(Q)      groups/mod.rs:578
-        if (j == 65) { G2Aff<F2> b2 = mul_by_q(st.get_base()); b2.y = f2_neg(b2.y); st.put_base(b2); }   // -pi^2(Q)   :579
+    for (int j = 0; j < ND + 2; ++j) {
+        const bool tail = j >= ND;
+        int digit = 1;
+        if (!tail) {
+            if (NAF) digit = k::ATE_NAF[ND - 1 - j];
+            else digit = (int)((k::ATE_LOOP_LOW64 >> (63 - (j & 63))) & 1);
+        }
+        if (j == ND) st.put_base(mul_by_q(st.get_base()));                          // pi(Q)      groups/mod.rs:578
+        if (j == ND + 1) { G2Aff<F2> b2 = mul_by_q(st.get_base()); b2.y = f2_neg(b2.y); st.put_base(b2); }   // -pi^2(Q)   :579
 #pragma unroll 1
-        for (int pass = tail ? 1 : 0; pass < (bit ? 2 : 1); ++pass) {
+        for (int pass = tail ? 1 : 0; pass < (digit != 0 ? 2 : 1); ++pass) {
             Line<F2> l;
             if (pass == 0) {
-                f = f12_sqr(f);
+                if (j != 0) f = f12_sqr(f);                                         // f == 1 in the first step
                 G2Proj<F2> r = st.get_r();
                 l = doubling_step(r);
                 st.put_r(r);
             } else {
                 G2Proj<F2> r = st.get_r();
-                l = addition_step(r, st.get_base());
+                G2Aff<F2> b = st.get_base();
+                if (NAF && digit < 0) b.y = f2_neg(b.y);
+                l = addition_step(r, b);
                 st.put_r(r);
             }
             f = apply_line(f, l, st.get_p());
@@ -118,6 +129,8 @@ BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q, Store &st) {
     }
     return f;
 }
+template <class F2, class S, class Store>
+BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q, Store &st) { return miller_loop_sched<false>(p, q, st); }
 template <class F2, class S>
 BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q) {
     MillerStateVars<F2, S> st;

@@ -269,3 +269,26 @@ def test_wire_format_on_gpu(oracle, eng):
         assert np.array_equal(d2[i], want if rc == 0 else oracle.g2_zero())
     assert list(s1[10:13]) == [3, 1, 4] and list(s2[10:14]) == [3, 2, 4, 5]
     assert np.array_equal(d1[7], oracle.g1_normalize(P[7])) and np.array_equal(d2[7], oracle.g2_normalize(Q[7]))
+
+
+@pytest.mark.parametrize("mapping", [0, 1])
+def test_miller_values_equal_reference_schedule(oracle, mapping):
+    """bn254_miller_batch_dev keeps the reference's schedule (groups/mod.rs:486-519), so the un-exponentiated values equal the
+    oracle's limb for limb; bn254_final_exp_batch_dev of them is the pairing (the pairing kernels use the NAF schedule)"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    e = bn_amd.Engine(0, mapping=mapping)
+    rng = np.random.default_rng(77)
+    n = 33
+    P, Q = _points(oracle, rng, n)
+    tp = torch.from_numpy(P.view(np.int64)).to(dev); tq = torch.from_numpy(Q.view(np.int64)).to(dev)
+    f = torch.empty(n, 48, dtype=torch.int64, device=dev); g = torch.empty_like(f)
+    e.miller_batch_dev(tp.data_ptr(), tq.data_ptr(), f.data_ptr(), n, torch.cuda.current_stream(dev).cuda_stream)
+    e.final_exp_batch_dev(f.data_ptr(), g.data_ptr(), n, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    fn = f.cpu().numpy().view(np.uint64); gn = g.cpu().numpy().view(np.uint64)
+    for i in range(n):
+        assert np.array_equal(fn[i], oracle.miller_only(P[i], Q[i]))
+    assert np.array_equal(gn, oracle.pairing_batch(P, Q))

@@ -147,12 +147,22 @@ def test_lane_pair_mapping(oracle, hs, kats):
     I = lambda l: [int(x) for x in l]
     k1 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k1"]); k2 = oracle.fp_from_decimal(FR, kats["test_miller_loop"]["k2"])
     P = oracle.g1_mul(oracle.g1_one(), k1); Q = oracle.g2_mul(oracle.g2_one(), k2)
+    P0, Q0 = P, Q
     assert oracle.fq12_to_ints(hs.call("hsb_pairing", P, Q, out_words=96)) == I(kats["test_reduced_pairing"]["expected"])
     for _ in range(3):
         P = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)); Q = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng))
         assert np.array_equal(hs.call("hsb_pairing", P, Q, out_words=96), oracle.pairing(P, Q))
     assert np.array_equal(hs.call("hsb_pairing", oracle.g1_zero(), Q, out_words=96), oracle.fq12_one())
     assert np.array_equal(hs.call("hsb_pairing", oracle.g1_one(), oracle.g2_one(), out_words=96), oracle.pairing(oracle.g1_one(), oracle.g2_one()))
+    # the NAF Miller schedule of the pairing kernels: same pairing value bit for bit (incl. the reference's known answer);
+    # the reference-schedule Miller value itself equals the reference's
+    assert oracle.fq12_to_ints(hs.call("hsb_pairing_naf", P0, Q0, out_words=96)) == I(kats["test_reduced_pairing"]["expected"])
+    assert oracle.fq12_to_ints(hs.call("hsb_miller", P0, Q0, out_words=96)) == I(kats["test_miller_loop"]["expected"])
+    for _ in range(3):
+        P = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)); Q = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng))
+        assert np.array_equal(hs.call("hsb_pairing_naf", P, Q, out_words=96), oracle.pairing(P, Q))
+    assert np.array_equal(hs.call("hsb_pairing_naf", oracle.g1_one(), oracle.g2_one(), out_words=96), oracle.pairing(oracle.g1_one(), oracle.g2_one()))
+    assert np.array_equal(hs.call("hsb_pairing_naf", P, oracle.g2_zero(), out_words=96), oracle.fq12_one())
 
 
 def _fr(oracle, rng):

@@ -27,7 +27,7 @@ def main():
         F = sum(fa[k]["FETCH_SIZE"]) / len(fa[k]["FETCH_SIZE"]); W = sum(wa[k]["WRITE_SIZE"]) / len(wa[k]["WRITE_SIZE"])
         raw = (F + W) * 1024; corr = (2 * F + W) * 1024
         lines.append("%-22s %14.1f %14.1f %12.4f %12.4f %6s %6s %8s %8s" % ((k, F, W, raw / 1e9, corr / 1e9) + meta[k][:4]))
-        short = {"bn254_miller_A": "miller", "bn254_miller_B": "miller", "bn254_final_exp_A": "final_exp", "bn254_final_exp_B": "final_exp"}.get(k)
+        short = {"bn254_miller_A": "miller", "bn254_miller_B": "miller", "bn254_miller_naf_B": "miller", "bn254_final_exp_A": "final_exp", "bn254_final_exp_B": "final_exp"}.get(k)
         if short:
             traffic[short] = {"hbm_bytes_per_launch": corr, "hbm_bytes_per_launch_raw": raw, "kernel": k, "source": f"profiles/{tag}_pmc.txt"}
     if sq:
