@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(BLOCK) bn254_g2_decode_k(const uint8_t *in, ui
 
 // ======================================================================================================== host side
 extern "C" int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s);      // bn254_kernels_b.hip
-extern "C" int bn254_launch_final_exp_B(const void *f, void *out, size_t n, hipStream_t s);
+extern "C" int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hipStream_t s);
+extern "C" size_t bn254_final_exp_table_bytes_B(size_t n);
 extern "C" int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
 extern "C" int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
 extern "C" int bn254_launch_gt_product_B(const void *in, void *out, size_t n, unsigned chunk, hipStream_t s);
@@ -161,6 +162,8 @@ struct bn254_ctx {
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
     void *ws = nullptr;                 // workspace (Miller values, product-tree levels)
     size_t ws_bytes = 0;
+    void *exp_tbl = nullptr;            // odd-power tables of the windowed exponentiation by u (final_exp_B), grow-only
+    size_t exp_tbl_bytes = 0;
     void *stage[3] = {nullptr, nullptr, nullptr};   // device staging of the host-buffer entry points (grow-only, reused)
     size_t stage_bytes[3] = {0, 0, 0};
     bool profile = false;
@@ -218,7 +221,15 @@ int launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n,
 }
 int launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s) {
     Scope sc(c, s, "final_exp");
-    if (c->mapping == 1) return bn254_launch_final_exp_B(f, out, n, s);
+    if (c->mapping == 1) {
+        size_t need = bn254_final_exp_table_bytes_B(n);
+        if (c->exp_tbl_bytes < need) {
+            if (c->exp_tbl) { HIP_TRY(hipFree(c->exp_tbl)); c->exp_tbl = nullptr; c->exp_tbl_bytes = 0; }
+            if (hipMalloc(&c->exp_tbl, need) != hipSuccess) return BN254_E_ALLOC;
+            c->exp_tbl_bytes = need;
+        }
+        return bn254_launch_final_exp_B(f, out, n, c->exp_tbl, s);
+    }
     hipLaunchKernelGGL(bn254_final_exp_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
@@ -276,6 +287,7 @@ void bn254_ctx_destroy(bn254_ctx *c) {
     hipSetDevice(c->device);
     for (auto &r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->ws) hipFree(c->ws);
+    if (c->exp_tbl) hipFree(c->exp_tbl);
     for (int i = 0; i < 3; ++i) if (c->stage[i]) hipFree(c->stage[i]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -76,12 +76,48 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     miller_B_body<true>(g1, g2, f_out, n);
 }
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n) {
+// Table of odd powers of the windowed exponentiation (pairing.hpp ExpTableVars) in global memory: slot-major, then the 54
+// dwords of this lane's half of an Fq12, then the lane - every access of a wave is one coalesced 256-byte row.
+struct ExpTableMem {
+    uint32_t *table;         // wave-uniform base (SGPRs)
+    uint32_t lane;           // this lane's column
+    uint32_t stride;         // lanes in the launch
+    __device__ __forceinline__ uint32_t *row(int slot, int half) const {          // uniform: scalar address arithmetic
+        return table + (size_t)(uint32_t)((slot * 2 + half) * 27) * stride;
+    }
+    __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
+        uint32_t *p = row(slot, half);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            (p + (size_t)i * stride)[lane] = v.c0.v.l[i];
+            (p + (size_t)(9 + i) * stride)[lane] = v.c1.v.l[i];
+            (p + (size_t)(18 + i) * stride)[lane] = v.c2.v.l[i];
+        }
+    }
+    __device__ __forceinline__ Fq6<F2> ld6(int slot, int half) const {
+        const uint32_t *p = row(slot, half);
+        Fq6<F2> v;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            v.c0.v.l[i] = (p + (size_t)i * stride)[lane];
+            v.c1.v.l[i] = (p + (size_t)(9 + i) * stride)[lane];
+            v.c2.v.l[i] = (p + (size_t)(18 + i) * stride)[lane];
+        }
+        return v;
+    }
+    __device__ __forceinline__ void put(int i, const Fq12<F2> &v) const { st6(i, 0, v.c0); st6(i, 1, v.c1); }
+    __device__ __forceinline__ Fq6<F2> c0(int i) const { return ld6(i, 0); }
+    __device__ __forceinline__ Fq6<F2> c1(int i) const { return ld6(i, 1); }
+};
+constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 54;
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n, uint32_t *table) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
-    Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair));
+    ExpTableMem tbl = {table, t, gridDim.x * BLOCK};
+    Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair), tbl);
     if (live) f12_store(f, out + 96u * pair);
 }
 // ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
@@ -207,9 +243,13 @@ int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int n
     hipLaunchKernelGGL(naf ? bn254_miller_naf_B : bn254_miller_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
-int bn254_launch_final_exp_B(const void *f, void *out, size_t n, hipStream_t s) {
+size_t bn254_final_exp_table_bytes_B(size_t n) {
+    size_t grid = (2 * n + BLOCK - 1) / BLOCK;
+    return grid * BLOCK * EXP_TABLE_DWORDS_PER_LANE * sizeof(uint32_t);
+}
+int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_final_exp_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
+    hipLaunchKernelGGL(bn254_final_exp_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n, (uint32_t *)table);
     return (int)hipGetLastError();
 }
 }

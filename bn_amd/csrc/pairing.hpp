@@ -176,20 +176,48 @@ BN_FN Fq12<F2> miller_loop_prepared(const G1Aff<S> &p, Source &source) {
     return f;
 }
 
+// Table of the windowed exponentiation below: EXP_SLOTS Fq12 values per pairing.  Default: ordinary variables (host
+// simulation); the lane-pair kernel keeps it in global memory (54 dwords per lane and slot, coalesced), which also takes the
+// multiplier of the exponentiation loop out of the register file.
+template <class F2>
+struct ExpTableVars {
+    Fq12<F2> s_[k::EXP_SLOTS];
+    BN_FN void put(int i, const Fq12<F2> &v) { s_[i] = v; }
+    BN_FN Fq6<F2> c0(int i) const { return s_[i].c0; }
+    BN_FN Fq6<F2> c1(int i) const { return s_[i].c1; }
+};
+template <class F2, class Tbl>
+struct Fq12Slot {
+    const Tbl &t;
+    int i;
+    BN_FN Fq6<F2> c0() const { return t.c0(i); }
+    BN_FN Fq6<F2> c1() const { return t.c1(i); }
+};
+
 // fq12.rs:229-246 + 97-101: f^u, then conjugate.  The reference walks the 63 bits of u (62 cyclotomic squarings, 27
 // multiplications).  On the cyclotomic subgroup f^-1 = conj(f) is free, so the same group element is reached through the
-// non-adjacent form of u (weight 24: 23 multiplications); the value - and therefore every output byte - is identical.
+// width-4 non-adjacent form of u over the odd powers f, f^3, f^5, f^7 (63 squarings, 16 multiplications including the table);
+// the value - and therefore every output byte - is identical.  k::EXP_SCHED holds one control word per step, so the squaring
+// and the product each exist once in the instruction stream.
 // Only valid for f in the cyclotomic subgroup, which is where final_exponentiation calls it (after the easy part).
-template <class F2>
-BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
+template <class F2, class Tbl>
+BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f, Tbl &tbl) {
     Fq12<F2> res = f;
 #pragma unroll 1
-    for (int i = k::BN_U_NAF_LEN - 2; i >= 0; --i) {
-        res = f12_cyclotomic_sqr(res);
-        const int d = k::BN_U_NAF[i];
-        if (d != 0) res = f12_mul_src(res, Fq12Ref<F2>{f}, d < 0);      // one copy of the product in the instruction stream
+    for (int s = 0; s < k::EXP_STEPS; ++s) {
+        const int w = k::EXP_SCHED[s];
+        const int get = (w >> 8) & 7, mul = (w >> 1) & 7, put = (w >> 5) & 7;
+        if (get) res = Fq12<F2>{tbl.c0(get - 1), tbl.c1(get - 1)};
+        if (w & 1) res = f12_cyclotomic_sqr(res);
+        if (mul) res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, mul - 1}, ((w >> 4) & 1) != 0);
+        if (put) tbl.put(put - 1, res);
     }
     return f12_conj(res);
+}
+template <class F2>
+BN_FN Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
+    ExpTableVars<F2> tbl;
+    return exp_by_neg_z(f, tbl);
 }
 // the reference's own schedule (plain binary expansion of u); kept for inputs OFF the cyclotomic subgroup - the known-answer
 // test of fields/mod.rs:171-201 feeds exp_by_neg_z such an element, where conj(f) != f^-1
@@ -211,15 +239,15 @@ BN_FN Fq12<F2> final_exp_first_chunk(const Fq12<F2> &f) {
     return f12_mul_o(f12_frobenius<2>(c), c);
 }
 // fq12.rs:54-84
-template <class F2>
-BN_FN Fq12<F2> final_exp_last_chunk(const Fq12<F2> &s) {
-    Fq12<F2> a = exp_by_neg_z(s);
+template <class F2, class Tbl>
+BN_FN Fq12<F2> final_exp_last_chunk(const Fq12<F2> &s, Tbl &tbl) {
+    Fq12<F2> a = exp_by_neg_z(s, tbl);
     Fq12<F2> b = f12_cyclotomic_sqr_o(a);
     Fq12<F2> c = f12_cyclotomic_sqr_o(b);
     Fq12<F2> d = f12_mul_o(c, b);
-    Fq12<F2> e = exp_by_neg_z(d);
+    Fq12<F2> e = exp_by_neg_z(d, tbl);
     Fq12<F2> f = f12_cyclotomic_sqr_o(e);
-    Fq12<F2> g = exp_by_neg_z(f);
+    Fq12<F2> g = exp_by_neg_z(f, tbl);
     Fq12<F2> h = f12_conj(d);
     Fq12<F2> i = f12_conj(g);
     Fq12<F2> j = f12_mul_o(i, e);
@@ -235,8 +263,13 @@ BN_FN Fq12<F2> final_exp_last_chunk(const Fq12<F2> &s) {
     Fq12<F2> u = f12_frobenius<3>(t);
     return f12_mul_o(u, r);
 }
+template <class F2, class Tbl>
+BN_FN Fq12<F2> final_exponentiation(const Fq12<F2> &f, Tbl &tbl) { return final_exp_last_chunk(final_exp_first_chunk(f), tbl); }
 template <class F2>
-BN_FN Fq12<F2> final_exponentiation(const Fq12<F2> &f) { return final_exp_last_chunk(final_exp_first_chunk(f)); }
+BN_FN Fq12<F2> final_exponentiation(const Fq12<F2> &f) {
+    ExpTableVars<F2> tbl;
+    return final_exponentiation(f, tbl);
+}
 
 // groups/mod.rs:113-130 for G2 (z == 1 needs no special case: the general path returns the same canonical values)
 template <class F2>

@@ -99,16 +99,17 @@ struct Fq12Ref {
 };
 template <class F2, class BSrc>
 BN_FN Fq12<F2> f12_mul_src(const Fq12<F2> &a, const BSrc &b, bool conj_b) {
-    Fq6<F2> aa = f6_mul(a.c0, b.c0());
+    // the Karatsuba cross term first: it is the only product that needs both halves of a and of b at once
     Fq6<F2> b1 = b.c1();
     if (conj_b) b1 = f6_neg(b1);
+    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add(b.c0(), b1));
     Fq6<F2> bb = f6_mul(a.c1, b1);
+    Fq6<F2> aa = f6_mul(a.c0, b.c0());
     Fq12<F2> r;
+    r.c1 = f6_lc3<1, -1, -1>(t, aa, bb);
     r.c0.c0 = f2_lc_xi<1, 1>(bb.c2, aa.c0);                  // aa + v*bb
     r.c0.c1 = f2_lc3<1, 1, 0>(aa.c1, bb.c0, bb.c0);
     r.c0.c2 = f2_lc3<1, 1, 0>(aa.c2, bb.c1, bb.c1);
-    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add(b.c0(), b1));
-    r.c1 = f6_lc3<1, -1, -1>(t, aa, bb);
     return r;
 }
 template <class F2>
