@@ -6,7 +6,7 @@ import pathlib
 import subprocess
 
 HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = HERE / "libbn254_hip.so"
+LIB_PATH = pathlib.Path(os.environ.get("BN254_LIB_PATH", HERE / "libbn254_hip.so"))     # override: kernel experiments only
 SRC = HERE / "csrc" / "bn254_hip.hip"
 SRC_B = HERE / "csrc" / "bn254_kernels_b.hip"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,6 +1,7 @@
 import pathlib
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
@@ -83,3 +84,9 @@ def g2_point_outside_subgroup():
     rec[1:65] = np.frombuffer((x[1] * M.Q + x[0]).to_bytes(64, "big"), np.uint8)
     rec[65:] = np.frombuffer((y[1] * M.Q + y[0]).to_bytes(64, "big"), np.uint8)
     return rec
+
+
+@pytest.fixture(scope="session")
+def goldens():
+    """tests/golden/pairing_goldens.npz (made by tests/golden/make_goldens.py with the KAT-pinned oracle)"""
+    return np.load(ROOT / "tests/golden/pairing_goldens.npz")

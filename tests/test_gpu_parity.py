@@ -292,3 +292,24 @@ def test_miller_values_equal_reference_schedule(oracle, mapping):
     for i in range(n):
         assert np.array_equal(fn[i], oracle.miller_only(P[i], Q[i]))
     assert np.array_equal(gn, oracle.pairing_batch(P, Q))
+
+
+def test_golden_fixtures_on_gpu(eng, goldens):
+    """the committed fixtures (tests/golden/pairing_goldens.npz: edge scalars 1, 2, r-1, ... then seeded random) through every
+    host-buffer entry point - this test does not touch the oracle at all"""
+    g = goldens
+    n = g["k1"].shape[0]
+    assert np.array_equal(eng.pairing_batch(g["g1"], g["g2"]), g["gt"])
+    one1 = np.tile(g["g1"][0], (n, 1)); one2 = np.tile(g["g2"][10], (n, 1))          # scalars1[0] == scalars2[10] == 1: the generators
+    assert int(g["scalars1"][0]) == 1 and int(g["scalars2"][10]) == 1
+    assert np.array_equal(eng.g1_mul_batch(one1, g["k1"]), g["g1"]) and np.array_equal(eng.g2_mul_batch(one2, g["k2"]), g["g2"])
+    assert np.array_equal(eng.g2_precompute(g["g2"][5:6]).reshape(102, 24), g["coeffs"])
+    assert np.array_equal(eng.g1_encode_batch(g["g1"][:32]), g["wire_g1"]) and np.array_equal(eng.g2_encode_batch(g["g2"][:32]), g["wire_g2"])
+    d1, s1 = eng.g1_decode_batch(g["wire_g1"]); d2, s2 = eng.g2_decode_batch(g["wire_g2"])
+    assert not s1.any() and not s2.any() and np.array_equal(d1, g["g1"][:32]) and np.array_equal(d2, g["g2"][:32])
+    # e(a G1, b G2) = e(G1, G2)^(ab) on the device: Gt::pow of golden (1, 1)... index with scalars (1, x): gt[0] = e(G1, s2[0] G2)
+    prod = eng.pairing_product(g["g1"], g["g2"])
+    acc = g["gt"][0:1]
+    for i in range(1, n):
+        acc = eng.gt_mul_batch(acc, g["gt"][i:i + 1])
+    assert np.array_equal(prod.reshape(1, 48), acc)

@@ -230,3 +230,11 @@ def test_wire_format_through_engine_code(oracle, hs):
     b = oracle.g2_encode(Q).copy(); b[1:65] = 255; assert dec("hs_g2_decode", b, 24)[0] == oracle.g2_decode(b)[0] == 2
     bad = g2_point_outside_subgroup()
     assert oracle.g2_decode(bad)[0] == 5 and dec("hs_g2_decode", bad, 24)[0] == 5
+
+
+def test_golden_fixtures_through_engine_code(hs, goldens):
+    """committed fixtures (edge scalars first) through the device code on the CPU, both Miller schedules"""
+    g = goldens
+    for i in (0, 1, 2, 3, 10, 50):
+        assert np.array_equal(hs.call("hsb_pairing_naf", g["g1"][i], g["g2"][i], out_words=96), g["gt"][i])
+    assert np.array_equal(hs.call("hsb_pairing", g["g1"][2], g["g2"][2], out_words=96), g["gt"][2])

@@ -35,9 +35,42 @@ def classify(op):
     if op.startswith("v_"): return "valu32"
     return "other"
 
+# issue interval seen by ONE wave at 2 waves per SIMD, in cycles (profiles/r01_ubench_valu_rates.txt)
+WEIGHT = {"mad64": 9.5, "valu64": 7.5, "v_mul32": 7.5, "valu32": 5.25, "v_mov": 5.25, "salu": 1, "scratch_ld": 5.25, "scratch_st": 5.25,
+          "lds": 5.25, "global": 5.25, "waitcnt": 1, "call/ret": 4, "other": 1}
+
+def blocks(text, pat):
+    """per basic block (split at branches) of the functions matching `pat`: class counts and a cycle estimate"""
+    fn = None; cur = collections.Counter(); first = None
+    def flush(tag):
+        nonlocal cur, first
+        if sum(cur.values()):
+            cyc = sum(WEIGHT[k] * v for k, v in cur.items())
+            print(f"  {first}..{tag:>9}: n {sum(cur.values()):5d} est_cycles {cyc:8.0f} calls {cur['call/ret']:3d}  " +
+                  ", ".join(f"{k} {v}" for k, v in cur.most_common() if k not in ("call/ret",)))
+        cur = collections.Counter(); first = None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            if fn: flush("end")
+            fn = m.group(1) if pat in m.group(1) else None
+            if fn: print(fn[:110])
+            continue
+        if not fn: continue
+        m = re.match(r"^\s+([a-z_0-9]+)\s.*//\s*([0-9A-F]+):", line)
+        if not m: continue
+        if first is None: first = m.group(2)[-5:]
+        cur[classify(m.group(1))] += 1
+        if m.group(1).startswith(("s_cbranch", "s_branch")): flush(m.group(2)[-5:])
+    if fn: flush("end")
+
 def main():
     pats = sys.argv[1:]
-    for text in disassemble(ROOT / "bn_amd" / "libbn254_hip.so"):
+    so = pathlib.Path(__import__("os").environ.get("ISA_LIB", ROOT / "bn_amd" / "libbn254_hip.so"))
+    if pats and pats[0] == "--blocks":
+        for text in disassemble(so): blocks(text, pats[1])
+        return
+    for text in disassemble(so):
         fn = None; mix = collections.OrderedDict()
         for line in text.splitlines():
             m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
