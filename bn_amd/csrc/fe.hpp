@@ -30,6 +30,7 @@
 #define BN_COARSE inline
 #define BN_OUTER inline
 #define BN254_CONSTANT constexpr
+#define BN_COMPILER_FENCE() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define BN_FN __device__ __forceinline__
@@ -43,6 +44,8 @@
 //           always real functions, so the hot loops are not diluted by their code
 #define BN_OUTER __device__ __noinline__ inline
 #define BN254_CONSTANT __device__ constexpr
+// keeps loads that follow in the source from being scheduled above this point (used where early loads only cause spills)
+#define BN_COMPILER_FENCE() asm volatile("" ::: "memory")
 #endif
 #include "bn254_constants.hpp"
 

@@ -110,6 +110,20 @@ BN_FN Fe lane_partner(const Fe &x) {          // DPP quad_perm [1,0,3,2]: swap t
 BN_FN bool lane_partner_flag(bool f) { return __builtin_amdgcn_mov_dpp((int)f, 0xB1, 0xF, 0xF, true) != 0; }
 BN_FN Fe lane_pick(const Fe &even_choice, const Fe &odd_choice) { return fe_select(lane_is_odd(), even_choice, odd_choice); }
 BN_FN Fe lane_bcast(const Fe *, const Fe &x) { return x; }
+// An Fq2 constant (c0 on even lanes, c1 on odd lanes) built from literals at the point of use: c0 ^ (mask & (c0 ^ c1)), two
+// full-rate instructions per limb.  The mask goes through an empty volatile asm so that the value is NOT loop-invariant for
+// the compiler: hoisted out of the Miller loop it was kept as nine partially built vectors in private memory (81 dword loads
+// per doubling step).
+template <class TAB>
+BN_FN Fe lane_const_pick(const Fe *, const TAB &even_tab, const TAB &odd_tab) {
+    uint32_t m = 0u - (threadIdx.x & 1u);
+    asm volatile("" : "+v"(m));
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = even_tab[i] ^ (m & (even_tab[i] ^ odd_tab[i]));
+    BN_SETB(r, 1, 1);
+    return r;
+}
 BN_FN Fe lane_load_pair(const Fe *, const uint32_t *w0, const uint32_t *w1) { return fe_from_u32x8(lane_is_odd() ? w1 : w0); }
 BN_FN void lane_store_pair(const Fe &a, uint32_t *w0, uint32_t *w1) { fe_to_u32x8(a, lane_is_odd() ? w1 : w0); }
 BN_FN bool lane_pair_all_zero(const Fe &a) { bool z = fe_is_zero(a); return z && lane_partner_flag(z); }
@@ -173,7 +187,7 @@ template <class T> BN_FN Fq2B<T> f2_conj_lazy(const Fq2B<T> &a) { return {lane_p
 template <class T> BN_FN Fq2B<T> f2_zero(const Fq2B<T> *) { return {lane_bcast(TP, fe_zero())}; }
 template <class T> BN_FN Fq2B<T> f2_one(const Fq2B<T> *) { return {lane_pick(lane_bcast(TP, fe_one()), lane_bcast(TP, fe_zero()))}; }
 template <class T, class TAB>
-BN_FN Fq2B<T> f2_const(const Fq2B<T> *, const TAB &tab) { return {lane_pick(lane_bcast(TP, fe_const(tab[0])), lane_bcast(TP, fe_const(tab[1])))}; }
+BN_FN Fq2B<T> f2_const(const Fq2B<T> *, const TAB &tab) { return {lane_const_pick(TP, tab[0], tab[1])}; }
 template <class T> BN_FN Fq2B<T> f2_select(bool take_b, const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_select(take_b, a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_mul(const Fq2B<T> &a, const Fq2B<T> &b) { return {f2b_mul(a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_sqr(const Fq2B<T> &a) { return {f2b_sqr(a.v)}; }

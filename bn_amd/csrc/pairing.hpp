@@ -114,6 +114,7 @@ BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p, const G2Aff<F2> &q, Store &s
             Line<F2> l;
             if (pass == 0) {
                 if (j != 0) f = f12_sqr(f);                                         // f == 1 in the first step
+                BN_COMPILER_FENCE();                                                // R is fetched AFTER the squaring
                 G2Proj<F2> r = st.get_r();
                 l = doubling_step(r);
                 st.put_r(r);
@@ -212,7 +213,10 @@ BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f, Tbl &tbl) {
         if (mul) res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, mul - 1}, ((w >> 4) & 1) != 0);
         if (put) tbl.put(put - 1, res);
     }
-    return f12_conj(res);
+    // hand a COPY to the out-of-line conjugation: a reference to `res` itself would pin the loop-carried value to a stack
+    // slot (its address escapes), and every iteration would go through private memory
+    const Fq12<F2> last = res;
+    return f12_conj(last);
 }
 template <class F2>
 BN_FN Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {

@@ -9,6 +9,7 @@ struct FeP { Fe v[2]; };
 BN_FN FeP lane_partner(const FeP &x) { return {{x.v[1], x.v[0]}}; }
 BN_FN FeP lane_pick(const FeP &even_choice, const FeP &odd_choice) { return {{even_choice.v[0], odd_choice.v[1]}}; }
 BN_FN FeP lane_bcast(const FeP *, const Fe &x) { return {{x, x}}; }
+template <class TAB> BN_FN FeP lane_const_pick(const FeP *, const TAB &even_tab, const TAB &odd_tab) { return {{fe_const(even_tab), fe_const(odd_tab)}}; }
 BN_FN FeP fe_add(const FeP &a, const FeP &b) { return {{fe_add(a.v[0], b.v[0]), fe_add(a.v[1], b.v[1])}}; }
 BN_FN FeP fe_dbl(const FeP &a) { return fe_add(a, a); }
 template <int LB, int K> BN_FN FeP fe_sub(const FeP &a, const FeP &b) { return {{fe_sub<LB, K>(a.v[0], b.v[0]), fe_sub<LB, K>(a.v[1], b.v[1])}}; }

@@ -6,7 +6,7 @@ import collections, csv, glob, json, pathlib, sys
 
 def load(d):
     agg = collections.defaultdict(lambda: collections.defaultdict(list)); meta = {}
-    for f in glob.glob(str(pathlib.Path(d) / "*counter_collection.csv")):
+    for f in glob.glob(str(pathlib.Path(d) / "**" / "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("::")[-1].split("(")[0]
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

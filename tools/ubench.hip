@@ -114,6 +114,48 @@ KERNEL_BEGIN(k_cndmask_indep)
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[u & 7]) : "v"(a) : );
 KERNEL_END
+KERNEL_BEGIN(k_cndmask_e64_indep)      // VOP3 form with the condition in an SGPR pair (what `cond ? a : b` compiles to)
+    uint64_t m = 0x5555555555555555ull;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[u & 7]) : "v"(a), "s"(m));
+KERNEL_END
+KERNEL_BEGIN(k_bfi_indep)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(r[u & 7]) : "v"(a), "v"(b));
+KERNEL_END
+KERNEL_BEGIN(k_xor_indep)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[u & 7]) : "v"(a));
+KERNEL_END
+KERNEL_BEGIN(k_mov_indep)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_mov_b32 %0, %1" : "=v"(r[u & 7]) : "v"(a));
+KERNEL_END
+KERNEL_BEGIN(k_mov_dpp_indep)          // partner exchange of the lane-pair mapping
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[u & 7]));
+KERNEL_END
+KERNEL_BEGIN(k_and_or_indep)           // v_and_or_b32 (VOP3, 3 operands)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r[u & 7]) : "v"(a), "v"(b));
+KERNEL_END
+KERNEL_BEGIN(k_alignbit_indep)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(r[u & 7]) : "v"(a));
+KERNEL_END
+KERNEL_BEGIN(k_ashr_indep)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(r[u & 7]));
+KERNEL_END
+KERNEL_BEGIN(k_sub_lit_indep)          // VOP2 with a 32-bit literal
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(r[u & 7]));
+KERNEL_END
+KERNEL_BEGIN(k_mad_lit_sgpr)           // mad with an SGPR multiplier (the q limbs of the Montgomery reduction)
+    uint32_t sq = 0x187cfd47u;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[u & 7]) : "v"(a), "s"(sq) : "vcc");
+KERNEL_END
 // mixed: one quarter-rate mad followed by two full-rate adds on other registers (the CIOS inner step)
 KERNEL_BEGIN(k_mix_mad_2add)
 #pragma unroll
@@ -144,7 +186,11 @@ int main() {
         {"v_lshrrev_b64 indep", k_lshrrev_b64_indep, UNROLL}, {"v_mad_u32_u24 indep", k_mad_u32_u24_indep, UNROLL},
         {"v_mul_hi_u32_u24 indep", k_mul_hi_u32_u24_indep, UNROLL}, {"v_fma_f64 indep", k_fma_f64_indep, UNROLL},
         {"v_fma_f64 dep", k_fma_f64_dep, UNROLL}, {"v_add_f64 indep", k_add_f64_indep, UNROLL},
-        {"v_cndmask indep", k_cndmask_indep, UNROLL},
+        {"v_cndmask vcc", k_cndmask_indep, UNROLL}, {"v_cndmask_e64 sgpr", k_cndmask_e64_indep, UNROLL},
+        {"v_bfi_b32", k_bfi_indep, UNROLL}, {"v_xor_b32", k_xor_indep, UNROLL}, {"v_mov_b32", k_mov_indep, UNROLL},
+        {"v_mov_b32_dpp quad", k_mov_dpp_indep, UNROLL}, {"v_and_or_b32", k_and_or_indep, UNROLL},
+        {"v_alignbit_b32", k_alignbit_indep, UNROLL}, {"v_ashrrev_i32", k_ashr_indep, UNROLL},
+        {"v_and_b32 literal", k_sub_lit_indep, UNROLL}, {"v_mad_u64_u32 sgpr", k_mad_lit_sgpr, UNROLL},
         {"mix 1 mad + 2 add", k_mix_mad_2add, 18},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
