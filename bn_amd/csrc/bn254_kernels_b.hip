@@ -10,8 +10,30 @@
 #ifndef BN_WAVES
 #define BN_WAVES 2          // resident waves per SIMD the kernels are compiled for (256 VGPRs each)
 #endif
+// ... and, since the measurement of round 1f, the multiplier- and reduction-sized leaves as well: without calls there is no
+// argument marshalling (v_mov was ~45 % of the non-leaf instructions) and no caller-saved/callee-saved split of the register
+// file.  The Miller loop body becomes ~160 KB of straight-line code (beyond the 64 KB instruction cache), and is still 7 %
+// faster than the call-based build (profiles/r01g_*).  -DBN_B_CALL_LEAVES restores the calls.
+#ifndef BN_B_CALL_LEAVES
+#define BN_LEAF_MUL __device__ __forceinline__
+#define BN_LEAF_RED __device__ __forceinline__
+#endif
+#ifdef BN_B_CALL_MUL               // experiments: call only one of the two leaf classes
+#undef BN_LEAF_MUL
+#endif
+#ifdef BN_B_CALL_RED
+#undef BN_LEAF_RED
+#endif
 #ifdef BN_B_INLINE_REDUCTIONS
 #define BN_INLINE_REDUCTIONS 1
+#endif
+#ifndef BN_B_BLOCK
+#define BN_B_BLOCK 64
+#endif
+#if BN_B_BLOCK > 64
+// several waves per workgroup: re-align them at every loop step so that they walk the (larger than the instruction cache)
+// loop bodies together and share the instruction fetches
+#define BN_LOOP_SYNC() __syncthreads()
 #endif
 #include <hip/hip_runtime.h>
 #include "curve.hpp"
@@ -20,7 +42,7 @@
 using namespace bn254;
 
 namespace {
-constexpr int BLOCK = 64;
+constexpr int BLOCK = BN_B_BLOCK;
 typedef Fq2B<Fe> F2;
 
 // Miller-loop state parked in LDS: 7 field elements x 9 limbs = 63 dwords per lane, laid out [dword][lane] so that a wave's

@@ -37,6 +37,12 @@
 #ifndef BN_LEAF
 #define BN_LEAF __device__ __noinline__ inline
 #endif
+#ifndef BN_LEAF_MUL                 // the multiplier-sized leaves (fe_mul, f2b_mul, f2b_sqr)
+#define BN_LEAF_MUL BN_LEAF
+#endif
+#ifndef BN_LEAF_RED                 // the reduction-sized leaves (fe_lc3 family)
+#define BN_LEAF_RED BN_LEAF
+#endif
 #ifndef BN_COARSE
 #define BN_COARSE __device__ __noinline__ inline
 #endif
@@ -46,6 +52,9 @@
 #define BN254_CONSTANT __device__ constexpr
 // keeps loads that follow in the source from being scheduled above this point (used where early loads only cause spills)
 #define BN_COMPILER_FENCE() asm volatile("" ::: "memory")
+#endif
+#ifndef BN_LOOP_SYNC                // optional workgroup barrier at the top of the long loop bodies (see bn254_kernels_b.hip)
+#define BN_LOOP_SYNC() ((void)0)
 #endif
 #include "bn254_constants.hpp"
 
@@ -144,14 +153,14 @@ BN_FN u32x9 bn_tov(const Fe &f) {
     BN_LEAF u32x9 NAME##_leaf(u32x9 a) { return bn_tov(BODY(bn_unv(a))); }                       \
     BN_FN Fe NAME(const Fe &a) { return bn_unv(NAME##_leaf(bn_tov(a))); }
 #define BN_LEAF2(NAME, BODY)                                                                      \
-    BN_LEAF u32x9 NAME##_leaf(u32x9 a, u32x9 b) { return bn_tov(BODY(bn_unv(a), bn_unv(b))); }   \
+    BN_LEAF_MUL u32x9 NAME##_leaf(u32x9 a, u32x9 b) { return bn_tov(BODY(bn_unv(a), bn_unv(b))); }   \
     BN_FN Fe NAME(const Fe &a, const Fe &b) { return bn_unv(NAME##_leaf(bn_tov(a), bn_tov(b))); }
 #if defined(BN_INLINE_REDUCTIONS)
 #define BN_LEAF3T(NAME, BODY)                                                                     \
     template <int C1, int C2, int C3> BN_FN Fe NAME(const Fe &a, const Fe &b, const Fe &c) { return BODY<C1, C2, C3>(a, b, c); }
 #else
 #define BN_LEAF3T(NAME, BODY)                                                                     \
-    template <int C1, int C2, int C3> BN_LEAF u32x9 NAME##_leaf(u32x9 a, u32x9 b, u32x9 c) {     \
+    template <int C1, int C2, int C3> BN_LEAF_RED u32x9 NAME##_leaf(u32x9 a, u32x9 b, u32x9 c) {     \
         return bn_tov(BODY<C1, C2, C3>(bn_unv(a), bn_unv(b), bn_unv(c)));                         \
     }                                                                                             \
     template <int C1, int C2, int C3> BN_FN Fe NAME(const Fe &a, const Fe &b, const Fe &c) {      \

@@ -162,8 +162,8 @@ BN_FN T f2b_sqr_body(const T &a) {
 template <class T> BN_FN T f2b_mul(const T &a, const T &b) { return f2b_mul_body(a, b); }
 template <class T> BN_FN T f2b_sqr(const T &a) { return f2b_sqr_body(a); }
 #else
-BN_LEAF u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_body(bn_unv(a), bn_unv(b))); }
-BN_LEAF u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_body(bn_unv(a))); }
+BN_LEAF_MUL u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_body(bn_unv(a), bn_unv(b))); }
+BN_LEAF_MUL u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_body(bn_unv(a))); }
 BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a), bn_tov(b))); }
 BN_FN Fe f2b_sqr(const Fe &a) { return bn_unv(f2b_sqr_leaf(bn_tov(a))); }
 #endif

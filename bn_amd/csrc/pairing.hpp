@@ -111,6 +111,7 @@ BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p, const G2Aff<F2> &q, Store &s
         if (j == ND + 1) { G2Aff<F2> b2 = mul_by_q(st.get_base()); b2.y = f2_neg(b2.y); st.put_base(b2); }   // -pi^2(Q)   :579
 #pragma unroll 1
         for (int pass = tail ? 1 : 0; pass < (digit != 0 ? 2 : 1); ++pass) {
+            BN_LOOP_SYNC();
             Line<F2> l;
             if (pass == 0) {
                 if (j != 0) f = f12_sqr(f);                                         // f == 1 in the first step
@@ -206,6 +207,7 @@ BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f, Tbl &tbl) {
     Fq12<F2> res = f;
 #pragma unroll 1
     for (int s = 0; s < k::EXP_STEPS; ++s) {
+        BN_LOOP_SYNC();
         const int w = k::EXP_SCHED[s];
         const int get = (w >> 8) & 7, mul = (w >> 1) & 7, put = (w >> 5) & 7;
         if (get) res = Fq12<F2>{tbl.c0(get - 1), tbl.c1(get - 1)};
