@@ -9,6 +9,7 @@ HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("BN254_LIB_PATH", HERE / "libbn254_hip.so"))     # override: kernel experiments only
 SRC = HERE / "csrc" / "bn254_hip.hip"
 SRC_B = HERE / "csrc" / "bn254_kernels_b.hip"
+SRC_MUL = HERE / "csrc" / "bn254_kernels_mul.hip"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 _VP = C.c_void_p
@@ -53,12 +54,12 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
 
 def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU; the .so is kept in-tree so it travels to the GPU box."""
-    deps = [SRC, SRC_B] + sorted((HERE / "csrc").glob("*.hpp")) + [HERE.parent / "include" / "bn254_hip.h"]
+    deps = [SRC, SRC_B, SRC_MUL] + sorted((HERE / "csrc").glob("*.hpp")) + [HERE.parent / "include" / "bn254_hip.h"]
     if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(d.stat().st_mtime for d in deps):
         return LIB_PATH
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
     cmd += os.environ.get("BN254_EXTRA_HIPCC_FLAGS", "").split()           # experiments only
-    cmd += [str(SRC), str(SRC_B), "-o", str(LIB_PATH)]
+    cmd += [str(SRC), str(SRC_B), str(SRC_MUL), "-o", str(LIB_PATH)]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

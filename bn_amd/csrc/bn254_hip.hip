@@ -153,6 +153,8 @@ extern "C" size_t bn254_final_exp_table_bytes_B(size_t n);
 extern "C" int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
 extern "C" int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
 extern "C" int bn254_launch_gt_product_B(const void *in, void *out, size_t n, unsigned chunk, hipStream_t s);
+extern "C" int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);   // bn254_kernels_mul.hip
+extern "C" int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);
 extern "C" int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
 extern "C" int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hipStream_t s);
 
@@ -361,6 +363,8 @@ static int mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void
     if (!d_p || !d_k || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     Scope sc(ctx, (hipStream_t)stream, g == 1 ? "g1_mul" : "g2_mul");
+    if (ctx->mapping == 1)          // registers-resident chains; G2 in the lane-pair mapping (bn254_kernels_mul.hip)
+        return g == 1 ? bn254_launch_g1_mul_M(d_p, d_k, d_out, n, normalize, (hipStream_t)stream) : bn254_launch_g2_mul_M(d_p, d_k, d_out, n, normalize, (hipStream_t)stream);
     if (g == 1)
         hipLaunchKernelGGL(bn254_g1_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
     else

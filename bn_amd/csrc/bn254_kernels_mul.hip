@@ -1,0 +1,70 @@
+// G * Fr kernels of the BN254 engine for MI355X (gfx950): `Mul<Fr> for G<P>` (src/groups/mod.rs:250-270) batched.
+//   bn254_g1_mul_M   one lane per point (G1 is over Fq: a Jacobian point is 27 VGPRs)
+//   bn254_g2_mul_M   one point per lane PAIR (Fq2B: even lane = c0, odd lane = c1 of every coordinate, DPP exchange)
+// normalize = 0 runs the reference's own double-and-add chain (raw Jacobian limbs identical to the crate's, used to make
+// benchmark inputs with z != 1); normalize = 1 runs fixed 4-bit windows and returns the normalized point.
+//
+// This translation unit inlines the point operations and the multiplier leaves: the running point stays in registers for the
+// whole chain (in the call-based build of bn254_hip.hip every doubling went through private memory: 6 / 27 GB of HBM traffic
+// per 2^16 G1 / G2 multiplications).  Only the 16-entry window table is a per-lane array in private memory.
+#define BN_COARSE __device__ __forceinline__
+#define BN_LEAF_MUL __device__ __forceinline__
+#define BN_LEAF_RED __device__ __forceinline__
+#include <hip/hip_runtime.h>
+#include "curve.hpp"
+#include "io.hpp"
+
+using namespace bn254;
+
+namespace {
+constexpr int BLOCK = 64;
+typedef Fq2B<Fe> F2;
+
+template <class F>
+__device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km, int normalize) {
+    uint32_t kw[8], raw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kw[i] = km[i];
+    fr_from_mont(kw, raw);
+    if (normalize) return jac_normalize<F>(scalar_mul_windowed<F>(p, raw));
+    return scalar_mul_reference_chain<F>(p, raw);
+}
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g1_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const uint32_t *w = p + 24u * idx;
+    Jac<FqField> pt = {fe_from_u32x8(w), fe_from_u32x8(w + 8), fe_from_u32x8(w + 16)};
+    Jac<FqField> r = run_chain<FqField>(pt, k + 8u * idx, normalize);
+    uint32_t *o = out + 24u * idx;
+    fe_to_u32x8(r.x, o); fe_to_u32x8(r.y, o + 8); fe_to_u32x8(r.z, o + 16);
+}
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;                       // keep both lanes of every pair active for the DPP exchanges
+    const uint32_t *w = p + 48u * pair;
+    typedef Fq2Field<F2> F;
+    Jac<F> pt = {f2_load((const F2 *)nullptr, w), f2_load((const F2 *)nullptr, w + 16), f2_load((const F2 *)nullptr, w + 32)};
+    Jac<F> r = run_chain<F>(pt, k + 8u * pair, normalize);
+    if (live) {
+        uint32_t *o = out + 48u * pair;
+        f2_store(r.x, o); f2_store(r.y, o + 16); f2_store(r.z, o + 32);
+    }
+}
+}  // namespace
+
+extern "C" {
+int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s) {
+    unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_g1_mul_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, normalize);
+    return (int)hipGetLastError();
+}
+int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_g2_mul_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, normalize);
+    return (int)hipGetLastError();
+}
+}

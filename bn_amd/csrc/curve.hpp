@@ -57,6 +57,9 @@ BN_COARSE Jac<F> jac_double(const Jac<F> &p) {
     r.z = F::template lc3<2, 0, 0>(F::mul(p.y, p.z), p.y, p.y);
     return r;
 }
+// out-of-line copy for the never-taken equal-points branch below (keeps the inlined builds small)
+template <class F>
+BN_OUTER Jac<F> jac_double_cold(const Jac<F> &p) { return jac_double(p); }
 // groups/mod.rs:275-311, all branches (zero operands, equal points) as per-lane selects; the doubling for equal points is a
 // divergent branch that no lane takes for valid prime-order inputs and scalars < r.  pz / qz: "p (q) is the point at infinity".
 template <class F>
@@ -76,7 +79,8 @@ BN_COARSE Jac<F> jac_add_flags(const Jac<F> &p, const Jac<F> &q, bool pz, bool q
     r.y = F::template lc3<1, -2, 0>(F::mul(rr, F::template lc3<1, -1, 0>(v, r.x, v)), F::mul(s1, j), j);
     r.z = F::mul(F::template lc3<1, -1, -1>(F::sqr(F::template lc3<1, 1, 0>(p.z, q.z, q.z)), z1s, z2s), h);
     if (same) {                                    // groups/mod.rs:291-292
-        Jac<F> d = jac_double(p);
+        const Jac<F> pc = p;                       // a copy: `p` itself must not escape by reference (it would live in memory)
+        Jac<F> d = jac_double_cold(pc);
         r.x = F::select(same, r.x, d.x); r.y = F::select(same, r.y, d.y); r.z = F::select(same, r.z, d.z);
     }
     r.x = F::select(qz, r.x, p.x); r.y = F::select(qz, r.y, p.y); r.z = F::select(qz, r.z, p.z);     // :280-282

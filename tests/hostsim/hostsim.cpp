@@ -131,6 +131,10 @@ EXPORT void hsb_pairing(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
     if (inf) f = f12_one<F2B>();
     f12_store(f, o);
 }
+// G2 * Fr in the lane-pair mapping (bn254_kernels_mul.hip bn254_g2_mul_M)
+static F2B ld2b(const uint32_t *w) { return f2_load((F2B *)0, w); }
+static void st2b(const F2B &a, uint32_t *w) { f2_store(a, w); }
+EXPORT void hsb_g2_mul(const uint32_t *p, const uint32_t *k, int normalize, uint32_t *o) { hs_mul_generic<Fq2Field<F2B>, 16>(p, k, o, normalize, ld2b, st2b); }
 // pairing through the NAF Miller schedule (what the pairing kernels run): only the exponentiated value is comparable
 EXPORT void hsb_pairing_naf(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
     bool inf = words_all_zero(g1 + 16, 8) || words_all_zero(g2 + 32, 16);

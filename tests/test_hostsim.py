@@ -179,7 +179,8 @@ def test_scalar_mul_reference_chain(oracle, hs):
         raw = hs.call("hs_fr_from_mont", k, out_words=8)
         assert sum(int(x) << (64 * i) for i, x in enumerate(raw)) == kv
         for base, fn, w, om, on in ((b1, "hs_g1_mul", 12, oracle.g1_mul, oracle.g1_normalize), (oracle.g1_zero(), "hs_g1_mul", 12, oracle.g1_mul, oracle.g1_normalize),
-                                    (b2, "hs_g2_mul", 24, oracle.g2_mul, oracle.g2_normalize), (oracle.g2_one(), "hs_g2_mul", 24, oracle.g2_mul, oracle.g2_normalize)):
+                                    (b2, "hs_g2_mul", 24, oracle.g2_mul, oracle.g2_normalize), (oracle.g2_one(), "hs_g2_mul", 24, oracle.g2_mul, oracle.g2_normalize),
+                                    (b2, "hsb_g2_mul", 24, oracle.g2_mul, oracle.g2_normalize), (oracle.g2_zero(), "hsb_g2_mul", 24, oracle.g2_mul, oracle.g2_normalize)):
             want = om(base, k)
             assert np.array_equal(hs.call(fn, base, k, 0, out_words=2 * w), want)
             assert np.array_equal(hs.call(fn, base, k, 1, out_words=2 * w), canon_infinity(on(want)))
