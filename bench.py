@@ -147,8 +147,8 @@ def bench_prepared(args, eng, dev, world, rank, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="pairings per GPU per step")
     ap.add_argument("--mapping", type=int, default=None, help="0: one lane per pairing, 1: lane pair per pairing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
