@@ -227,9 +227,10 @@ def main():
             "config": {"workload": f"{n} independent pairings per GPU per step, inputs r*G1 / s*G2 (Jacobian, z != 1) resident in HBM "
                                    "(BASELINE.json configs[1])", "pairings_per_gpu": n, "parallelism": f"dp{world} (sharded, no collective)",
                        "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
-                       "mapping": args.mapping},
+                       "mapping": 1 if args.mapping is None else args.mapping},
             "roofline": {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": achieved,
                          "peak": PEAK_TMAC32, "unit": "TMAC32/s", "frac": achieved / PEAK_TMAC32, "traffic": traffic,
+                         "hbm_GBps_of_8000": None if traffic is None else traffic / avg_s / 1e9,
                          "avg_launch_ms": avg_s * 1e3, "launches": cnt,
                          "algorithmic_hbm_bytes_per_launch": n * ALGO_BYTES_PER_PAIRING,
                          "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in stats.items()}},
