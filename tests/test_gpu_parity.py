@@ -127,6 +127,10 @@ def test_both_lane_mappings_agree_with_oracle(oracle, mapping):
     P[5] = oracle.g1_zero(); Q[6] = oracle.g2_zero(); P[7] = oracle.g1_one(); Q[7] = oracle.g2_one()
     assert np.array_equal(e.pairing_batch(P, Q), oracle.pairing_batch(P, Q))
     assert np.array_equal(e.pairing_product(P[:33], Q[:33]), oracle.pairing_product(P[:33], Q[:33]))
+    # G * Fr: mapping 0 = call-based kernels with G2 over Fq2A, mapping 1 = inlined kernels with G2 on lane pairs
+    k = _fr(oracle, _scalars(rng, n))
+    assert np.array_equal(e.g1_mul_batch(P, k), canon_infinity(oracle.g1_mul_batch(P, k)))
+    assert np.array_equal(e.g2_mul_batch(Q, k), canon_infinity(oracle.g2_mul_batch(Q, k)))
 
 
 def test_device_resident_path_and_input_generator(oracle):
