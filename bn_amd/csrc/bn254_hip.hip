@@ -144,6 +144,21 @@ __global__ void __launch_bounds__(BLOCK) bn254_g2_decode_k(const uint8_t *in, ui
     status[idx] = g2_decode_record(b, out + 48u * idx);
 }
 
+__global__ void __launch_bounds__(BLOCK) bn254_fr_encode_k(const uint32_t *k, uint8_t *out, uint32_t n) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    uint32_t w[8];
+    for (int i = 0; i < 8; ++i) w[i] = k[8u * idx + i];
+    fr_encode_record(w, out + 32u * idx);
+}
+__global__ void __launch_bounds__(BLOCK) bn254_fr_decode_k(const uint8_t *in, uint32_t *out, int32_t *status, uint32_t n) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    uint8_t b[32];
+    for (int i = 0; i < 32; ++i) b[i] = in[32u * idx + i];
+    status[idx] = fr_decode_record(b, out + 8u * idx);
+}
+
 }  // namespace
 
 // ======================================================================================================== host side
@@ -509,7 +524,7 @@ static int wire_host(bn254_ctx *ctx, int g, int decode, const void *in, void *ou
     if (n == 0) return BN254_OK;
     if (!in || !out || (decode && !status) || n > 0x7fffffffu / 129) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2), rs = g == 1 ? BN254_G1_WIRE_BYTES : BN254_G2_WIRE_BYTES;
+    size_t ps = g == 0 ? sizeof(bn_fr) : g == 1 ? sizeof(bn_g1) : sizeof(bn_g2), rs = g == 0 ? BN254_FR_WIRE_BYTES : g == 1 ? BN254_G1_WIRE_BYTES : BN254_G2_WIRE_BYTES;
     size_t in_b = n * (decode ? rs : ps), out_b = n * (decode ? ps : rs);
     DevBuf din(ctx, 0), dout(ctx, 1), dst(ctx, 2);
     if ((rc = din.alloc(in_b)) || (rc = dout.alloc(out_b)) || (rc = dst.alloc(n * sizeof(int32_t)))) return rc;
@@ -517,6 +532,8 @@ static int wire_host(bn254_ctx *ctx, int g, int decode, const void *in, void *ou
     {
         Scope sc(ctx, ctx->stream, decode ? "wire_decode" : "wire_encode");
         dim3 grid(grid_for(n)), block(BLOCK);
+        if (g == 0 && !decode) hipLaunchKernelGGL(bn254_fr_encode_k, grid, block, 0, ctx->stream, (const uint32_t *)din.p, (uint8_t *)dout.p, (uint32_t)n);
+        if (g == 0 && decode) hipLaunchKernelGGL(bn254_fr_decode_k, grid, block, 0, ctx->stream, (const uint8_t *)din.p, (uint32_t *)dout.p, (int32_t *)dst.p, (uint32_t)n);
         if (g == 1 && !decode) hipLaunchKernelGGL(bn254_g1_encode_k, grid, block, 0, ctx->stream, (const uint32_t *)din.p, (uint8_t *)dout.p, (uint32_t)n);
         if (g == 2 && !decode) hipLaunchKernelGGL(bn254_g2_encode_k, grid, block, 0, ctx->stream, (const uint32_t *)din.p, (uint8_t *)dout.p, (uint32_t)n);
         if (g == 1 && decode) hipLaunchKernelGGL(bn254_g1_decode_k, grid, block, 0, ctx->stream, (const uint8_t *)din.p, (uint32_t *)dout.p, (int32_t *)dst.p, (uint32_t)n);
@@ -528,6 +545,8 @@ static int wire_host(bn254_ctx *ctx, int g, int decode, const void *in, void *ou
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;
 }
+int bn254_fr_encode_batch(bn254_ctx *ctx, const bn_fr *k, uint8_t *out, size_t n) { return wire_host(ctx, 0, 0, k, out, nullptr, n); }
+int bn254_fr_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_fr *out, int32_t *status, size_t n) { return wire_host(ctx, 0, 1, in, out, status, n); }
 int bn254_g1_encode_batch(bn254_ctx *ctx, const bn_g1 *p, uint8_t *out, size_t n) { return wire_host(ctx, 1, 0, p, out, nullptr, n); }
 int bn254_g2_encode_batch(bn254_ctx *ctx, const bn_g2 *p, uint8_t *out, size_t n) { return wire_host(ctx, 2, 0, p, out, nullptr, n); }
 int bn254_g1_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g1 *out, int32_t *status, size_t n) { return wire_host(ctx, 1, 1, in, out, status, n); }

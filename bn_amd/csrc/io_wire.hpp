@@ -165,4 +165,67 @@ BN_FN int g2_decode_record(const uint8_t *in, uint32_t *out) {
     return status;
 }
 
+// ---- Fr records (fields/fp.rs:24-36 for Fr): 32 bytes big-endian of the canonical integer; decode rejects values >= r -----
+// a * b / 2^256 mod r on 8 x u32 words (word-serial Montgomery; used only here and for the scalar extraction in curve.hpp)
+BN_FN void fr_montmul(const uint32_t *a, const uint32_t *b, uint32_t *out) {
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t x = (uint64_t)a[i] * b[j] + t[j] + c;
+            t[j] = (uint32_t)x; c = x >> 32;
+        }
+        uint64_t x = (uint64_t)t[8] + c;
+        t[8] = (uint32_t)x; t[9] = (uint32_t)(x >> 32);
+        uint32_t m = t[0] * k::FR_INV32;
+        c = ((uint64_t)m * k::FR_MOD32[0] + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            uint64_t y = (uint64_t)m * k::FR_MOD32[j] + t[j] + c;
+            t[j - 1] = (uint32_t)y; c = y >> 32;
+        }
+        uint64_t y = (uint64_t)t[8] + c;
+        t[7] = (uint32_t)y;
+        t[8] = t[9] + (uint32_t)(y >> 32);
+        t[9] = 0;
+    }
+    uint32_t d[8];
+    int64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int64_t v = (int64_t)t[i] - (int64_t)k::FR_MOD32[i] + br;
+        d[i] = (uint32_t)v; br = v >> 32;
+    }
+    bool ge = (t[8] != 0) || (br == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = ge ? d[i] : t[i];
+}
+BN_FN bool words_lt_r(const uint32_t *w) {
+    int64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { int64_t v = (int64_t)w[i] - (int64_t)k::FR_MOD32[i] + br; br = v >> 32; }
+    return br != 0;
+}
+BN_FN void fr_encode_record(const uint32_t *km, uint8_t *out) {
+    uint32_t raw[8];
+    fr_from_mont(km, raw);
+    words_to_be<8>(raw, out);
+}
+BN_FN int fr_decode_record(const uint8_t *in, uint32_t *out) {
+    uint32_t w[8], r2[8];
+    be_to_words<8>(in, w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2[i] = k::FR_R2_32[i];
+    bool ok = words_lt_r(w);
+    uint32_t m[8];
+    fr_montmul(w, r2, m);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = ok ? m[i] : 0u;                  // rejected records come back as Fr::zero()
+    return ok ? WIRE_OK : WIRE_E_NOT_LESS_THAN_MODULUS;
+}
+
 }  // namespace bn254

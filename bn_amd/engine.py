@@ -96,6 +96,15 @@ class Engine:
         return out
 
     # ---- wire format (fixed-size records: G1 65 bytes, G2 129 bytes)
+    def fr_encode_batch(self, k):
+        k = _arr(k, 4); out = np.empty((k.shape[0], 32), np.uint8)
+        _native.check(self._lib.bn254_fr_encode_batch(self._h, _p(k), _p(out), k.shape[0])); return out
+
+    def fr_decode_batch(self, b):
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32); n = b.shape[0]
+        out = np.empty((n, 4), np.uint64); st = np.empty(n, np.int32)
+        _native.check(self._lib.bn254_fr_decode_batch(self._h, _p(b), _p(out), _p(st), n)); return out, st
+
     def g1_encode_batch(self, p):
         p = _arr(p, G1_WORDS); out = np.empty((p.shape[0], 65), np.uint8)
         _native.check(self._lib.bn254_g1_encode_batch(self._h, _p(p), _p(out), p.shape[0])); return out

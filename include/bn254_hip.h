@@ -93,8 +93,11 @@ int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *ou
    what the crate validates, in its order, and reports per record: 0 ok, 1 "integer is not less than modulus", 2 "integer not
    less than modulus squared", 3 "invalid leading byte", 4 "point is not on the curve", 5 "point is not in the subgroup" (G2
    only).  A rejected record decodes to G::zero(). */
+#define BN254_FR_WIRE_BYTES 32    /* Fr: big-endian canonical integer (fields/fp.rs:24-36); decode status 0 or 1, rejected -> Fr::zero() */
 #define BN254_G1_WIRE_BYTES 65
 #define BN254_G2_WIRE_BYTES 129
+int bn254_fr_encode_batch(bn254_ctx *ctx, const bn_fr *k, uint8_t *out, size_t n);
+int bn254_fr_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_fr *out, int32_t *status, size_t n);
 int bn254_g1_encode_batch(bn254_ctx *ctx, const bn_g1 *p, uint8_t *out, size_t n);
 int bn254_g2_encode_batch(bn254_ctx *ctx, const bn_g2 *p, uint8_t *out, size_t n);
 int bn254_g1_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g1 *out, int32_t *status, size_t n);

@@ -714,6 +714,14 @@ static int fq_decode(const uint8_t *in, fq *out) {                        /* fp.
     if (u256_cmp(&a, &FQ_MOD) >= 0) return BNO_E_NOT_LESS_THAN_MODULUS;
     u256_mul(&a, &FQ_R2, &FQ_MOD, FQ_INV); *out = a; return BNO_OK;
 }
+EXPORT void bno_fr_encode(const u64 *k, uint8_t *out) {                    /* fp.rs:24-29 instantiated for Fr */
+    u256 a; memcpy(&a, k, 32); a = fr_to_raw(a); u256_encode_be(&a, out);
+}
+EXPORT int bno_fr_decode(const uint8_t *in, u64 *out) {                    /* fp.rs:31-35 */
+    u256 a; u256_decode_be(in, &a);
+    if (u256_cmp(&a, &FR_MOD) >= 0) { memset(out, 0, 32); return BNO_E_NOT_LESS_THAN_MODULUS; }
+    u256_mul(&a, &FR_R2, &FR_MOD, FR_INV); memcpy(out, &a, 32); return BNO_OK;
+}
 static void fq2_encode(fq2 a, uint8_t *out) {                             /* fq2.rs:31-38 */
     u256 one = {{1, 0, 0, 0}}, c0 = a.c0, c1 = a.c1;
     u256_mul(&c0, &one, &FQ_MOD, FQ_INV); u256_mul(&c1, &one, &FQ_MOD, FQ_INV);

@@ -166,6 +166,11 @@ class Oracle:
     def g2_mul_batch_jacobian(self, p, k, nthreads=None): return self._mulb("bno_g2_mul_batch_jacobian", 24, p, k, nthreads)
 
     # ---- wire format (fixed-size batch records: G1 65 bytes, G2 129 bytes)
+    def fr_encode(self, k):
+        o = np.zeros(32, np.uint8); self.lib.bno_fr_encode(_p(_u64(k, 4)), o.ctypes.data_as(C.c_void_p)); return o
+    def fr_decode(self, b):
+        b = np.ascontiguousarray(b, np.uint8); o = np.zeros(4, np.uint64)
+        return int(self.lib.bno_fr_decode(b.ctypes.data_as(C.c_void_p), _p(o))), o
     def g1_encode(self, p):
         o = np.zeros(65, np.uint8); self.lib.bno_g1_encode(_p(_u64(p, 12)), o.ctypes.data_as(C.c_void_p)); return o
     def g2_encode(self, p):

@@ -168,5 +168,7 @@ EXPORT void hsb_miller_only(const uint32_t *g1, const uint32_t *g2, uint32_t *o)
 // wire format through the engine code
 EXPORT void hs_g1_encode(const uint32_t *p, uint8_t *o) { g1_encode_record(p, o); }
 EXPORT void hs_g2_encode(const uint32_t *p, uint8_t *o) { g2_encode_record(p, o); }
+EXPORT void hs_fr_encode(const uint32_t *k, uint8_t *out) { fr_encode_record(k, out); }
+EXPORT int hs_fr_decode(const uint8_t *in, uint32_t *out) { return fr_decode_record(in, out); }
 EXPORT int hs_g1_decode(const uint8_t *in, uint32_t *o) { return g1_decode_record(in, o); }
 EXPORT int hs_g2_decode(const uint8_t *in, uint32_t *o) { return g2_decode_record(in, o); }

@@ -272,6 +272,16 @@ def test_wire_format_on_gpu(oracle, eng):
         rc, want = oracle.g2_decode(b2[i]); assert s2[i] == rc
         assert np.array_equal(d2[i], want if rc == 0 else oracle.g2_zero())
     assert list(s1[10:13]) == [3, 1, 4] and list(s2[10:14]) == [3, 2, 4, 5]
+    # Fr records
+    k = _fr(oracle, [0, 1, M.R_ORD - 1] + _scalars(rng, 60))
+    ek = eng.fr_encode_batch(k)
+    for i in range(k.shape[0]):
+        assert np.array_equal(ek[i], oracle.fr_encode(k[i]))
+    bk = ek.copy(); bk[5] = np.frombuffer(M.R_ORD.to_bytes(32, "big"), np.uint8); bk[6] = 255
+    dk, sk = eng.fr_decode_batch(bk)
+    assert list(sk[4:8]) == [0, 1, 1, 0] and not dk[5].any() and not dk[6].any()
+    mask = np.ones(k.shape[0], bool); mask[5:7] = False
+    assert np.array_equal(dk[mask], k[mask])
     assert np.array_equal(d1[7], oracle.g1_normalize(P[7])) and np.array_equal(d2[7], oracle.g2_normalize(Q[7]))
 
 

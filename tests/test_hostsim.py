@@ -231,6 +231,15 @@ def test_wire_format_through_engine_code(oracle, hs):
     b = oracle.g2_encode(Q).copy(); b[1:65] = 255; assert dec("hs_g2_decode", b, 24)[0] == oracle.g2_decode(b)[0] == 2
     bad = g2_point_outside_subgroup()
     assert oracle.g2_decode(bad)[0] == 5 and dec("hs_g2_decode", bad, 24)[0] == 5
+    # Fr records (fields/fp.rs:24-36): canonical big-endian integer, rejected when >= r
+    for v in (0, 1, M.R_ORD - 1, 1 << 253, int.from_bytes(rng.bytes(40), "little") % M.R_ORD):
+        k = oracle.fp_from_int(FR, v)
+        e = enc("hs_fr_encode", k, 32)
+        assert bytes(e) == v.to_bytes(32, "big") == bytes(oracle.fr_encode(k))
+        rc, d = dec("hs_fr_decode", e, 4); assert rc == 0 and np.array_equal(d, k)
+    for v in (M.R_ORD, M.R_ORD + 5, (1 << 256) - 1):
+        b = np.frombuffer(v.to_bytes(32, "big"), np.uint8)
+        rc, d = dec("hs_fr_decode", b, 4); assert rc == 1 == oracle.fr_decode(b)[0] and not d.any()
 
 
 def test_golden_fixtures_through_engine_code(hs, goldens):
