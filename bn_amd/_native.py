@@ -25,6 +25,8 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_pairing_product": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_g1_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_g2_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_g1_add_batch": [_VP, _VP, _VP, _VP, _SZ, C.c_int],
+    "bn254_g2_add_batch": [_VP, _VP, _VP, _VP, _SZ, C.c_int],
     "bn254_fr_encode_batch": [_VP, _VP, _VP, _SZ],
     "bn254_fr_decode_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_g1_encode_batch": [_VP, _VP, _VP, _SZ],

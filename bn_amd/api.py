@@ -99,6 +99,12 @@ class G1(_Point):
     def random(rng): return G1.one() * Fr.random(rng)        # groups/mod.rs:220-222
     def __mul__(self, k):                 # lib.rs:116-120 (result returned normalized)
         return G1(default_engine().g1_mul_batch(self.limbs, k.limbs)[0])
+    def __add__(self, o):                 # lib.rs:103-106 (the reference's Jacobian limbs)
+        return G1(default_engine().g1_add_batch(self.limbs, o.limbs)[0])
+    def __sub__(self, o):                 # lib.rs:108-111
+        return G1(default_engine().g1_add_batch(self.limbs, o.limbs, negate_b=True)[0])
+    def __neg__(self):                    # lib.rs:113-114
+        return G1(default_engine().g1_add_batch(G1.zero().limbs, self.limbs, negate_b=True)[0])
 
 
 _G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
@@ -122,6 +128,12 @@ class G2(_Point):
     def random(rng): return G2.one() * Fr.random(rng)
     def __mul__(self, k):
         return G2(default_engine().g2_mul_batch(self.limbs, k.limbs)[0])
+    def __add__(self, o):                 # lib.rs:146-149
+        return G2(default_engine().g2_add_batch(self.limbs, o.limbs)[0])
+    def __sub__(self, o):
+        return G2(default_engine().g2_add_batch(self.limbs, o.limbs, negate_b=True)[0])
+    def __neg__(self):
+        return G2(default_engine().g2_add_batch(G2.zero().limbs, self.limbs, negate_b=True)[0])
 
 
 class Gt:

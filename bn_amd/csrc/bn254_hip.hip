@@ -170,6 +170,8 @@ extern "C" int bn254_launch_miller_prepared_B(const void *p, const void *coeffs,
 extern "C" int bn254_launch_gt_product_B(const void *in, void *out, size_t n, unsigned chunk, hipStream_t s);
 extern "C" int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);   // bn254_kernels_mul.hip
 extern "C" int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);
+extern "C" int bn254_launch_g1_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s);
+extern "C" int bn254_launch_g2_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s);
 extern "C" int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
 extern "C" int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hipStream_t s);
 
@@ -551,6 +553,28 @@ int bn254_g1_encode_batch(bn254_ctx *ctx, const bn_g1 *p, uint8_t *out, size_t n
 int bn254_g2_encode_batch(bn254_ctx *ctx, const bn_g2 *p, uint8_t *out, size_t n) { return wire_host(ctx, 2, 0, p, out, nullptr, n); }
 int bn254_g1_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g1 *out, int32_t *status, size_t n) { return wire_host(ctx, 1, 1, in, out, status, n); }
 int bn254_g2_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g2 *out, int32_t *status, size_t n) { return wire_host(ctx, 2, 1, in, out, status, n); }
+// G + G / G - G on host buffers
+static int add_host(bn254_ctx *ctx, int g, const void *a, const void *b, void *out, size_t n, int negate_b) {
+    int rc = get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
+    if (!a || !b || !out || n > 0x7fffffffu / 48) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf da(ctx, 0), db(ctx, 1), dout(ctx, 2);
+    if ((rc = da.alloc(n * ps)) || (rc = db.alloc(n * ps)) || (rc = dout.alloc(n * ps))) return rc;
+    HIP_TRY(hipMemcpyAsync(da.p, a, n * ps, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db.p, b, n * ps, hipMemcpyHostToDevice, ctx->stream));
+    {
+        Scope sc(ctx, ctx->stream, g == 1 ? "g1_add" : "g2_add");
+        rc = g == 1 ? bn254_launch_g1_add_M(da.p, db.p, dout.p, n, negate_b, ctx->stream) : bn254_launch_g2_add_M(da.p, db.p, dout.p, n, negate_b, ctx->stream);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n * ps, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_g1_add_batch(bn254_ctx *ctx, const bn_g1 *a, const bn_g1 *b, bn_g1 *out, size_t n, int negate_b) { return add_host(ctx, 1, a, b, out, n, negate_b); }
+int bn254_g2_add_batch(bn254_ctx *ctx, const bn_g2 *a, const bn_g2 *b, bn_g2 *out, size_t n, int negate_b) { return add_host(ctx, 2, a, b, out, n, negate_b); }
 static int gt_binop_host(bn254_ctx *ctx, int op, const bn_gt *a, const void *b, size_t bsize, bn_gt *out, size_t n) {
     int rc = get_ctx(ctx); if (rc) return rc;
     if (n == 0) return BN254_OK;

@@ -54,9 +54,52 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
         f2_store(r.x, o); f2_store(r.y, o + 16); f2_store(r.z, o + 32);
     }
 }
+// a[i] + b[i]  (or a[i] - b[i] = a[i] + (-b[i]): lib.rs:103-114,146-157, groups/mod.rs:275-347): the reference's add-2007-bl
+// with its zero / equal-point branches, so the Jacobian limbs returned are the reference's own
+template <class F>
+__device__ __forceinline__ Jac<F> add_body(const Jac<F> &a, Jac<F> b, int negate_b) {
+    const bool bz = F::is_zero(b.z);
+    if (negate_b) b.y = F::select(bz, F::template lc3<-1, 0, 0>(b.y, b.y, b.y), b.y);     // neg(0) = 0 (groups/mod.rs:334-346)
+    return jac_add_flags<F>(a, b, F::is_zero(a.z), bz);
+}
+__global__ void __launch_bounds__(BLOCK) bn254_g1_add_M(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n, int negate_b) {
+    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const uint32_t *wa = a + 24u * idx, *wb = b + 24u * idx;
+    Jac<FqField> pa = {fe_from_u32x8(wa), fe_from_u32x8(wa + 8), fe_from_u32x8(wa + 16)};
+    Jac<FqField> pb = {fe_from_u32x8(wb), fe_from_u32x8(wb + 8), fe_from_u32x8(wb + 16)};
+    Jac<FqField> r = add_body<FqField>(pa, pb, negate_b);
+    uint32_t *o = out + 24u * idx;
+    fe_to_u32x8(r.x, o); fe_to_u32x8(r.y, o + 8); fe_to_u32x8(r.z, o + 16);
+}
+__global__ void __launch_bounds__(BLOCK) bn254_g2_add_M(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n, int negate_b) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;
+    typedef Fq2Field<F2> F;
+    const uint32_t *wa = a + 48u * pair, *wb = b + 48u * pair;
+    Jac<F> pa = {f2_load((const F2 *)nullptr, wa), f2_load((const F2 *)nullptr, wa + 16), f2_load((const F2 *)nullptr, wa + 32)};
+    Jac<F> pb = {f2_load((const F2 *)nullptr, wb), f2_load((const F2 *)nullptr, wb + 16), f2_load((const F2 *)nullptr, wb + 32)};
+    Jac<F> r = add_body<F>(pa, pb, negate_b);
+    if (live) {
+        uint32_t *o = out + 48u * pair;
+        f2_store(r.x, o); f2_store(r.y, o + 16); f2_store(r.z, o + 32);
+    }
+}
 }  // namespace
 
 extern "C" {
+int bn254_launch_g1_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s) {
+    unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_g1_add_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, (uint32_t)n, negate_b);
+    return (int)hipGetLastError();
+}
+int bn254_launch_g2_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_g2_add_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, (uint32_t)n, negate_b);
+    return (int)hipGetLastError();
+}
 int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s) {
     unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(bn254_g1_mul_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, normalize);

@@ -77,6 +77,15 @@ class Engine:
         _native.check(self._lib.bn254_g2_mul_batch(self._h, _p(p), _p(k), _p(out), p.shape[0]))
         return out
 
+    def g1_add_batch(self, a, b, negate_b=False):
+        """a + b (a - b): the reference's Jacobian limbs (groups/mod.rs:275-347)"""
+        a = _arr(a, G1_WORDS); b = _arr(b, G1_WORDS); out = np.empty_like(a)
+        _native.check(self._lib.bn254_g1_add_batch(self._h, _p(a), _p(b), _p(out), a.shape[0], 1 if negate_b else 0)); return out
+
+    def g2_add_batch(self, a, b, negate_b=False):
+        a = _arr(a, G2_WORDS); b = _arr(b, G2_WORDS); out = np.empty_like(a)
+        _native.check(self._lib.bn254_g2_add_batch(self._h, _p(a), _p(b), _p(out), a.shape[0], 1 if negate_b else 0)); return out
+
     def g2_precompute(self, q):
         """(n,24) G2 -> (n,102,24) line coefficients [ell_0 | ell_vw | ell_vv] (groups/mod.rs:557-588)"""
         q = _arr(q, G2_WORDS)

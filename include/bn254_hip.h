@@ -18,6 +18,7 @@
  *   bn254_pairing_product  fold(Gt::one(), |acc,(p,q)| acc * pairing(p,q))          shootout/main.rs:11-16, lib.rs:175-179
  *   bn254_g1_mul_batch     out[i] = normalize(p[i] * k[i])                          lib.rs:116-120,88-95, groups/mod.rs:250-270
  *   bn254_g2_mul_batch     same over G2                                             lib.rs:159-163,131-138
+ *   bn254_g1/g2_add_batch  out[i] = a[i] + b[i] / a[i] - b[i] (raw Jacobian limbs)       lib.rs:103-114,146-157, groups/mod.rs:275-347
  *   bn254_g2_precompute    coeffs[i][0..102) = q[i].to_affine().precompute().coeffs   groups/mod.rs:557-588 (Q != infinity)
  *   bn254_pairing_prepared_batch  out[i] = final_exponentiation(prepared.miller_loop(p[i]))   groups/mod.rs:486-519,768
  *   bn254_gt_mul_batch     out[i] = a[i] * b[i]                                     lib.rs:175-179, fields/fq12.rs:295-307
@@ -80,6 +81,11 @@ int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *o
 int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out);
 int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n);
 int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n);
+/* out[i] = a[i] + b[i]  (negate_b != 0: a[i] - b[i] = a[i] + (-b[i])): `Add`/`Sub` of lib.rs:103-114,146-157 over
+   groups/mod.rs:275-347.  The reference's own formulas and branches (zero operands, equal points), so the Jacobian limbs
+   returned are the reference's - no normalization involved.  `Neg` is 0 - b. */
+int bn254_g1_add_batch(bn254_ctx *ctx, const bn_g1 *a, const bn_g1 *b, bn_g1 *out, size_t n, int negate_b);
+int bn254_g2_add_batch(bn254_ctx *ctx, const bn_g2 *a, const bn_g2 *b, bn_g2 *out, size_t n, int negate_b);
 /* prepared-G2 mode: precompute once per Q (must not be infinity), then pair many P against it.  `shared` != 0: ONE coefficient
    set (102 entries) is used for every p[i]; otherwise coeffs holds n sets, set i for p[i]. */
 int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, size_t n);

@@ -135,6 +135,17 @@ EXPORT void hsb_pairing(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
 static F2B ld2b(const uint32_t *w) { return f2_load((F2B *)0, w); }
 static void st2b(const F2B &a, uint32_t *w) { f2_store(a, w); }
 EXPORT void hsb_g2_mul(const uint32_t *p, const uint32_t *k, int normalize, uint32_t *o) { hs_mul_generic<Fq2Field<F2B>, 16>(p, k, o, normalize, ld2b, st2b); }
+// G + G / G - G with the reference's branches (bn254_kernels_mul.hip add_body), G1 one lane and G2 on a lane pair
+template <class F, int W>
+static void hs_add_generic(const uint32_t *a, const uint32_t *b, int negate_b, uint32_t *o, typename F::T (*ld)(const uint32_t *), void (*st)(const typename F::T &, uint32_t *)) {
+    Jac<F> pa = {ld(a), ld(a + W), ld(a + 2 * W)}, pb = {ld(b), ld(b + W), ld(b + 2 * W)};
+    const bool bz = F::is_zero(pb.z);
+    if (negate_b) pb.y = F::select(bz, F::template lc3<-1, 0, 0>(pb.y, pb.y, pb.y), pb.y);
+    Jac<F> r = jac_add_flags<F>(pa, pb, F::is_zero(pa.z), bz);
+    st(r.x, o); st(r.y, o + W); st(r.z, o + 2 * W);
+}
+EXPORT void hs_g1_add(const uint32_t *a, const uint32_t *b, int negate_b, uint32_t *o) { hs_add_generic<FqField, 8>(a, b, negate_b, o, ld1, st1); }
+EXPORT void hsb_g2_add(const uint32_t *a, const uint32_t *b, int negate_b, uint32_t *o) { hs_add_generic<Fq2Field<F2B>, 16>(a, b, negate_b, o, ld2b, st2b); }
 // pairing through the NAF Miller schedule (what the pairing kernels run): only the exponentiated value is comparable
 EXPORT void hsb_pairing_naf(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
     bool inf = words_all_zero(g1 + 16, 8) || words_all_zero(g2 + 32, 16);

@@ -327,3 +327,21 @@ def test_golden_fixtures_on_gpu(eng, goldens):
     for i in range(1, n):
         acc = eng.gt_mul_batch(acc, g["gt"][i:i + 1])
     assert np.array_equal(prod.reshape(1, 48), acc)
+
+
+def test_group_addition_matches_reference_limbs(oracle, eng):
+    """`G + G`, `G - G`, `-G` (lib.rs:103-114,146-157): raw Jacobian limbs incl. the zero / equal-point branches"""
+    import bn_amd
+    rng = np.random.default_rng(111)
+    n = 40
+    A1, A2 = _points(oracle, rng, n); B1, B2 = _points(oracle, rng, n)
+    B1[1] = A1[1]; B2[1] = A2[1]                                    # equal points -> doubling branch
+    A1[2] = oracle.g1_zero(); A2[2] = oracle.g2_zero(); B1[3] = oracle.g1_zero(); B2[3] = oracle.g2_zero()
+    A1[4] = oracle.g1_zero(); B1[4] = oracle.g1_zero(); A2[4] = oracle.g2_zero(); B2[4] = oracle.g2_zero()
+    s1 = eng.g1_add_batch(A1, B1); d1 = eng.g1_add_batch(A1, B1, negate_b=True)
+    s2 = eng.g2_add_batch(A2, B2); d2 = eng.g2_add_batch(A2, B2, negate_b=True)
+    for i in range(n):
+        assert np.array_equal(s1[i], oracle.g1_add(A1[i], B1[i])) and np.array_equal(d1[i], oracle.g1_add(A1[i], oracle.g1_neg(B1[i])))
+        assert np.array_equal(s2[i], oracle.g2_add(A2[i], B2[i])) and np.array_equal(d2[i], oracle.g2_add(A2[i], oracle.g2_neg(B2[i])))
+    p = bn_amd.G1(A1[0]); q = bn_amd.G1(B1[0])
+    assert np.array_equal((-q).limbs, oracle.g1_neg(B1[0])) and (p + q) - q == p and (p - p).is_zero()

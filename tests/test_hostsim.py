@@ -248,3 +248,16 @@ def test_golden_fixtures_through_engine_code(hs, goldens):
     for i in (0, 1, 2, 3, 10, 50):
         assert np.array_equal(hs.call("hsb_pairing_naf", g["g1"][i], g["g2"][i], out_words=96), g["gt"][i])
     assert np.array_equal(hs.call("hsb_pairing", g["g1"][2], g["g2"][2], out_words=96), g["gt"][2])
+
+
+def test_group_addition_branches(oracle, hs):
+    """groups/mod.rs:275-347 through the engine code: generic sum, a + a (doubling branch), a + 0, 0 + b, a - a, 0 - b, 0 - 0:
+    the raw Jacobian limbs equal the reference's in every branch"""
+    rng = np.random.default_rng(29)
+    a1 = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)); b1 = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng))
+    a2 = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng)); b2 = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng))
+    for fn, w, a, b, z, add, neg in (("hs_g1_add", 12, a1, b1, oracle.g1_zero(), oracle.g1_add, oracle.g1_neg),
+                                      ("hsb_g2_add", 24, a2, b2, oracle.g2_zero(), oracle.g2_add, oracle.g2_neg)):
+        for x, y in ((a, b), (a, a), (a, z), (z, b), (z, z), (b, a)):
+            assert np.array_equal(hs.call(fn, x, y, 0, out_words=2 * w), add(x, y))
+            assert np.array_equal(hs.call(fn, x, y, 1, out_words=2 * w), add(x, neg(y)))
