@@ -42,6 +42,9 @@ struct G1 {
     static G1 zero() { G1 r; std::memset(&r.v, 0, sizeof r.v); std::memcpy(r.v.y, FQ_ONE, 32); return r; }   // (0,1,0)
     bool is_zero() const { return (v.z[0] | v.z[1] | v.z[2] | v.z[3]) == 0; }
     G1 operator*(const Fr &k) const { G1 r; check(bn254_g1_mul_batch(nullptr, &v, &k.v, &r.v, 1)); return r; }
+    G1 operator+(const G1 &o) const { G1 r; check(bn254_g1_add_batch(nullptr, &v, &o.v, &r.v, 1, 0)); return r; }     // lib.rs:103-106
+    G1 operator-(const G1 &o) const { G1 r; check(bn254_g1_add_batch(nullptr, &v, &o.v, &r.v, 1, 1)); return r; }     // lib.rs:108-111
+    G1 operator-() const { return zero() - *this; }                                                                  // lib.rs:113-114
     void normalize() { *this = *this * Fr::one(); }                          // lib.rs:88-95
 };
 struct G2 {
@@ -56,11 +59,16 @@ struct G2 {
     static G2 zero() { G2 r; std::memset(&r.v, 0, sizeof r.v); std::memcpy(r.v.y, FQ_ONE, 32); return r; }
     bool is_zero() const { uint64_t o = 0; for (int i = 0; i < 8; ++i) o |= v.z[i]; return o == 0; }
     G2 operator*(const Fr &k) const { G2 r; check(bn254_g2_mul_batch(nullptr, &v, &k.v, &r.v, 1)); return r; }
+    G2 operator+(const G2 &o) const { G2 r; check(bn254_g2_add_batch(nullptr, &v, &o.v, &r.v, 1, 0)); return r; }
+    G2 operator-(const G2 &o) const { G2 r; check(bn254_g2_add_batch(nullptr, &v, &o.v, &r.v, 1, 1)); return r; }
+    G2 operator-() const { return zero() - *this; }
     void normalize() { *this = *this * Fr::one(); }
 };
 struct Gt {
     bn_gt v;
     static Gt one() { Gt r; std::memset(&r.v, 0, sizeof r.v); std::memcpy(r.v.c, FQ_ONE, 32); return r; }     // lib.rs:169
+    Gt operator*(const Gt &o) const { Gt r; check(bn254_gt_mul_batch(nullptr, &v, &o.v, &r.v, 1)); return r; }      // lib.rs:175-179
+    Gt pow(const Fr &k) const { Gt r; check(bn254_gt_pow_batch(nullptr, &v, &k.v, &r.v, 1)); return r; }            // lib.rs:171
     bool operator==(const Gt &o) const { return std::memcmp(&v, &o.v, sizeof v) == 0; }
     bool operator!=(const Gt &o) const { return !(*this == o); }
 };
