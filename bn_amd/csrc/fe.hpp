@@ -360,7 +360,8 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
         if (C4 != 0 && !N4) t += (int64_t)C4 * (int64_t)(int32_t)w.l[i];
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
-    BN_SETB(r, 1, 3);
+    // floor() loses < 1 and the margins of `te` ~3e-4, so kq > value/q - 1.001 and the result is < 1.001 q
+    BN_SETB(r, 1, 2);
     BN_VERIFY(r, "fe_lc4_core");
     return r;
 }
@@ -389,7 +390,7 @@ BN_FN Fe fe_lc3w_body(const Fe &x, const Fe &y, const Fe &z) {
         if (C3 != 0) t += (int64_t)C3 * (int64_t)z.l[i];
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
-    BN_SETB(r, 1, 3);
+    BN_SETB(r, 1, 2);
     BN_VERIFY(r, "fe_lc3w_body");
     return r;
 }

@@ -147,7 +147,7 @@ template <class T>
 BN_FN T f2b_mul_body(const T &a, const T &b) {
     T pa = lane_partner(a), pb = lane_partner(b);
     T u = lane_pick(b, pb);
-    T v = lane_pick(fe_neg<1, 7>(pb), b);
+    T v = lane_pick(fe_neg<1, 9>(pb), b);
     return fe_mul2(a, u, pa, v);
 }
 // complex squaring: even lane (a0+a1)(a0-a1), odd lane (2 a0) a1 : ONE plain Montgomery product per lane
@@ -155,7 +155,7 @@ template <class T>
 BN_FN T f2b_sqr_body(const T &a) {
     T pa = lane_partner(a);
     T s = lane_pick(fe_add(a, pa), fe_dbl(pa));
-    T t = lane_pick(fe_sub<1, 4>(a, pa), a);
+    T t = lane_pick(fe_sub<1, 5>(a, pa), a);
     return fe_mul_body(s, t);
 }
 #if defined(BN_HOSTSIM)

@@ -25,7 +25,7 @@ BN_COARSE Line<F2> doubling_step(G2Proj<F2> &r) {
     F2 e = f2_mul_const(c, k::G2_3B);
     F2 f3 = f2_add(f2_add(e, e), e);                                     // f = 3e, lazy
     F2 g = f2_scale(f2_add(b, f3), f2_scalar_const(F2P, k::TWO_INV));                // (b + f)/2
-    F2 h = f2_lc3<1, -1, -1>(f2_sqr(f2_lc3<1, 1, 0>(r.y, r.z, r.z)), b, c);
+    F2 h = f2_lc3<1, -1, -1>(f2_sqr(f2_sum_for_mul(r.y, r.z)), b, c);
     F2 j = f2_sqr(r.x), e_sq = f2_sqr(e);
     Line<F2> l;
     l.ell_0 = f2_mul_xi(f2_ssub(e, b));                             // xi * (e - b)

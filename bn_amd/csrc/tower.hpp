@@ -102,7 +102,7 @@ BN_FN Fq12<F2> f12_mul_src(const Fq12<F2> &a, const BSrc &b, bool conj_b) {
     // the Karatsuba cross term first: it is the only product that needs both halves of a and of b at once
     Fq6<F2> b1 = b.c1();
     if (conj_b) b1 = f6_neg(b1);
-    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add(b.c0(), b1));
+    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add_norm(b.c0(), b1));
     Fq6<F2> bb = f6_mul(a.c1, b1);
     Fq6<F2> aa = f6_mul(a.c0, b.c0());
     Fq12<F2> r;
@@ -120,14 +120,14 @@ BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     Fq6<F2> ab = f6_mul(a.c0, a.c1);
     Fq6<F2> u;                                                // v*c1 + c0
     u.c0 = f2_lc_xi<1, 1>(a.c1.c2, a.c0.c0);
-    u.c1 = f2_lc3<1, 1, 0>(a.c1.c0, a.c0.c1, a.c0.c1);
-    u.c2 = f2_lc3<1, 1, 0>(a.c1.c1, a.c0.c2, a.c0.c2);
+    u.c1 = f2_sum_for_mul(a.c1.c0, a.c0.c1);
+    u.c2 = f2_sum_for_mul(a.c1.c1, a.c0.c2);
     Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), u);
     Fq12<F2> r;
     r.c0.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_ssub(t.c0, ab.c0));      // t - ab - v*ab
     r.c0.c1 = f2_lc3<1, -1, -1>(t.c1, ab.c1, ab.c0);
     r.c0.c2 = f2_lc3<1, -1, -1>(t.c2, ab.c2, ab.c1);
-    r.c1 = f6_lc3<2, 0, 0>(ab, ab, ab);
+    r.c1 = f6_add_norm(ab, ab);                                // 2ab as a plain sum (carries propagated)
     return r;
 }
 // fq12.rs:103-105
@@ -185,7 +185,7 @@ BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &
         r.c1.c1 = f2_lc_xi<1, 1>(z5x2, f2_ssub(f2_ssub(m04, d0), d4));   // xi z5 x2 + (z0+z4)(x0+x4) - d0 - d4
         s1 = f2_add(s1, z5x2);
     }
-    F2 ms = f2_mul(f2_sum3_for_mul(z1, z3, z5), f2_lc3<1, 1, 1>(x0, x2, x4));
+    F2 ms = f2_mul(f2_sum3_for_mul(z1, z3, z5), f2_sum3_for_mul(x0, x2, x4));
     r.c1.c2 = f2_lc3w<1, -1, 0>(ms, s1, s1);                              // (z1+z3+z5)(x0+x2+x4) - s1
     return r;
 }
