@@ -20,6 +20,8 @@ struct FqField {
     static BN_FN T sqr(const T &a) { return fe_sqr(a); }
     template <int C1, int C2, int C3> static BN_FN T lc3(const T &x, const T &y, const T &z) { return fe_lc3<C1, C2, C3>(x, y, z); }
     template <int C1, int C2, int C3> static BN_FN T lc3w(const T &x, const T &y, const T &z) { return fe_lc3w<C1, C2, C3>(x, y, z); }
+    static BN_FN T sum(const T &x, const T &y) { return fe_norm(fe_add(x, y)); }                  // lazy sum, carries propagated
+    static BN_FN T sum3(const T &x, const T &y, const T &z) { return fe_norm(fe_add(fe_add(x, y), z)); }
     static BN_FN T zero() { return fe_zero(); }
     static BN_FN T one() { return fe_one(); }
     static BN_FN T select(bool b, const T &x, const T &y) { return fe_select(b, x, y); }
@@ -33,6 +35,8 @@ struct Fq2Field {
     static BN_FN T sqr(const T &a) { return f2_sqr(a); }
     template <int C1, int C2, int C3> static BN_FN T lc3(const T &x, const T &y, const T &z) { return f2_lc3<C1, C2, C3>(x, y, z); }
     template <int C1, int C2, int C3> static BN_FN T lc3w(const T &x, const T &y, const T &z) { return f2_lc3w<C1, C2, C3>(x, y, z); }
+    static BN_FN T sum(const T &x, const T &y) { return f2_sum_for_mul(x, y); }
+    static BN_FN T sum3(const T &x, const T &y, const T &z) { return f2_sum3_for_mul(x, y, z); }
     static BN_FN T zero() { return f2_zero((const F2 *)nullptr); }
     static BN_FN T one() { return f2_one((const F2 *)nullptr); }
     static BN_FN T select(bool b, const T &x, const T &y) { return f2_select(b, x, y); }
@@ -47,14 +51,14 @@ template <class F>
 BN_COARSE Jac<F> jac_double(const Jac<F> &p) {
     using T = typename F::T;
     T a = F::sqr(p.x), b = F::sqr(p.y), c = F::sqr(b);
-    T t = F::sqr(F::template lc3<1, 1, 0>(p.x, b, b));
+    T t = F::sqr(F::sum(p.x, b));
     T d = F::template lc3w<2, -2, -2>(t, a, c);
-    T e = F::template lc3<3, 0, 0>(a, a, a);
+    T e = F::sum3(a, a, a);
     T f = F::sqr(e);
     Jac<F> r;
     r.x = F::template lc3<1, -2, 0>(f, d, d);
     r.y = F::template lc3<1, -8, 0>(F::mul(e, F::template lc3<1, -1, 0>(d, r.x, d)), c, c);
-    r.z = F::template lc3<2, 0, 0>(F::mul(p.y, p.z), p.y, p.y);
+    { T yz = F::mul(p.y, p.z); r.z = F::sum(yz, yz); }
     return r;
 }
 // out-of-line copy for the never-taken equal-points branch below (keeps the inlined builds small)
@@ -70,9 +74,9 @@ BN_COARSE Jac<F> jac_add_flags(const Jac<F> &p, const Jac<F> &q, bool pz, bool q
     T s1 = F::mul(p.y, F::mul(q.z, z2s)), s2 = F::mul(q.y, F::mul(p.z, z1s));
     T h = F::template lc3<1, -1, 0>(u2, u1, u1), sd = F::template lc3<1, -1, 0>(s2, s1, s1);
     bool same = F::is_zero(h) && F::is_zero(sd) && !pz && !qz;
-    T i = F::sqr(F::template lc3<2, 0, 0>(h, h, h));
+    T i = F::sqr(F::sum(h, h));
     T j = F::mul(h, i);
-    T rr = F::template lc3<2, 0, 0>(sd, sd, sd);
+    T rr = F::sum(sd, sd);
     T v = F::mul(u1, i);
     Jac<F> r;
     r.x = F::template lc3<1, -1, -2>(F::sqr(rr), j, v);

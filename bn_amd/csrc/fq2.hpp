@@ -155,7 +155,7 @@ template <class T>
 BN_FN T f2b_sqr_body(const T &a) {
     T pa = lane_partner(a);
     T s = lane_pick(fe_add(a, pa), fe_dbl(pa));
-    T t = lane_pick(fe_sub<1, 5>(a, pa), a);
+    T t = lane_pick(fe_sub<1, 7>(a, pa), a);
     return fe_mul_body(s, t);
 }
 #if defined(BN_HOSTSIM)
