@@ -16,6 +16,10 @@ extern "C" {
     fn bn254_g2_mul_batch(ctx: *mut c_void, p: *const G2, k: *const Fr, out: *mut G2, n: usize) -> c_int;
     fn bn254_gt_mul_batch(ctx: *mut c_void, a: *const Gt, b: *const Gt, out: *mut Gt, n: usize) -> c_int;
     fn bn254_gt_pow_batch(ctx: *mut c_void, a: *const Gt, k: *const Fr, out: *mut Gt, n: usize) -> c_int;
+    fn bn254_g1_add_batch(ctx: *mut c_void, a: *const G1, b: *const G1, out: *mut G1, n: usize, negate_b: c_int) -> c_int;
+    fn bn254_g2_add_batch(ctx: *mut c_void, a: *const G2, b: *const G2, out: *mut G2, n: usize, negate_b: c_int) -> c_int;
+    fn bn254_g1_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut G1, status: *mut i32, n: usize) -> c_int;
+    fn bn254_g2_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut G2, status: *mut i32, n: usize) -> c_int;
 }
 
 /// Error code of the HIP engine: negative `BN254_E_*`, positive `hipError_t`.  There is no CPU fallback.
@@ -69,6 +73,40 @@ pub fn gt_pow_batch(a: &[Gt], k: &[Fr]) -> Result<Vec<Gt>, GpuError> {
     let mut out = a.to_vec();
     check(unsafe { bn254_gt_pow_batch(std::ptr::null_mut(), a.as_ptr(), k.as_ptr(), out.as_mut_ptr(), a.len()) })?;
     Ok(out)
+}
+
+/// `out[i] = a[i] + b[i]` (`sub`: `a[i] - b[i]`), src/lib.rs:103-111 - the crate's own Jacobian limbs
+pub fn g1_add_batch(a: &[G1], b: &[G1], sub: bool) -> Result<Vec<G1>, GpuError> {
+    assert_eq!(a.len(), b.len());
+    let mut out = a.to_vec();
+    check(unsafe { bn254_g1_add_batch(std::ptr::null_mut(), a.as_ptr(), b.as_ptr(), out.as_mut_ptr(), a.len(), sub as c_int) })?;
+    Ok(out)
+}
+
+pub fn g2_add_batch(a: &[G2], b: &[G2], sub: bool) -> Result<Vec<G2>, GpuError> {
+    assert_eq!(a.len(), b.len());
+    let mut out = a.to_vec();
+    check(unsafe { bn254_g2_add_batch(std::ptr::null_mut(), a.as_ptr(), b.as_ptr(), out.as_mut_ptr(), a.len(), sub as c_int) })?;
+    Ok(out)
+}
+
+/// Batch `Decodable` for G2 (src/groups/mod.rs:162-205): `records` holds 129-byte records (what bincode yields for a finite
+/// point); `Err(code)` per record carries the crate's error in order of appearance: 1 "integer is not less than modulus",
+/// 2 "integer not less than modulus squared", 3 "invalid leading byte", 4 "point is not on the curve", 5 "point is not in the subgroup"
+pub fn g2_decode_batch(records: &[u8]) -> Result<Vec<Result<G2, i32>>, GpuError> {
+    assert_eq!(records.len() % 129, 0);
+    let n = records.len() / 129;
+    let (mut out, mut status) = (vec![G2::zero(); n], vec![0i32; n]);
+    check(unsafe { bn254_g2_decode_batch(std::ptr::null_mut(), records.as_ptr(), out.as_mut_ptr(), status.as_mut_ptr(), n) })?;
+    Ok(out.into_iter().zip(status).map(|(p, s)| if s == 0 { Ok(p) } else { Err(s) }).collect())
+}
+
+pub fn g1_decode_batch(records: &[u8]) -> Result<Vec<Result<G1, i32>>, GpuError> {
+    assert_eq!(records.len() % 65, 0);
+    let n = records.len() / 65;
+    let (mut out, mut status) = (vec![G1::zero(); n], vec![0i32; n]);
+    check(unsafe { bn254_g1_decode_batch(std::ptr::null_mut(), records.as_ptr(), out.as_mut_ptr(), status.as_mut_ptr(), n) })?;
+    Ok(out.into_iter().zip(status).map(|(p, s)| if s == 0 { Ok(p) } else { Err(s) }).collect())
 }
 
 #[cfg(test)]
