@@ -31,6 +31,27 @@ PEAK_TMAC32 = 30.1            # measured v_mad_u64_u32 issue peak, profiles/r01_
 ALGO_BYTES_PER_PAIRING = 672
 
 
+def _barrier(dist, dev):
+    """barrier + device sync on both sides of a timed region (RCCL: tied to this rank's GPU)"""
+    import torch
+    torch.cuda.synchronize(dev)
+    if dist.is_initialized():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[dev.index])
+        else:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+
+def _max_over_ranks(dist, dev, elapsed):
+    import torch
+    if not dist.is_initialized():
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def cpu_baseline(batch_p, batch_q):
     """reference-faithful CPU port on all host cores, bounded sample (~20 s of CPU work)"""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -63,18 +84,12 @@ def bench_g1mul(args, eng, dev, world, rank, local_rank):
     k = torch.from_numpy(D.synthetic_scalars(0, n >> 4, 1).view(np.int64)).to(dev).repeat(16, 1).contiguous()
     for _ in range(args.warmup):
         eng.g1_mul(P, k)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier(device_ids=[local_rank]); torch.cuda.synchronize(dev)
+    _barrier(dist, dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.g1_mul(P, k)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier(device_ids=[local_rank]); torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    _barrier(dist, dev)
+    elapsed = _max_over_ranks(dist, dev, time.perf_counter() - t0)
     if rank == 0:
         print(json.dumps({"metric": "BN254 G1 scalar multiplications/sec (normalized output, bit-exact vs ref)", "value": world * n * args.steps / elapsed,
                           "unit": "scalar muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -94,18 +109,12 @@ def bench_product(args, eng, dev, world, rank, local_rank):
     P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
     for _ in range(args.warmup):
         gt = D.pairing_product_sharded(eng, P, Q)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier(device_ids=[local_rank]); torch.cuda.synchronize(dev)
+    _barrier(dist, dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gt = D.pairing_product_sharded(eng, P, Q)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier(device_ids=[local_rank]); torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    _barrier(dist, dev)
+    elapsed = _max_over_ranks(dist, dev, time.perf_counter() - t0)
     if rank == 0:
         print(json.dumps({"metric": "BN254 pairs/sec folded into one multi-pairing product (bit-exact vs ref)", "value": world * n * args.steps / elapsed,
                           "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -170,12 +179,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: bn_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hooks for a ONE-GPU box (never set by the driver): all ranks share cuda:0 and rendezvous over gloo, which exercises
+    # the N>1 control flow (shards, barriers, MAX over ranks, rank-0 line) without RCCL's one-GPU-per-rank requirement.
+    share_gpu = os.environ.get("BN254_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("BN254_BENCH_BACKEND", "nccl")
+    gpu_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    eng = D.TorchEngine(bn_amd.Engine(local_rank, mapping=args.mapping), dev)
+    eng = D.TorchEngine(bn_amd.Engine(gpu_index, mapping=args.mapping), dev)
     if args.workload == "g1mul":
         return bench_g1mul(args, eng, dev, world, rank, local_rank)
     if args.workload == "prepared":
@@ -188,10 +205,7 @@ def main():
     out = eng.empty(n, 48)
 
     def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-            torch.cuda.synchronize(dev)
+        _barrier(dist, dev)
 
     for _ in range(args.warmup):
         D.pairing_batch_sharded(eng, P, Q, out)
@@ -203,10 +217,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     eng.e.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = _max_over_ranks(dist, dev, elapsed)
 
     if rank == 0:
         value = world * n * args.steps / elapsed

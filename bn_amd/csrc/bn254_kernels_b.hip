@@ -27,15 +27,124 @@
 #ifdef BN_B_INLINE_REDUCTIONS
 #define BN_INLINE_REDUCTIONS 1
 #endif
-#ifndef BN_B_BLOCK
-#define BN_B_BLOCK 64
+// Two waves share a SIMD and the hardware arbitrates OLDEST FIRST: measured with per-wave time stamps (tools/stamp_test.py),
+// wave 0 of every SIMD ran at solo speed and finished the Miller kernel after 3.0 ms while wave 1 crawled and needed 5.2 ms,
+// the SIMD running one wave only for the last 40 % of the kernel (a SIMD with two waves delivers only 1.3x the work of one).
+// Policies (BN_B_FAIR):
+//   2 (default, needs BN_B_BLOCK = 512 = the 8 waves of one CU in one workgroup): every wave counts its progress ticks in LDS and
+//     reads the counter of the wave it shares its SIMD with; whoever is ahead drops to the lowest user priority, whoever is
+//     behind takes the highest.  Both waves reach the end together, both slots stay busy (work-conserving).
+//   1 (any block size): priority alternates with (step number XOR wave slot) - no communication, first-order fairness only.
+//   0: plain age arbitration.
+#ifndef BN_B_FAIR
+#define BN_B_FAIR 5
 #endif
-#if BN_B_BLOCK > 64
-// several waves per workgroup: re-align them at every loop step so that they walk the (larger than the instruction cache)
-// loop bodies together and share the instruction fetches
-#define BN_LOOP_SYNC() __syncthreads()
+#ifndef BN_B_BLOCK
+#define BN_B_BLOCK (BN_B_FAIR == 2 ? 512 : 64)
+#endif
+#if BN_B_FAIR == 2
+#define BN_MILLER_HOOK(step, total) bn_fair_progress()
+#define BN_EXP_HOOK(step, total) bn_fair_progress()
+#define BN_FAIR_TICK() bn_fair_progress()
+#elif BN_B_FAIR == 1
+#define BN_MILLER_HOOK(step, total) bn_fair_priority(step)
+#define BN_EXP_HOOK(step, total) bn_fair_priority(step)
+#elif BN_B_FAIR == 3
+#define BN_MILLER_HOOK(step, total) bn_fair_priority_time()
+#define BN_EXP_HOOK(step, total) bn_fair_priority_time()
+#elif BN_B_FAIR == 4
+#define BN_MILLER_HOOK(step, total) bn_fair_handover(step, total)
+#define BN_EXP_HOOK(step, total) bn_fair_handover(step, total)
+#elif BN_B_FAIR == 5              // default: what measured best per kernel
+#define BN_MILLER_HOOK(step, total) bn_fair_handover(step, total)
+#define BN_EXP_HOOK(step, total) bn_fair_priority_time()
+#endif
+#ifndef BN_B_FAIR_SHIFT
+#define BN_B_FAIR_SHIFT 21
 #endif
 #include <hip/hip_runtime.h>
+__device__ __forceinline__ void bn_fair_priority(int step) {
+    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_ID.wave_id: 0 / 1 for the two resident waves
+    if ((step ^ slot) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+}
+// ONE hand-over: the older wave of a SIMD (slot 0) runs with priority until it has done 1/(1+r) of its steps (r = 0.3: the rate at
+// which the other wave advances meanwhile), then yields for good; the younger wave takes over when it has done r/(1+r) of its
+// steps - the same moment if the model holds, and the intermediate levels (1, 2) make either order of arrival safe.  Both
+// waves then finish together and the SIMD always runs its efficient mode: one privileged stream, one filling the gaps.
+#ifndef BN_B_FAIR_PERMILLE
+#define BN_B_FAIR_PERMILLE 769
+#endif
+__device__ __forceinline__ void bn_fair_handover(int step, int total) {
+    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1;
+    if (slot == 0) { if (step * 1000 < BN_B_FAIR_PERMILLE * total) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+    else { if (step * 1000 < (1000 - BN_B_FAIR_PERMILLE) * total) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+}
+__shared__ uint32_t bn_fair_t0[16];                            // shader-clock stamp of each wave's start (>> 10)
+__device__ __forceinline__ void bn_fair_time_init() {
+    if ((threadIdx.x & 63) == 0) bn_fair_t0[threadIdx.x >> 6] = (uint32_t)(__builtin_amdgcn_s_memtime() >> 10);
+    __builtin_amdgcn_s_setprio(0);
+}
+// opposite priorities for the two waves of a SIMD, swapped every 2^SHIFT cycles counted from the start of the kernel
+__device__ __forceinline__ void bn_fair_priority_time() {
+    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);
+    const uint32_t t0 = __builtin_amdgcn_readfirstlane(bn_fair_t0[threadIdx.x >> 6]);
+    const uint32_t phase = ((uint32_t)(__builtin_amdgcn_s_memtime() >> 10) - t0) >> (BN_B_FAIR_SHIFT - 10);
+    if ((phase ^ slot) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+}
+// progress counters of the (up to 16) waves of the workgroup, the index of the wave each one shares its SIMD with, and each
+// wave's current role (1 = runs with priority).  Roles swap when the privileged wave is BN_B_FAIR_LEAD ticks ahead: strict
+// priority is the efficient way to share a SIMD (the two instruction streams stay out of phase; in lockstep both hit the
+// multiplier at the same time and the pair is 6 % slower than even the unmanaged kernel), the swap only bounds the lead so
+// that both waves reach the end of the kernel within a few ticks of each other.
+#ifndef BN_B_FAIR_LEAD
+#define BN_B_FAIR_LEAD 8
+#endif
+#ifndef BN_B_FAIR_HI
+#define BN_B_FAIR_HI 3
+#endif
+__shared__ uint32_t bn_fair_ticks[16];
+__shared__ uint32_t bn_fair_partner[16];
+__shared__ uint32_t bn_fair_role[16];
+__shared__ uint32_t bn_fair_simd[16];
+__device__ __forceinline__ void bn_fair_init() {
+    const uint32_t w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        bn_fair_ticks[w] = 0;
+        bn_fair_simd[w] = (__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) >> 4) & 3;     // HW_ID.simd_id
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t partner = w;
+        for (uint32_t v = 0; v < nw; ++v)
+            if (v != w && bn_fair_simd[v] == bn_fair_simd[w]) partner = v;
+        bn_fair_partner[w] = partner;
+        bn_fair_role[w] = w <= partner;               // the first wave of a pair starts with the priority
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void bn_fair_progress() {
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t partner = __builtin_amdgcn_readfirstlane(bn_fair_partner[w]);
+    const int32_t mine = (int32_t)__builtin_amdgcn_readfirstlane(bn_fair_ticks[w]) + 1;
+    const int32_t other = (int32_t)__builtin_amdgcn_readfirstlane(bn_fair_ticks[partner]);
+    uint32_t role = __builtin_amdgcn_readfirstlane(bn_fair_role[w]);
+    if (partner != w) {
+        if (mine - other >= BN_B_FAIR_LEAD) role = 0;
+        else if (other - mine >= BN_B_FAIR_LEAD) role = 1;
+    }
+    if ((threadIdx.x & 63) == 0) { bn_fair_ticks[w] = (uint32_t)mine; bn_fair_role[w] = role; }
+#ifndef BN_B_FAIR_NOPRIO
+    if (role) __builtin_amdgcn_s_setprio(BN_B_FAIR_HI); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+#if BN_B_FAIR == 2
+#define BN_KERNEL_PROLOGUE() bn_fair_init()
+#elif BN_B_FAIR == 3 || BN_B_FAIR == 5
+#define BN_KERNEL_PROLOGUE() bn_fair_time_init()
+#else
+#define BN_KERNEL_PROLOGUE() ((void)0)
+#endif
 #include "curve.hpp"
 #include "io.hpp"
 
@@ -68,8 +177,23 @@ struct MillerStateLds {
     __device__ __forceinline__ G1Aff<Fe> get_p() const { return {ld_fe(5), ld_fe(6)}; }
 };
 
+#ifdef BN_STAMP   // experiment: per-wave start/end wall-clock stamps (100 MHz) + XCC id, read back with bn254_debug_stamps
+__device__ uint64_t bn_stamps[3 * 4096];
+#define BN_STAMP_BEGIN() uint64_t stamp_t0_ = __builtin_amdgcn_s_memrealtime()
+#define BN_STAMP_END()                                                                                              \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 4096) {                 \
+        const uint32_t sw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                  \
+        bn_stamps[3 * sw_] = stamp_t0_; bn_stamps[3 * sw_ + 1] = __builtin_amdgcn_s_memrealtime();                 \
+        bn_stamps[3 * sw_ + 2] = (uint64_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32 | (uint32_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);                    \
+    }
+extern "C" int bn254_debug_stamps(uint64_t *out, size_t n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bn_stamps), n * 8); }
+#else
+#define BN_STAMP_BEGIN() ((void)0)
+#define BN_STAMP_END() ((void)0)
+#endif
 template <bool NAF>
 __device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+    BN_STAMP_BEGIN();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -87,14 +211,17 @@ __device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t
     f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
     f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);
     if (live) f12_store(f, f_out + 96u * pair);
+    BN_STAMP_END();
 }
 
 // reference schedule: the Miller VALUES equal the reference's (bn254_miller_batch_dev, prepared-mode cross checks)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+    BN_KERNEL_PROLOGUE();
     miller_B_body<false>(g1, g2, f_out, n);
 }
 // NAF schedule (pairing.hpp miller_loop_sched<true>): used wherever a final exponentiation follows
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_naf_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+    BN_KERNEL_PROLOGUE();
     miller_B_body<true>(g1, g2, f_out, n);
 }
 
@@ -104,6 +231,7 @@ struct ExpTableMem {
     uint32_t *table;         // wave-uniform base (SGPRs)
     uint32_t lane;           // this lane's column
     uint32_t stride;         // lanes in the launch
+    int round;               // which of the three exponentiations is running (progress reporting of the loop hook)
     __device__ __forceinline__ uint32_t *row(int slot, int half) const {          // uniform: scalar address arithmetic
         return table + (size_t)(uint32_t)((slot * 2 + half) * 27) * stride;
     }
@@ -134,17 +262,19 @@ struct ExpTableMem {
 constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 54;
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n, uint32_t *table) {
+    BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
-    ExpTableMem tbl = {table, t, gridDim.x * BLOCK};
+    ExpTableMem tbl = {table, t, gridDim.x * BLOCK, 0};
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair), tbl);
     if (live) f12_store(f, out + 96u * pair);
 }
 // ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
 constexpr int NCOEFF = 102, COEFF_WORDS = 48;
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_g2_precompute_B(const uint32_t *g2, uint32_t *coeffs, uint32_t n) {
+    BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -162,6 +292,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 }
 // f[i] = miller_loop(coeffs, P[i])  (groups/mod.rs:486-519); coeff_stride = 0 shares one coefficient set among all P
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_prepared_B(const uint32_t *g1, const uint32_t *coeffs, uint32_t coeff_stride, uint32_t *f_out, uint32_t n) {
+    BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -186,6 +317,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // out[t] = product of in[t*chunk .. min(n, (t+1)*chunk))   (product tree of the multi-pairing; chunk is small so that every
 // level keeps many lane pairs busy: 2^15 values -> 1 in 8 levels of 3 multiplications instead of 3 levels of 63)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_product_B(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t chunk) {
+    BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     uint32_t groups = (n + chunk - 1) / chunk;
@@ -200,6 +332,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 
 // out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
+    BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -210,6 +343,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // out[i] = a[i] ^ k[i]   (Gt::pow, lib.rs:171 -> fields/mod.rs:35-46: 256 x { res = res^2; if bit { res = a * res } } on the scalar
 // taken out of Montgomery form).  Exponent bits differ per element, so the conditional product is a per-pair select.
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n) {
+    BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;

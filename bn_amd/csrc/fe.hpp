@@ -53,8 +53,14 @@
 // keeps loads that follow in the source from being scheduled above this point (used where early loads only cause spills)
 #define BN_COMPILER_FENCE() asm volatile("" ::: "memory")
 #endif
-#ifndef BN_LOOP_SYNC                // optional workgroup barrier at the top of the long loop bodies (see bn254_kernels_b.hip)
-#define BN_LOOP_SYNC() ((void)0)
+#ifndef BN_FAIR_TICK                // executed inside the Fq6-sized steps (a few thousand cycles apart); see bn254_kernels_b.hip
+#define BN_FAIR_TICK() ((void)0)
+#endif
+#ifndef BN_MILLER_HOOK              // executed at the top of every step of the Miller loop: step number, number of steps
+#define BN_MILLER_HOOK(step, total) ((void)0)
+#endif
+#ifndef BN_EXP_HOOK                 // same for the three exponentiation loops of the final exponentiation
+#define BN_EXP_HOOK(step, total) ((void)0)
 #endif
 #include "bn254_constants.hpp"
 

@@ -111,7 +111,7 @@ BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p, const G2Aff<F2> &q, Store &s
         if (j == ND + 1) { G2Aff<F2> b2 = mul_by_q(st.get_base()); b2.y = f2_neg(b2.y); st.put_base(b2); }   // -pi^2(Q)   :579
 #pragma unroll 1
         for (int pass = tail ? 1 : 0; pass < (digit != 0 ? 2 : 1); ++pass) {
-            BN_LOOP_SYNC();
+            BN_MILLER_HOOK(2 * j + pass, 2 * (ND + 2));
             Line<F2> l;
             if (pass == 0) {
                 if (j != 0) f = f12_sqr(f);                                         // f == 1 in the first step
@@ -184,6 +184,7 @@ BN_FN Fq12<F2> miller_loop_prepared(const G1Aff<S> &p, Source &source) {
 template <class F2>
 struct ExpTableVars {
     Fq12<F2> s_[k::EXP_SLOTS];
+    int round = 0;                      // which of the three exponentiations of the hard part is running (progress reporting)
     BN_FN void put(int i, const Fq12<F2> &v) { s_[i] = v; }
     BN_FN Fq6<F2> c0(int i) const { return s_[i].c0; }
     BN_FN Fq6<F2> c1(int i) const { return s_[i].c1; }
@@ -207,7 +208,7 @@ BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f, Tbl &tbl) {
     Fq12<F2> res = f;
 #pragma unroll 1
     for (int s = 0; s < k::EXP_STEPS; ++s) {
-        BN_LOOP_SYNC();
+        BN_EXP_HOOK(tbl.round * k::EXP_STEPS + s, 3 * k::EXP_STEPS);
         const int w = k::EXP_SCHED[s];
         const int get = (w >> 8) & 7, mul = (w >> 1) & 7, put = (w >> 5) & 7;
         if (get) res = Fq12<F2>{tbl.c0(get - 1), tbl.c1(get - 1)};
@@ -215,6 +216,7 @@ BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f, Tbl &tbl) {
         if (mul) res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, mul - 1}, ((w >> 4) & 1) != 0);
         if (put) tbl.put(put - 1, res);
     }
+    tbl.round = tbl.round + 1;
     // hand a COPY to the out-of-line conjugation: a reference to `res` itself would pin the loop-carried value to a stack
     // slot (its address escapes), and every iteration would go through private memory
     const Fq12<F2> last = res;

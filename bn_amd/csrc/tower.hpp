@@ -37,6 +37,7 @@ template <class F2> BN_FN Fq6<F2> f6_mul_by_v(const Fq6<F2> &a) { return {f2_mul
 // coefficient is finished as soon as its products exist (short live ranges: see f12_mul_by_024)
 template <class F2>
 BN_COARSE Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
+    BN_FAIR_TICK();
     F2 aa = f2_mul(a.c0, b.c0), bb = f2_mul(a.c1, b.c1), cc = f2_mul(a.c2, b.c2);
     Fq6<F2> r;
     {

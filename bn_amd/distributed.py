@@ -76,8 +76,13 @@ def all_gather_partials(partial, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return partial.reshape(1, GT_WORDS)
     world = dist.get_world_size(group)
+    src = partial.contiguous().reshape(GT_WORDS)
+    if dist.get_backend(group) != "nccl" and src.is_cuda:          # gloo (tests, one-GPU smoke runs): exchange through the host
+        out = torch.empty(world * GT_WORDS, dtype=src.dtype)
+        dist.all_gather_into_tensor(out, src.cpu(), group=group)
+        return out.reshape(world, GT_WORDS).to(partial.device)
     out = torch.empty(world * GT_WORDS, dtype=partial.dtype, device=partial.device)
-    dist.all_gather_into_tensor(out, partial.contiguous().reshape(GT_WORDS), group=group)
+    dist.all_gather_into_tensor(out, src, group=group)
     return out.reshape(world, GT_WORDS)
 
 
