@@ -28,14 +28,19 @@
 #define BN_INLINE_REDUCTIONS 1
 #endif
 // Two waves share a SIMD and the hardware arbitrates OLDEST FIRST: measured with per-wave time stamps (tools/stamp_test.py),
-// wave 0 of every SIMD ran at solo speed and finished the Miller kernel after 3.0 ms while wave 1 crawled and needed 5.2 ms,
-// the SIMD running one wave only for the last 40 % of the kernel (a SIMD with two waves delivers only 1.3x the work of one).
-// Policies (BN_B_FAIR):
-//   2 (default, needs BN_B_BLOCK = 512 = the 8 waves of one CU in one workgroup): every wave counts its progress ticks in LDS and
-//     reads the counter of the wave it shares its SIMD with; whoever is ahead drops to the lowest user priority, whoever is
-//     behind takes the highest.  Both waves reach the end together, both slots stay busy (work-conserving).
-//   1 (any block size): priority alternates with (step number XOR wave slot) - no communication, first-order fairness only.
-//   0: plain age arbitration.
+// wave 0 of every SIMD ran at solo speed and finished the Miller kernel after 3.0 ms while wave 1 crawled (0.3 of the solo
+// rate) and needed 5.2 ms - the SIMD ran ONE wave for the last 40 % of the kernel.  A SIMD with a privileged and a gap-filling
+// wave delivers 1.3x the work of one wave, so keeping both alive to the end is worth 10 % (two concurrent processes, whose
+// kernels backfill each other's freed slots, showed exactly that: 7.94 vs 7.24 M pairings/s).  Keeping the two waves in
+// lockstep is NOT the answer: measured 6 % slower than doing nothing, because both streams then hit the multiplier at the same
+// time; strict priority with a role swap is.  Policies (BN_B_FAIR), all through s_setprio at the top of the loop steps:
+//   5 (default) hand-over by progress in the Miller loop (4), clocked alternation in the final exponentiation (3)
+//   4 one hand-over: the older wave keeps the priority for 1/(1+r) = 77 % of its steps, then yields for good
+//   3 opposite priorities, swapped every 2^BN_B_FAIR_SHIFT shader cycles counted from the start of the kernel
+//   2 progress counters of the 8 waves of a CU in LDS (512-thread workgroups), the wave behind gets the priority - slower:
+//     the bookkeeping inside the Fq6 products costs more than the tail it removes
+//   1 priority = (step number XOR wave slot) & 1
+//   0 plain age arbitration
 #ifndef BN_B_FAIR
 #define BN_B_FAIR 5
 #endif

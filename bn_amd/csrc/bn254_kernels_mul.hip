@@ -10,6 +10,9 @@
 #define BN_COARSE __device__ __forceinline__
 #define BN_LEAF_MUL __device__ __forceinline__
 #define BN_LEAF_RED __device__ __forceinline__
+#ifndef BN_MUL_WAVES
+#define BN_MUL_WAVES 2        // resident waves per SIMD the G1 kernel is compiled for
+#endif
 #include <hip/hip_runtime.h>
 #include "curve.hpp"
 #include "io.hpp"
@@ -30,7 +33,7 @@ __device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km,
     return scalar_mul_reference_chain<F>(p, raw);
 }
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g1_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_MUL_WAVES, BN_MUL_WAVES))) bn254_g1_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
     uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= n) return;
     const uint32_t *w = p + 24u * idx;

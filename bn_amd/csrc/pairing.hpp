@@ -154,6 +154,7 @@ BN_FN void precompute_lines(const G2Aff<F2> &q, Sink &sink) {
         if (j == 65) { base = mul_by_q(base); base.y = f2_neg(base.y); }
 #pragma unroll 1
         for (int pass = tail ? 1 : 0; pass < (bit ? 2 : 1); ++pass) {
+            BN_MILLER_HOOK(2 * j + pass, 2 * 66);
             Line<F2> l = pass == 0 ? doubling_step(r) : addition_step(r, base);
             sink(idx++, l);
         }
@@ -170,6 +171,7 @@ BN_FN Fq12<F2> miller_loop_prepared(const G1Aff<S> &p, Source &source) {
         const bool bit = tail ? true : (((k::ATE_LOOP_LOW64 >> (63 - (j & 63))) & 1) != 0);
 #pragma unroll 1
         for (int pass = tail ? 1 : 0; pass < (bit ? 2 : 1); ++pass) {
+            BN_MILLER_HOOK(2 * j + pass, 2 * 66);
             if (pass == 0) f = f12_sqr(f);
             Line<F2> l = source(idx++);
             f = apply_line(f, l, p);
