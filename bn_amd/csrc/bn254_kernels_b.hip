@@ -268,6 +268,7 @@ constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 54;
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n, uint32_t *table) {
     BN_KERNEL_PROLOGUE();
+    BN_STAMP_BEGIN();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -275,6 +276,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     ExpTableMem tbl = {table, t, gridDim.x * BLOCK, 0};
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair), tbl);
     if (live) f12_store(f, out + 96u * pair);
+    BN_STAMP_END();
 }
 // ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
 constexpr int NCOEFF = 102, COEFF_WORDS = 48;
@@ -361,6 +363,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     Fq12<F2> res = f12_one<F2>();
 #pragma unroll 1
     for (int i = 255; i >= 0; --i) {
+        BN_EXP_HOOK(255 - i, 256);
         res = f12_sqr(res);
         Fq12<F2> m = f12_mul(base, res);
         bool bit = (raw[i >> 5] >> (i & 31)) & 1;

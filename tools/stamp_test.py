@@ -7,17 +7,24 @@ import bn_amd
 from bn_amd import _native, distributed as D
 dev = torch.device("cuda", 0)
 eng = D.TorchEngine(bn_amd.Engine(0), dev)
-n = 1 << 16
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 16
 P, Q = D.synthetic_points(eng, 0, n)
 out = eng.empty(n, 48)
+which = sys.argv[1] if len(sys.argv) > 1 else "miller"
 for _ in range(5):
     eng.e.miller_batch_dev(P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, eng._stream())
 torch.cuda.synchronize()
+if which == "final_exp":                       # the stamps of the LAST kernel that ran are the ones read back
+    out2 = eng.empty(n, 48)
+    for _ in range(5):
+        eng.e.final_exp_batch_dev(out.data_ptr(), out2.data_ptr(), n, eng._stream())
+    torch.cuda.synchronize()
 lib = _native.lib()
-st = np.zeros(3 * 2048, np.uint64)
+nw = (2 * n + 63) // 64
+st = np.zeros(3 * nw, np.uint64)
 lib.bn254_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.bn254_debug_stamps(st.ctypes.data, st.size) == 0
-st = st.reshape(2048, 3)
+st = st.reshape(nw, 3)
 t0, t1, xcc = st[:, 0].astype(np.int64), st[:, 1].astype(np.int64), st[:, 2]
 base = t0.min()
 print("kernel span (100 MHz ticks -> us):", (t1.max() - base) / 100)
@@ -29,7 +36,7 @@ wave_id = hw & 15; simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 
 key = ((xcc * 8 + se) * 2 + sh) * 16 * 4 + cu * 4 + simd
 import collections
 pairs = collections.defaultdict(list)
-for i in range(2048): pairs[int(key[i])].append(((t1[i] - t0[i]) / 100, int(wave_id[i])))
+for i in range(nw): pairs[int(key[i])].append(((t1[i] - t0[i]) / 100, int(wave_id[i])))
 sizes = collections.Counter(len(v) for v in pairs.values()); print("waves per SIMD histogram:", dict(sizes), " distinct SIMDs:", len(pairs))
 two = [sorted(v) for v in pairs.values() if len(v) == 2]
 if two:
