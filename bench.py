@@ -58,13 +58,7 @@ def cpu_baseline(batch_p, batch_q):
     import bn_oracle
     bn_oracle.build()
     o = bn_oracle.Oracle()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:                                   # respect a cgroup CPU quota (the GPU box grants 16 of its 256 hardware threads)
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            cores = max(1, min(cores, int(int(quota) / int(period))))
-    except Exception:
-        pass
+    cores = bn_oracle.usable_cpus()          # respects a cgroup CPU quota (the GPU box grants 16 of its 256 hardware threads)
     t0 = time.perf_counter(); o.pairing_batch(batch_p[:8], batch_q[:8], nthreads=1); t1 = (time.perf_counter() - t0) / 8
     n = int(min(len(batch_p), max(cores, min(4096, 20.0 / t1))))   # ~20 s of single-thread work
     t0 = time.perf_counter(); o.pairing_batch(batch_p[:n], batch_q[:n], nthreads=cores); dt = time.perf_counter() - t0

@@ -37,6 +37,19 @@ def _p(a):
     return a.ctypes.data_as(_U64P)
 
 
+def usable_cpus():
+    """hardware threads this process may actually use: the affinity mask, capped by a cgroup v2 CPU quota (the GPU box
+    shows 256 threads but grants 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def _u64(a, n=None):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     if n is not None:
@@ -150,7 +163,7 @@ class Oracle:
     def pairing_batch(self, p, q, nthreads=None):
         p = _u64(p).reshape(-1, 12); q = _u64(q).reshape(-1, 24); n = p.shape[0]; assert q.shape[0] == n
         o = np.empty((n, 48), np.uint64)
-        self.lib.bno_pairing_batch(_p(p), _p(q), _p(o), n, nthreads or os.cpu_count() or 1); return o
+        self.lib.bno_pairing_batch(_p(p), _p(q), _p(o), n, nthreads or usable_cpus()); return o
 
     def pairing_product(self, p, q):
         p = _u64(p).reshape(-1, 12); q = _u64(q).reshape(-1, 24); n = p.shape[0]; assert q.shape[0] == n
@@ -159,7 +172,7 @@ class Oracle:
     def _mulb(self, fn, w, p, k, nthreads):
         p = _u64(p).reshape(-1, w); k = _u64(k).reshape(-1, 4); n = p.shape[0]; assert k.shape[0] == n
         o = np.empty((n, w), np.uint64)
-        getattr(self.lib, fn)(_p(p), _p(k), _p(o), n, nthreads or os.cpu_count() or 1); return o
+        getattr(self.lib, fn)(_p(p), _p(k), _p(o), n, nthreads or usable_cpus()); return o
     def g1_mul_batch(self, p, k, nthreads=None): return self._mulb("bno_g1_mul_batch", 12, p, k, nthreads)
     def g2_mul_batch(self, p, k, nthreads=None): return self._mulb("bno_g2_mul_batch", 24, p, k, nthreads)
     def g1_mul_batch_jacobian(self, p, k, nthreads=None): return self._mulb("bno_g1_mul_batch_jacobian", 12, p, k, nthreads)

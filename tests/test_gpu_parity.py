@@ -158,7 +158,7 @@ def test_device_resident_path_and_input_generator(oracle):
 
 
 def test_full_size_batch_properties(oracle):
-    """BASELINE.json configs[1] size (2^16): a 1024-index random sample against the oracle, both lane mappings agree on the
+    """BASELINE.json configs[1] size (2^16): the whole batch against the oracle, both lane mappings agree on the
     whole batch, determinism, and product(batch) == pairing_product (size-independent checks)"""
     import torch
     import bn_amd
@@ -171,7 +171,11 @@ def test_full_size_batch_properties(oracle):
     outB = D.pairing_batch_sharded(engB, P, Q); outB2 = D.pairing_batch_sharded(engB, P, Q); outA = D.pairing_batch_sharded(engA, P, Q)
     torch.cuda.synchronize()
     assert torch.equal(outB, outB2) and torch.equal(outA, outB)
-    idx = np.random.default_rng(5).choice(n, 1024, replace=False)
+    # SURVEY 8d parity protocol: memcmp of the FULL 2^16 batch against the multi-threaded CPU oracle (~15 s on 16 host threads);
+    # on a host with few cores a 2048-index random sample instead
+    import bn_oracle
+    cores = bn_oracle.usable_cpus()
+    idx = np.arange(n) if cores >= 8 else np.random.default_rng(5).choice(n, 2048, replace=False)
     Pn = P.cpu().numpy().view(np.uint64)[idx]; Qn = Q.cpu().numpy().view(np.uint64)[idx]
     assert np.array_equal(outB.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn, Qn))
     prod_of_batch = engB.gt_product(outB)                       # product of the 2^16 reduced pairings ...
