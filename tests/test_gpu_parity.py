@@ -186,7 +186,7 @@ def test_full_size_batch_properties(oracle):
 
 def test_g1_mul_full_size_config5(oracle):
     """BASELINE.json configs[4]: 2^20 G1 scalar multiplications by random Fr on one GPU (windowed kernel, normalized output):
-    a 512-index sample against the oracle, and the two device algorithms (windowed vs the reference's own chain) agree on all
+    a 16384-index sample against the oracle, and the two device algorithms (windowed vs the reference's own chain) agree on all
     2^20 after normalization (compared on the GPU through a second normalization-by-one)"""
     import torch
     import bn_amd
@@ -203,7 +203,7 @@ def test_g1_mul_full_size_config5(oracle):
     out2 = te.g1_mul(jac, one, normalize=True)                        # normalize(chain result) via * 1
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
-    idx = np.random.default_rng(9).choice(n, 512, replace=False)
+    idx = np.random.default_rng(9).choice(n, 16384, replace=False)
     Pn = P.cpu().numpy().view(np.uint64)[idx]; kn = k.cpu().numpy().view(np.uint64)[idx]
     assert np.array_equal(out.cpu().numpy().view(np.uint64)[idx], canon_infinity(oracle.g1_mul_batch(Pn, kn)))
 
