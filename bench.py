@@ -1,33 +1,45 @@
 #!/usr/bin/env python3
 """Benchmark of the BN254 pairing hot path on MI355X (BASELINE.json metric: optimal-ate pairings/sec, bit-exact).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE re-launches itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of `pairing_batch` over one batch of 2^16 synthetic (r*G1, s*G2) pairs per GPU, resident in HBM
-(BASELINE.json configs[1]; with N GPUs every rank owns its own 2^16 pairs: weak scaling, no data-path collective).
+A "step" is one pass of `pairing_batch` over one batch of synthetic (r*G1, s*G2) pairs resident in HBM:
+  N = 1   BASELINE.json configs[1]: 2^16 independent pairings on one MI355X;
+  N > 1   BASELINE.json configs[2]: 2^20 independent pairings sharded over the N GPUs (2^20/N each, contiguous index ranges, no
+          data-path collective) - total work fixed, so "scaling": "strong".
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline     the dominant kernel's algorithmic 32x32->64 MACs per launch / its HIP-event-measured duration, against the
-               measured v_mad_u64_u32 peak of the chip (this path is integer-VALU bound, not HBM or MFMA: SURVEY.md 8d);
-               `traffic` is the rocprofv3 HBM byte count per launch from profiles/ (null if not collected)
+               v_mad_u64_u32 issue peak of the chip MEASURED IN THIS RUN (bn254_ubench_mac32 in the untimed prologue; this path is
+               integer-VALU bound, not HBM or MFMA: SURVEY.md 8d); `traffic` is the rocprofv3 HBM byte count per launch taken
+               from profiles/ (a separate --pmc run, not this run - `traffic_source` says which)
+  host_api     PCIe-inclusive rate of the host-buffer entry point bn254_pairing_batch on pageable numpy buffers (never `value`)
   cpu_baseline the reference-faithful CPU port (oracle/) timed on this box's host cores on a bounded sample
+Side workloads (--workload g1mul | g2mul | gtpow | prepared | product) print the same kind of line for their own metric.
 """
 import argparse
 import json
 import os
 import pathlib
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-BATCH = 1 << 16
-# algorithmic work per pairing (DESIGN.md "Work per pairing"): Fq multiplication equivalents of the reference's formulas
-# with 3-mult Fq2 products and add-only beta/xi, x 136 MAC32 (8x32-bit-limb Montgomery), split by kernel
+BATCH = 1 << 16               # configs[1]
+TOTAL_MULTI = 1 << 20         # configs[2]: total over all GPUs when N > 1
+PRODUCT_TOTAL = 1 << 18       # configs[3]
+# algorithmic work per unit: Fq multiplication equivalents of the reference's formulas with 3-mult Fq2
+# products, 2-mult Fq2 squarings and add-only beta/xi, x 136 MAC32 (8x32-bit-limb Montgomery)
+MAC32_PER_FQMUL = 136
 MAC32_PER_PAIRING = 2.583e6
 KERNEL_SHARE = {"miller": 9919 / 18686, "final_exp": 8767 / 18686}
-PEAK_TMAC32 = 30.1            # measured v_mad_u64_u32 issue peak, profiles/r01_ubench_valu_rates.txt (1024 SIMDs x 0.459 G/s x 64)
+MAC32_PER_G1MUL = 3817 * MAC32_PER_FQMUL      # 255 x dbl-2009-l (2M+5S) + 127 x add-2007-bl (11M+5S), groups/mod.rs:228-311
+MAC32_PER_G2MUL = 9541 * MAC32_PER_FQMUL      # the same chain over Fq2 (M = 3, S = 2 Fq products)
+MAC32_PER_GTPOW = 16128 * MAC32_PER_FQMUL     # 256 Fq12 squarings (36) + 128 Fq12 products (54), fields/mod.rs:35-46
 ALGO_BYTES_PER_PAIRING = 672
 
 
@@ -52,6 +64,40 @@ def _max_over_ranks(dist, dev, elapsed):
     return float(t.item())
 
 
+def measured_peak(eng):
+    """same-run ceiling: G lane-MAC32/s of a pure v_mad_u64_u32 stream at 8 waves/SIMD (the chip's issue peak) and at the 2
+    waves/SIMD the pairing kernels run at (256 VGPRs each)"""
+    best8 = max(eng.e.ubench_mac32(8, 1 << 14)[0] for _ in range(3))
+    best2 = max(eng.e.ubench_mac32(2, 1 << 14)[0] for _ in range(3))
+    return best8 / 1e3, best2 / 1e3            # T MAC32/s
+
+
+def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=None):
+    """roofline object for the dominant kernel among `stats` = {name: (total_ms, launches)}"""
+    peak8, peak2 = measured_peak(eng)
+    dom = max(stats, key=lambda k: stats[k][0])
+    per = {}
+    for k, (ms, cnt) in stats.items():
+        if not cnt:
+            continue
+        avg = ms * 1e-3 / cnt
+        share = shares[k] if shares else 1.0
+        ach = unit_count * mac32_per_unit * share / avg / 1e12
+        per[k] = {"avg_launch_ms": avg * 1e3, "launches": cnt, "achieved": ach, "frac": ach / peak8}
+    traffic, src = None, None
+    tf = ROOT / "profiles" / "pmc_traffic.json"
+    if traffic_key and tf.exists():
+        ent = json.loads(tf.read_text()).get(dom, {})
+        traffic = ent.get("hbm_bytes_per_launch")
+        src = (ent.get("source", "profiles/pmc_traffic.json") + " (separate rocprofv3 --pmc run at 2^16 pairings per launch, NOT this run)") if traffic else None
+    d = per[dom]
+    return {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": d["achieved"], "peak": peak8,
+            "unit": "TMAC32/s", "frac": d["frac"],
+            "peak_source": "bn254_ubench_mac32 in this run: pure v_mad_u64_u32 stream, 8 waves/SIMD",
+            "peak_at_kernel_occupancy": peak2, "kernel_occupancy_waves_per_simd": 2, "frac_of_occupancy_peak": d["achieved"] / peak2,
+            "traffic": traffic, "traffic_source": src, "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"], "kernels": per}
+
+
 def cpu_baseline(batch_p, batch_q):
     """reference-faithful CPU port on all host cores, bounded sample (~20 s of CPU work)"""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -66,63 +112,112 @@ def cpu_baseline(batch_p, batch_q):
             "sample": f"{n} pairings of the same synthetic batch on {cores} threads ({dt:.2f} s wall); 1 thread: {t1 * 1e3:.2f} ms/pairing"}
 
 
-def bench_g1mul(args, eng, dev, world, rank, local_rank):
-    """side metric (not the headline): 2^20 normalized G1 scalar multiplications per GPU per step"""
-    import numpy as np
-    import torch
+def host_api_rate(gpu_index, Pn, Qn, reps=5):
+    """what a binding of the reference's `pairing` gets: pageable host buffers in and out through bn254_pairing_batch (chunked,
+    pinned staging, copies overlapped with the kernels)"""
+    import bn_amd
+    e = bn_amd.Engine(gpu_index)
+    e.pairing_batch(Pn, Qn)                                  # allocates the pinned / device staging
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e.pairing_batch(Pn, Qn)
+    dt = (time.perf_counter() - t0) / reps
+    n = Pn.shape[0]
+    e.close()
+    return {"value": n / dt, "unit": "pairings/s", "ms_per_call": dt * 1e3,
+            "what": f"bn254_pairing_batch, {n} pairings per call, pageable numpy buffers: H2D {n * 288 / 1e6:.1f} MB + kernels + D2H {n * 384 / 1e6:.1f} MB"}
+
+
+def _line(metric, unit, value, world, args, elapsed, scaling, workload, extra=None, cfg=None):
+    d = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+         "dtype": "u32", "data": "synthetic", "config": dict({"workload": workload}, **(cfg or {}))}
+    d.update(extra or {})
+    return d
+
+
+def bench_mul(args, eng, dev, world, rank, which):
+    """side metrics: BASELINE.json configs[4] - 2^20 normalized G1 scalar multiplications of DISTINCT random points by distinct
+    random Fr on one GPU (benches/api.rs:107-111) - and the same for G2 (2^18)"""
     import torch.distributed as dist
     from bn_amd import distributed as D
-    n = 1 << 20
-    base, _ = D.synthetic_points(eng, rank * (1 << 14), (rank + 1) * (1 << 14))
-    P = base.repeat(n >> 14, 1).contiguous()
-    k = torch.from_numpy(D.synthetic_scalars(0, n >> 4, 1).view(np.int64)).to(dev).repeat(16, 1).contiguous()
+    n = (1 << 20) if which == 1 else (1 << 18)
+    lo = rank * n
+    P, Q = D.synthetic_points(eng, lo, lo + n)                              # distinct points r_i*G, Jacobian z != 1
+    pts = P if which == 1 else Q
+    k = D.synthetic_scalars_device(eng, (1 << 24) + lo, (1 << 24) + lo + n, 1)    # distinct scalars, another index range
+    fn = eng.g1_mul if which == 1 else eng.g2_mul
+    name = "g1_mul" if which == 1 else "g2_mul"
     for _ in range(args.warmup):
-        eng.g1_mul(P, k)
+        fn(pts, k)
+    eng.e.profile(True); eng.e.profile_reset()
     _barrier(dist, dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.g1_mul(P, k)
+        fn(pts, k)
     _barrier(dist, dev)
     elapsed = _max_over_ranks(dist, dev, time.perf_counter() - t0)
+    eng.e.profile(False)
     if rank == 0:
-        print(json.dumps({"metric": "BN254 G1 scalar multiplications/sec (normalized output, bit-exact vs ref)", "value": world * n * args.steps / elapsed,
-                          "unit": "scalar muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-                          "data": "synthetic", "config": {"workload": "2^20 G1 scalar muls by random Fr per GPU per step (BASELINE.json configs[4])"}}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        rf = roofline(eng, {name: eng.e.kernel_stats(name)}, n, MAC32_PER_G1MUL if which == 1 else MAC32_PER_G2MUL)
+        print(json.dumps(_line(f"BN254 G{which} scalar multiplications/sec (normalized output, bit-exact vs ref)", "scalar muls/s",
+                               world * n * args.steps / elapsed, world, args, elapsed, "weak",
+                               f"{n} G{which} scalar muls of distinct random points by distinct random Fr per GPU per step"
+                               + (" (BASELINE.json configs[4])" if which == 1 else ""), {"roofline": rf})), flush=True)
 
 
-def bench_product(args, eng, dev, world, rank, local_rank):
-    """side metric: BASELINE.json configs[3] - multi-pairing product of 2^15 pairs per GPU -> ONE Gt; the only workload with an
-    exchange step: one RCCL all-gather of 384 B per rank, then world-1 Fq12 products and a single final exponentiation"""
-    import torch
+def bench_gtpow(args, eng, dev, world, rank):
+    """side metric: Gt::pow (lib.rs:171) on 2^16 pairing values with distinct random exponents"""
     import torch.distributed as dist
     from bn_amd import distributed as D
-    n = 1 << 15
-    P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
+    n = 1 << 16
+    lo = rank * n
+    P, Q = D.synthetic_points(eng, lo, lo + n)
+    g = eng.pairing_batch(P, Q)
+    k = D.synthetic_scalars_device(eng, (1 << 24) + lo, (1 << 24) + lo + n, 0)
     for _ in range(args.warmup):
-        gt = D.pairing_product_sharded(eng, P, Q)
+        eng.gt_pow(g, k)
+    eng.e.profile(True); eng.e.profile_reset()
     _barrier(dist, dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        gt = D.pairing_product_sharded(eng, P, Q)
+        eng.gt_pow(g, k)
+    _barrier(dist, dev)
+    elapsed = _max_over_ranks(dist, dev, time.perf_counter() - t0)
+    eng.e.profile(False)
+    if rank == 0:
+        rf = roofline(eng, {"gt_pow": eng.e.kernel_stats("gt_pow")}, n, MAC32_PER_GTPOW)
+        print(json.dumps(_line("BN254 Gt::pow/sec (bit-exact vs ref)", "pows/s", world * n * args.steps / elapsed, world, args, elapsed,
+                               "weak", f"{n} Gt values ^ distinct random Fr per GPU per step", {"roofline": rf})), flush=True)
+
+
+def bench_product(args, eng, dev, world, rank):
+    """side metric: BASELINE.json configs[3] - multi-pairing product of 2^18 pairs -> ONE Gt, sharded 2^18/N per GPU; the only
+    workload with an exchange step: one RCCL all-gather of 384 B per rank, then world-1 Fq12 products and a single final
+    exponentiation"""
+    import torch.distributed as dist
+    from bn_amd import distributed as D
+    lo, hi = D.shard_range(PRODUCT_TOTAL, rank, world)
+    P, Q = D.synthetic_points(eng, lo, hi)
+    for _ in range(args.warmup):
+        D.pairing_product_sharded(eng, P, Q)
+    _barrier(dist, dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        D.pairing_product_sharded(eng, P, Q)
     _barrier(dist, dev)
     elapsed = _max_over_ranks(dist, dev, time.perf_counter() - t0)
     if rank == 0:
-        print(json.dumps({"metric": "BN254 pairs/sec folded into one multi-pairing product (bit-exact vs ref)", "value": world * n * args.steps / elapsed,
-                          "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "data": "synthetic",
-                          "config": {"workload": f"product of {n} pairs per GPU -> 1 Gt (BASELINE.json configs[3]); all_gather of 384 B per rank"}}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(_line("BN254 pairs/sec folded into one multi-pairing product (bit-exact vs ref)", "pairs/s",
+                               PRODUCT_TOTAL * args.steps / elapsed, world, args, elapsed, "strong",
+                               f"product of 2^18 pairs -> 1 Gt, {hi - lo} pairs per GPU (BASELINE.json configs[3]); all_gather of 384 B per rank")), flush=True)
 
 
-def bench_prepared(args, eng, dev, world, rank, local_rank):
+def bench_prepared(args, eng, dev, world, rank):
     """side metric: prepared-G2 mode - 2^16 pairings of random P against ONE precomputed Q per GPU per step"""
     import torch
     from bn_amd import distributed as D
-    n = args.batch
+    n = args.batch or BATCH
     P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
     coeffs = eng.empty(102, 24)
     eng.e.g2_precompute_dev(Q.data_ptr(), coeffs.data_ptr(), 1, eng._stream())
@@ -141,10 +236,19 @@ def bench_prepared(args, eng, dev, world, rank, local_rank):
     elapsed = time.perf_counter() - t0
     if rank == 0:
         st = {k: eng.e.kernel_stats(k) for k in ("miller_prepared", "final_exp")}
-        print(json.dumps({"metric": "BN254 pairings/sec against one prepared G2 point (bit-exact vs ref)", "value": world * n * args.steps / elapsed,
-                          "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "higher_is_better": True, "data": "synthetic", "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in st.items()},
-                          "config": {"workload": f"{n} random P against one precomputed Q (102 x 192 B coefficients shared by all lanes)"}}), flush=True)
+        print(json.dumps(_line("BN254 pairings/sec against one prepared G2 point (bit-exact vs ref)", "pairings/s", world * n * args.steps / elapsed,
+                               world, args, elapsed, "weak", f"{n} random P against one precomputed Q (102 x 192 B coefficients shared by all lanes)",
+                               {"kernel_ms": {k: v[0] / max(v[1], 1) for k, v in st.items()}})), flush=True)
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a rendezvous environment: start N ranks of this script on one node"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(pathlib.Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -152,12 +256,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH, help="pairings per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="pairings per GPU per step (default: 2^16 at N = 1, 2^20/N at N > 1)")
     ap.add_argument("--mapping", type=int, default=None, help="0: one lane per pairing, 1: lane pair per pairing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["pairing", "g1mul", "prepared", "product"], default="pairing",
-                    help="pairing: the headline metric (default); g1mul: BASELINE.json configs[4], 2^20 G1 scalar muls (side metric)")
+    ap.add_argument("--no-host-api", action="store_true")
+    ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product"], default="pairing",
+                    help="pairing: the headline metric (default); the others are side metrics with their own line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
 
     import numpy as np
     import torch
@@ -170,7 +278,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: bn_amd has no CPU path")
     # Test hooks for a ONE-GPU box (never set by the driver): all ranks share cuda:0 and rendezvous over gloo, which exercises
@@ -187,65 +295,64 @@ def main():
             dist.init_process_group(backend)
 
     eng = D.TorchEngine(bn_amd.Engine(gpu_index, mapping=args.mapping), dev)
-    if args.workload == "g1mul":
-        return bench_g1mul(args, eng, dev, world, rank, local_rank)
-    if args.workload == "prepared":
-        return bench_prepared(args, eng, dev, world, rank, local_rank)
-    if args.workload == "product":
-        return bench_product(args, eng, dev, world, rank, local_rank)
-    n = args.batch
-    lo = rank * n
-    P, Q = D.synthetic_points(eng, lo, lo + n)              # untimed: inputs resident in HBM before the clock starts
-    out = eng.empty(n, 48)
+    try:
+        if args.workload in ("g1mul", "g2mul"):
+            return bench_mul(args, eng, dev, world, rank, 1 if args.workload == "g1mul" else 2)
+        if args.workload == "gtpow":
+            return bench_gtpow(args, eng, dev, world, rank)
+        if args.workload == "prepared":
+            return bench_prepared(args, eng, dev, world, rank)
+        if args.workload == "product":
+            return bench_product(args, eng, dev, world, rank)
 
-    def sync():
+        if args.batch is not None:
+            n = args.batch; lo = rank * n; scaling = "weak"; total = world * n
+            workload = f"{n} independent pairings per GPU per step (--batch override)"
+        elif world == 1:
+            n = BATCH; lo = 0; scaling = "weak"; total = n
+            workload = "2^16 independent pairings per step on 1 MI355X (BASELINE.json configs[1])"
+        else:
+            lo, hi = D.shard_range(TOTAL_MULTI, rank, world)
+            n = hi - lo; scaling = "strong"; total = TOTAL_MULTI
+            workload = f"2^20 independent pairings per step sharded over {world} MI355X, {n} per GPU, contiguous ranges (BASELINE.json configs[2])"
+        P, Q = D.synthetic_points(eng, lo, lo + n)              # untimed: inputs resident in HBM before the clock starts
+        out = eng.empty(n, 48)
+
+        for _ in range(args.warmup):
+            D.pairing_batch_sharded(eng, P, Q, out)
+        eng.e.profile(True); eng.e.profile_reset()
         _barrier(dist, dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            D.pairing_batch_sharded(eng, P, Q, out)
+        _barrier(dist, dev)
+        elapsed = time.perf_counter() - t0
+        eng.e.profile(False)
+        elapsed = _max_over_ranks(dist, dev, elapsed)
 
-    for _ in range(args.warmup):
-        D.pairing_batch_sharded(eng, P, Q, out)
-    eng.e.profile(True); eng.e.profile_reset()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        D.pairing_batch_sharded(eng, P, Q, out)
-    sync()
-    elapsed = time.perf_counter() - t0
-    eng.e.profile(False)
-    elapsed = _max_over_ranks(dist, dev, elapsed)
-
-    if rank == 0:
-        value = world * n * args.steps / elapsed
-        stats = {k: eng.e.kernel_stats(k) for k in ("miller", "final_exp")}
-        dom = max(stats, key=lambda k: stats[k][0])
-        ms, cnt = stats[dom]
-        avg_s = ms * 1e-3 / max(cnt, 1)
-        achieved = n * MAC32_PER_PAIRING * KERNEL_SHARE[dom] / avg_s / 1e12
-        traffic = None
-        tf = ROOT / "profiles" / "pmc_traffic.json"
-        if tf.exists():
-            traffic = json.loads(tf.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
-        line = {
-            "metric": "BN254 optimal-ate pairings/sec (bit-exact vs ref)", "value": value, "unit": "pairings/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": f"{n} independent pairings per GPU per step, inputs r*G1 / s*G2 (Jacobian, z != 1) resident in HBM "
-                                   "(BASELINE.json configs[1])", "pairings_per_gpu": n, "parallelism": f"dp{world} (sharded, no collective)",
-                       "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
-                       "mapping": 1 if args.mapping is None else args.mapping},
-            "roofline": {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": achieved,
-                         "peak": PEAK_TMAC32, "unit": "TMAC32/s", "frac": achieved / PEAK_TMAC32, "traffic": traffic,
-                         "hbm_GBps_of_8000": None if traffic is None else traffic / avg_s / 1e9,
-                         "avg_launch_ms": avg_s * 1e3, "launches": cnt,
-                         "algorithmic_hbm_bytes_per_launch": n * ALGO_BYTES_PER_PAIRING,
-                         "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in stats.items()}},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            Pn = P[:4096].cpu().numpy().view(np.uint64); Qn = Q[:4096].cpu().numpy().view(np.uint64)
-            line["cpu_baseline"] = cpu_baseline(Pn, Qn)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        if rank == 0:
+            stats = {k: eng.e.kernel_stats(k) for k in ("miller", "final_exp")}
+            rf = roofline(eng, stats, n, MAC32_PER_PAIRING, KERNEL_SHARE, traffic_key=True)
+            rf["algorithmic_hbm_bytes_per_launch"] = n * ALGO_BYTES_PER_PAIRING
+            if n != BATCH:
+                rf["traffic"] = rf["traffic_source"] = None          # the PMC figures in profiles/ were taken at 2^16 per launch
+            if rf["traffic"] is not None:
+                rf["hbm_GBps_of_8000"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+            line = _line("BN254 optimal-ate pairings/sec (bit-exact vs ref)", "pairings/s", total * args.steps / elapsed, world, args, elapsed,
+                         scaling, workload, {"roofline": rf},
+                         {"pairings_per_gpu": n, "inputs": "r*G1 / s*G2 (Jacobian, z != 1) resident in HBM", "parallelism": f"dp{world} (sharded, no collective)",
+                          "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
+                          "mapping": 1 if args.mapping is None else args.mapping})
+            if world == 1:
+                Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
+                if not args.no_host_api:
+                    line["host_api"] = host_api_rate(gpu_index, Pn, Qn)
+                if not args.no_cpu_baseline:
+                    line["cpu_baseline"] = cpu_baseline(Pn[:4096], Qn[:4096])
+            print(json.dumps(line), flush=True)
+    finally:
+        if world > 1 and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

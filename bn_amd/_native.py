@@ -7,9 +7,8 @@ import subprocess
 
 HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("BN254_LIB_PATH", HERE / "libbn254_hip.so"))     # override: kernel experiments only
-SRC = HERE / "csrc" / "bn254_hip.hip"
-SRC_B = HERE / "csrc" / "bn254_kernels_b.hip"
-SRC_MUL = HERE / "csrc" / "bn254_kernels_mul.hip"
+SOURCES = [HERE / "csrc" / f for f in ("bn254_hip.hip", "bn254_kernels_b.hip", "bn254_kernels_mul.hip", "bn254_multi.hip")]
+OBJ_DIR = HERE / "csrc" / "build"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 _VP = C.c_void_p
@@ -39,6 +38,18 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_miller_prepared_dev": [_VP, _VP, _VP, C.c_int, _VP, _SZ, _VP],
     "bn254_gt_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_gt_pow_batch": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_gt_inverse_batch": [_VP, _VP, _VP, _SZ],
+    "bn254_gt_inverse_batch_dev": [_VP, _VP, _VP, _SZ, _VP],
+    "bn254_multi_create": [C.POINTER(C.c_int), C.c_int, C.POINTER(_VP)],
+    "bn254_multi_destroy": [_VP],
+    "bn254_multi_device_count": [_VP],
+    "bn254_multi_exchange_kind": [_VP],
+    "bn254_multi_ctx": [_VP, C.c_int],
+    "bn254_pairing_batch_multi": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_pairing_product_multi": [_VP, _VP, _VP, _SZ, _VP],
+    "bn254_synthetic_scalars_dev": [_VP, C.c_uint64, C.c_uint64, _SZ, C.c_int, _VP, _VP],
+    "bn254_tile_dev": [_VP, _VP, _SZ, _SZ, _VP, _VP],
+    "bn254_ubench_mac32": [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "bn254_gt_mul_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
     "bn254_gt_pow_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
     "bn254_pairing_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
@@ -57,16 +68,35 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
 
 
 def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU; the .so is kept in-tree so it travels to the GPU box."""
-    deps = [SRC, SRC_B, SRC_MUL] + sorted((HERE / "csrc").glob("*.hpp")) + [HERE.parent / "include" / "bn254_hip.h"]
-    if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(d.stat().st_mtime for d in deps):
-        return LIB_PATH
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-    cmd += os.environ.get("BN254_EXTRA_HIPCC_FLAGS", "").split()           # experiments only
-    cmd += [str(SRC), str(SRC_B), str(SRC_MUL), "-o", str(LIB_PATH)]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    """hipcc cross-compiles for gfx950 without a GPU; the .so is kept in-tree so it travels to the GPU box.  The translation
+    units are compiled in parallel into csrc/build/*.o and only those whose inputs changed are rebuilt."""
+    import concurrent.futures
+    hdrs = sorted((HERE / "csrc").glob("*.hpp")) + [HERE.parent / "include" / "bn254_hip.h"]
+    hdr_m = max(h.stat().st_mtime for h in hdrs)
+    extra = os.environ.get("BN254_EXTRA_HIPCC_FLAGS", "").split()           # experiments only
+    flags = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + extra
+    OBJ_DIR.mkdir(exist_ok=True)
+    stamp = OBJ_DIR / "flags.txt"
+    if not stamp.exists() or stamp.read_text() != " ".join(flags):
+        force = True
+    jobs = []
+    for src in SOURCES:
+        obj = OBJ_DIR / (src.stem + ".o")
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_m):
+            jobs.append(flags + ["-c", str(src), "-o", str(obj)])
+    if jobs:
+        if verbose:
+            for j in jobs:
+                print(" ".join(j))
+        with concurrent.futures.ThreadPoolExecutor(len(jobs)) as ex:
+            list(ex.map(subprocess.check_call, jobs))
+        stamp.write_text(" ".join(flags))
+    objs = [OBJ_DIR / (src.stem + ".o") for src in SOURCES]
+    if jobs or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < max(o.stat().st_mtime for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [str(o) for o in objs] + ["-ldl", "-lpthread", "-o", str(LIB_PATH)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB_PATH
 
 
@@ -90,6 +120,10 @@ def _preload_shared_hip_runtime():
         if c and os.path.exists(c):
             try:
                 C.CDLL(c, mode=C.RTLD_GLOBAL)
+                # the multi-device path dlopens RCCL lazily: it must be the one built against THIS runtime
+                rccl = os.path.join(os.path.dirname(c), "librccl.so")
+                if os.path.exists(rccl):
+                    os.environ.setdefault("BN254_RCCL_PATH", rccl)
                 return c
             except OSError:
                 continue
@@ -110,6 +144,8 @@ def lib():
             fn.restype = C.c_int
         l.bn254_error_string.restype = C.c_char_p
         l.bn254_ctx_destroy.restype = None
+        l.bn254_multi_destroy.restype = None
+        l.bn254_multi_ctx.restype = C.c_void_p
         _lib = l
     return _lib
 

@@ -44,8 +44,10 @@ class Fr:
     @staticmethod
     def one(): return Fr(1)
     @staticmethod
-    def from_str(s):                      # lib.rs:24
-        return Fr(int(s)) if s.isdigit() else None
+    def from_str(s):                      # lib.rs:24 -> fields/fp.rs:39-59: ASCII decimal digits only; "" is zero; anything else None
+        if not all(c in "0123456789" for c in s):
+            return None
+        return Fr(int(s)) if s else Fr(0)
     @staticmethod
     def random(rng):                      # uniform mod r from 512 bits, like arith.rs:195-198
         return Fr(int.from_bytes(rng.bytes(64), "little"))
@@ -151,6 +153,8 @@ class Gt:
         return Gt(default_engine().gt_mul_batch(self.limbs, o.limbs)[0])
     def pow(self, k):                     # lib.rs:171
         return Gt(default_engine().gt_pow_batch(self.limbs, k.limbs)[0])
+    def inverse(self):                    # lib.rs:172
+        return Gt(default_engine().gt_inverse_batch(self.limbs)[0])
     def __eq__(self, o): return isinstance(o, Gt) and np.array_equal(self.limbs, o.limbs)   # canonical limbs: memcmp
     def __repr__(self): return "Gt(%s...)" % hex(int(self.limbs[0]))
 

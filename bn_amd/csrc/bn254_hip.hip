@@ -162,98 +162,93 @@ __global__ void __launch_bounds__(BLOCK) bn254_fr_decode_k(const uint8_t *in, ui
 }  // namespace
 
 // ======================================================================================================== host side
-extern "C" int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s);      // bn254_kernels_b.hip
-extern "C" int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hipStream_t s);
-extern "C" size_t bn254_final_exp_table_bytes_B(size_t n);
-extern "C" int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
-extern "C" int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
-extern "C" int bn254_launch_gt_product_B(const void *in, void *out, size_t n, unsigned chunk, hipStream_t s);
-extern "C" int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);   // bn254_kernels_mul.hip
-extern "C" int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);
-extern "C" int bn254_launch_g1_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s);
-extern "C" int bn254_launch_g2_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s);
-extern "C" int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
-extern "C" int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hipStream_t s);
+#include "host_ctx.hpp"
 
-struct bn254_ctx {
-    int device = 0;
-    int mapping = 1;                    // 1: lane-pair mapping (default), 0: one lane per pairing
-    hipStream_t stream = nullptr;       // used by the host-buffer entry points
-    void *ws = nullptr;                 // workspace (Miller values, product-tree levels)
-    size_t ws_bytes = 0;
-    void *exp_tbl = nullptr;            // odd-power tables of the windowed exponentiation by u (final_exp_B), grow-only
-    size_t exp_tbl_bytes = 0;
-    void *stage[3] = {nullptr, nullptr, nullptr};   // device staging of the host-buffer entry points (grow-only, reused)
-    size_t stage_bytes[3] = {0, 0, 0};
-    bool profile = false;
-    struct Rec { std::string name; hipEvent_t a, b; };
-    std::vector<Rec> recs;
-};
+// bn254_multi.hip: chunked, double-buffered host-buffer path (pinned staging, one stream + worker thread per chunk in flight)
+struct BnMapSpec;
+int bn_pairing_batch_pipelined(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n);
+int bn_mul_batch_pipelined(bn254_ctx *ctx, int g, const void *p, const bn_fr *k, void *out, size_t n);
 
 namespace {
 
-#define HIP_TRY(expr)                         \
-    do {                                      \
-        hipError_t e__ = (expr);              \
-        if (e__ != hipSuccess) return (int)e__; \
-    } while (0)
-
+constexpr int MAX_DEFAULT_CTX = 64;
 std::mutex g_default_mu;
-bn254_ctx *g_default = nullptr;
+bn254_ctx *g_default[MAX_DEFAULT_CTX] = {};
 
-int get_ctx(bn254_ctx *&ctx) {
-    if (ctx) return BN254_OK;
-    std::lock_guard<std::mutex> lk(g_default_mu);
-    if (!g_default) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return BN254_E_NO_DEVICE;
-        int rc = bn254_ctx_create(dev, &g_default);
-        if (rc) return rc;
-    }
-    ctx = g_default;
-    return BN254_OK;
-}
-int ensure_ws(bn254_ctx *c, size_t bytes) {
-    if (c->ws_bytes >= bytes) return BN254_OK;
-    if (c->ws) { HIP_TRY(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
-    if (hipMalloc(&c->ws, bytes) != hipSuccess) return BN254_E_ALLOC;
-    c->ws_bytes = bytes;
-    return BN254_OK;
-}
-struct Scope {      // brackets one kernel launch with events when profiling is on
-    bn254_ctx *c; hipStream_t s; bool on; hipEvent_t a, b; const char *name;
-    Scope(bn254_ctx *c_, hipStream_t s_, const char *n) : c(c_), s(s_), on(c_->profile), name(n) {
-        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
-    }
-    ~Scope() {
-        if (on) { hipEventRecord(b, s); c->recs.push_back({name, a, b}); }
-    }
-};
 inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
+// folds the oldest finished records into the per-name totals and recycles their events (bounded memory with profiling left on)
+void fold_records(bn254_ctx *c, size_t keep) {
+    size_t drop = c->recs.size() > keep ? c->recs.size() - keep : 0;
+    for (size_t i = 0; i < drop; ++i) {
+        auto &r = c->recs[i];
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto &t = c->folded[r.name];
+            t.first += ms; t.second += 1;
+        }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    c->recs.erase(c->recs.begin(), c->recs.begin() + drop);
+}
+
+}  // namespace
+
+BnScope::BnScope(bn254_ctx *c_, hipStream_t s_, const char *n) : c(c_), s(s_), on(c_->profile), name(n) {
+    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+}
+BnScope::~BnScope() {
+    if (!on) return;
+    hipEventRecord(b, s);
+    std::lock_guard<std::mutex> lk(c->prof_mu);
+    c->recs.push_back({name, a, b});
+    if (c->recs.size() > 4096) fold_records(c, 2048);
+}
+
+BnScratchGuard::BnScratchGuard(bn254_ctx *c_, hipStream_t s_) : c(c_), s(s_), rc(BN254_OK) {
+    c->scratch_mu.lock();
+    if (c->scratch_used && c->scratch_stream != s) rc = (int)hipStreamWaitEvent(s, c->scratch_ev, 0);
+}
+BnScratchGuard::~BnScratchGuard() {
+    if (!c->scratch_ev) hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming);
+    if (c->scratch_ev && hipEventRecord(c->scratch_ev, s) == hipSuccess) { c->scratch_used = true; c->scratch_stream = s; }
+    c->scratch_mu.unlock();
+}
+
+int bn_get_ctx(bn254_ctx *&ctx) {
+    if (ctx) return BN254_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEFAULT_CTX) return BN254_E_NO_DEVICE;
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default[dev]) {
+        int rc = bn254_ctx_create(dev, &g_default[dev]);
+        if (rc) return rc;
+    }
+    ctx = g_default[dev];
+    return BN254_OK;
+}
+
 // naf: the value is only consumed by a final exponentiation, so the shorter NAF schedule may be used (pairing.hpp)
-int launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf = false) {
-    Scope sc(c, s, "miller");
+int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf) {
+    BnScope sc(c, s, "miller");
     if (c->mapping == 1) return bn254_launch_miller_B(p, q, f, n, naf ? 1 : 0, s);
     hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
-int launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s) {
-    Scope sc(c, s, "final_exp");
+// table: the caller's own table buffer (pipelined path: one per chunk in flight) or NULL for the context's (under a BnScratchGuard)
+int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table) {
     if (c->mapping == 1) {
-        size_t need = bn254_final_exp_table_bytes_B(n);
-        if (c->exp_tbl_bytes < need) {
-            if (c->exp_tbl) { HIP_TRY(hipFree(c->exp_tbl)); c->exp_tbl = nullptr; c->exp_tbl_bytes = 0; }
-            if (hipMalloc(&c->exp_tbl, need) != hipSuccess) return BN254_E_ALLOC;
-            c->exp_tbl_bytes = need;
-        }
-        return bn254_launch_final_exp_B(f, out, n, c->exp_tbl, s);
+        BnBuf *t = table ? table : &c->exp_tbl;
+        int rc = t->reserve(bn254_final_exp_table_bytes_B(n)); if (rc) return rc;
+        BnScope sc(c, s, "final_exp");
+        return bn254_launch_final_exp_B(f, out, n, t->p, s);
     }
+    BnScope sc(c, s, "final_exp");
     hipLaunchKernelGGL(bn254_final_exp_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
 // reduces n Fq12 values at `in` to one at `out` using ping-pong space `tmp` (>= 2 * ceil(n/4) * 384 B)
-int launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s) {
+int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s) {
     const uint32_t chunk = 4;
     const uint32_t *src = (const uint32_t *)in;
     size_t level_cap = (n + chunk - 1) / chunk;
@@ -264,7 +259,7 @@ int launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp,
         uint32_t *dst = (m == 1) ? (uint32_t *)out : (useA ? bufA : bufB);
         int rc;
         {
-            Scope sc(c, s, "gt_product");
+            BnScope sc(c, s, "gt_product");
             if (c->mapping == 1) {
                 rc = bn254_launch_gt_product_B(src, dst, n, chunk, s);
             } else {
@@ -278,9 +273,18 @@ int launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp,
     }
     return BN254_OK;
 }
-size_t product_tmp_bytes(size_t n) { return 2 * ((n + 3) / 4) * 384 + 384; }
+size_t bn_product_tmp_bytes(size_t n) { return 2 * ((n + 3) / 4) * 384 + 384; }
 
-}  // namespace
+int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize) {
+    BnScope sc(ctx, s, g == 1 ? "g1_mul" : "g2_mul");
+    if (ctx->mapping == 1)          // registers-resident chains; G2 in the lane-pair mapping (bn254_kernels_mul.hip)
+        return g == 1 ? bn254_launch_g1_mul_M(d_p, d_k, d_out, n, normalize, s) : bn254_launch_g2_mul_M(d_p, d_k, d_out, n, normalize, s);
+    if (g == 1)
+        hipLaunchKernelGGL(bn254_g1_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
+    else
+        hipLaunchKernelGGL(bn254_g2_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
+    return (int)hipGetLastError();
+}
 
 extern "C" {
 
@@ -303,11 +307,22 @@ int bn254_ctx_create(int device, bn254_ctx **out) {
 }
 void bn254_ctx_destroy(bn254_ctx *c) {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_default_mu);          // a default context handed out by bn_get_ctx must not dangle
+        for (auto &d : g_default) if (d == c) d = nullptr;
+    }
     hipSetDevice(c->device);
+    hipDeviceSynchronize();
     for (auto &r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-    if (c->ws) hipFree(c->ws);
-    if (c->exp_tbl) hipFree(c->exp_tbl);
-    for (int i = 0; i < 3; ++i) if (c->stage[i]) hipFree(c->stage[i]);
+    c->ws.release(); c->exp_tbl.release(); c->pow_tbl.release();
+    for (auto &b : c->stage) b.release();
+    for (auto &s : c->slot) {
+        for (auto &b : s.d_in) b.release();
+        for (auto &b : s.h_in) b.release();
+        s.d_out.release(); s.h_out.release(); s.tbl.release();
+        if (s.stream) hipStreamDestroy(s.stream);
+    }
+    if (c->scratch_ev) hipEventDestroy(c->scratch_ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -317,76 +332,72 @@ const char *bn254_error_string(int code) {
         case BN254_E_NO_DEVICE: return "no usable HIP device (this engine has no CPU fallback)";
         case BN254_E_BAD_ARG: return "bad argument";
         case BN254_E_ALLOC: return "device allocation failed";
+        case BN254_E_COMM: return "RCCL / peer exchange failed";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
 int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping) {
     if (!ctx || (mapping != 0 && mapping != 1)) return BN254_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->mapping = mapping;
     return BN254_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- device-resident API
+#define BN_DEV_PROLOGUE(null_check, limit)                                           \
+    int rc = bn_get_ctx(ctx); if (rc) return rc;                                     \
+    if (n == 0) return BN254_OK;                                                     \
+    if ((null_check) || n > (limit)) return BN254_E_BAD_ARG;                         \
+    HIP_TRY(hipSetDevice(ctx->device));                                              \
+    hipStream_t s = (hipStream_t)stream
+
 int bn254_miller_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_f, size_t n, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_p || !d_q || !d_f || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    return launch_miller(ctx, d_p, d_q, d_f, n, (hipStream_t)stream);
+    BN_DEV_PROLOGUE(!d_p || !d_q || !d_f, 0x7fffffffu / 96);
+    return bn_launch_miller(ctx, d_p, d_q, d_f, n, s, false);
 }
 int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size_t n, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_f || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    return launch_final_exp(ctx, d_f, d_out, n, (hipStream_t)stream);
+    BN_DEV_PROLOGUE(!d_f || !d_out, 0x7fffffffu / 96);
+    BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
+    return bn_launch_final_exp(ctx, d_f, d_out, n, s, nullptr);
 }
 int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_out, size_t n, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_p || !d_q || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BN_DEV_PROLOGUE(!d_p || !d_q || !d_out, 0x7fffffffu / 96);
+    BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
     // the Miller values are written to d_out and exponentiated in place (same 384-byte slots)
-    rc = launch_miller(ctx, d_p, d_q, d_out, n, (hipStream_t)stream, true); if (rc) return rc;
-    return launch_final_exp(ctx, d_out, d_out, n, (hipStream_t)stream);
+    rc = bn_launch_miller(ctx, d_p, d_q, d_out, n, s, true); if (rc) return rc;
+    return bn_launch_final_exp(ctx, d_out, d_out, n, s, nullptr);
 }
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
     if (!d_out || (n && !d_in) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
     if (n == 0) {       // empty product = one
         bn_gt one; memset(&one, 0, sizeof one);
         one.c[0] = 0xd35d438dc58f0d9dull; one.c[1] = 0x0a78eb28f5c70b3dull; one.c[2] = 0x666ea36f7879462cull; one.c[3] = 0x0e0a77c19a07df2full;
-        HIP_TRY(hipMemcpyAsync(d_out, &one, sizeof one, hipMemcpyHostToDevice, (hipStream_t)stream));
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpyAsync(d_out, &one, sizeof one, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
         return BN254_OK;
     }
-    rc = ensure_ws(ctx, product_tmp_bytes(n)); if (rc) return rc;
-    return launch_product(ctx, d_in, n, d_out, ctx->ws, (hipStream_t)stream);
+    BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
+    rc = ctx->ws.reserve(bn_product_tmp_bytes(n)); if (rc) return rc;
+    return bn_launch_product(ctx, d_in, n, d_out, ctx->ws.p, s);
 }
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
     if (!d_partial || (n && (!d_p || !d_q)) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     if (n == 0) return bn254_gt_product_dev(ctx, nullptr, 0, d_partial, stream);
     HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
     size_t fbytes = n * 384;
-    rc = ensure_ws(ctx, fbytes + product_tmp_bytes(n)); if (rc) return rc;
-    rc = launch_miller(ctx, d_p, d_q, ctx->ws, n, (hipStream_t)stream, true); if (rc) return rc;
-    return launch_product(ctx, ctx->ws, n, d_partial, (char *)ctx->ws + fbytes, (hipStream_t)stream);
+    rc = ctx->ws.reserve(fbytes + bn_product_tmp_bytes(n)); if (rc) return rc;
+    rc = bn_launch_miller(ctx, d_p, d_q, ctx->ws.p, n, s, true); if (rc) return rc;
+    return bn_launch_product(ctx, ctx->ws.p, n, d_partial, (char *)ctx->ws.p + fbytes, s);
 }
 static int mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream, int normalize) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_p || !d_k || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    Scope sc(ctx, (hipStream_t)stream, g == 1 ? "g1_mul" : "g2_mul");
-    if (ctx->mapping == 1)          // registers-resident chains; G2 in the lane-pair mapping (bn254_kernels_mul.hip)
-        return g == 1 ? bn254_launch_g1_mul_M(d_p, d_k, d_out, n, normalize, (hipStream_t)stream) : bn254_launch_g2_mul_M(d_p, d_k, d_out, n, normalize, (hipStream_t)stream);
-    if (g == 1)
-        hipLaunchKernelGGL(bn254_g1_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
-    else
-        hipLaunchKernelGGL(bn254_g2_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
-    return (int)hipGetLastError();
+    BN_DEV_PROLOGUE(!d_p || !d_k || !d_out, 0x7fffffffu / 96);
+    return bn_mul_dev(ctx, g, d_p, d_k, d_out, n, s, normalize);
 }
 int bn254_g1_mul_batch_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 1, p, k, o, n, s, 1); }
 int bn254_g2_mul_batch_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 2, p, k, o, n, s, 1); }
@@ -394,76 +405,52 @@ int bn254_g1_mul_jacobian_dev(bn254_ctx *c, const void *p, const void *k, void *
 int bn254_g2_mul_jacobian_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 2, p, k, o, n, s, 0); }
 
 int bn254_g2_precompute_dev(bn254_ctx *ctx, const void *d_q, void *d_coeffs, size_t n, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_q || !d_coeffs || n > 0x7fffffffu / (102 * 48)) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    Scope sc(ctx, (hipStream_t)stream, "g2_precompute");
-    return bn254_launch_g2_precompute_B(d_q, d_coeffs, n, (hipStream_t)stream);
+    BN_DEV_PROLOGUE(!d_q || !d_coeffs, 0x7fffffffu / (102 * 48));
+    BnScope sc(ctx, s, "g2_precompute");
+    return bn254_launch_g2_precompute_B(d_q, d_coeffs, n, s);
 }
 int bn254_miller_prepared_dev(bn254_ctx *ctx, const void *d_p, const void *d_coeffs, int shared, void *d_f, size_t n, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_p || !d_coeffs || !d_f || n > 0x7fffffffu / (102 * 48)) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    Scope sc(ctx, (hipStream_t)stream, "miller_prepared");
-    return bn254_launch_miller_prepared_B(d_p, d_coeffs, shared, d_f, n, (hipStream_t)stream);
+    BN_DEV_PROLOGUE(!d_p || !d_coeffs || !d_f, 0x7fffffffu / (102 * 48));
+    BnScope sc(ctx, s, "miller_prepared");
+    return bn254_launch_miller_prepared_B(d_p, d_coeffs, shared, d_f, n, s);
 }
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_a || !d_b || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    Scope sc(ctx, (hipStream_t)stream, "gt_mul");
-    return bn254_launch_gt_mul_B(d_a, d_b, d_out, n, (hipStream_t)stream);
+    BN_DEV_PROLOGUE(!d_a || !d_b || !d_out, 0x7fffffffu / 96);
+    BnScope sc(ctx, s, "gt_mul");
+    return bn254_launch_gt_mul_B(d_a, d_b, d_out, n, s);
 }
 int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_a || !d_k || !d_out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    Scope sc(ctx, (hipStream_t)stream, "gt_pow");
-    return bn254_launch_gt_pow_B(d_a, d_k, d_out, n, (hipStream_t)stream);
+    BN_DEV_PROLOGUE(!d_a || !d_k || !d_out, 0x7fffffffu / 96);
+    BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
+    rc = ctx->pow_tbl.reserve(bn254_gt_pow_table_bytes_B(n)); if (rc) return rc;
+    BnScope sc(ctx, s, "gt_pow");
+    return bn254_launch_gt_pow_B(d_a, d_k, d_out, n, ctx->pow_tbl.p, s);
+}
+int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, size_t n, void *stream) {
+    BN_DEV_PROLOGUE(!d_a || !d_out, 0x7fffffffu / 96);
+    BnScope sc(ctx, s, "gt_inverse");
+    return bn254_launch_gt_inverse_B(d_a, d_out, n, s);
 }
 
 // ---------------------------------------------------------------------------------------------- host-buffer API
-namespace {
-// a slot of the context's staging memory: allocated once, grown when a larger batch arrives, freed with the context
-struct DevBuf {
-    bn254_ctx *c; int slot; void *p = nullptr;
-    DevBuf(bn254_ctx *c_, int slot_) : c(c_), slot(slot_) {}
-    int alloc(size_t bytes) {
-        if (bytes == 0) bytes = 1;
-        if (c->stage_bytes[slot] < bytes) {
-            if (c->stage[slot]) { hipFree(c->stage[slot]); c->stage[slot] = nullptr; c->stage_bytes[slot] = 0; }
-            if (hipMalloc(&c->stage[slot], bytes) != hipSuccess) return BN254_E_ALLOC;
-            c->stage_bytes[slot] = bytes;
-        }
-        p = c->stage[slot];
-        return BN254_OK;
-    }
-};
-}
+// Every function below holds the context's mutex for the whole call: concurrent callers of one context (in particular of
+// the default context behind ctx == NULL) are serialised, never interleaved on the staging memory.
+#define BN_HOST_PROLOGUE()                                                           \
+    int rc = bn_get_ctx(ctx); if (rc) return rc;                                     \
+    std::lock_guard<std::mutex> host_lock(ctx->mu);                                  \
+    HIP_TRY(hipSetDevice(ctx->device))
+
 int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
-    int rc = get_ctx(ctx); if (rc) return rc;
     if (n == 0) return BN254_OK;
-    if (!p || !q || !out) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dp(ctx, 0), dq(ctx, 1), dout(ctx, 2);
-    if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
-    HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
-    rc = bn254_pairing_batch_dev(ctx, dp.p, dq.p, dout.p, n, ctx->stream); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return BN254_OK;
+    if (!p || !q || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    return bn_pairing_batch_pipelined(ctx, p, q, out, n);
 }
 int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
-    int rc = get_ctx(ctx); if (rc) return rc;
-    if (!out || (n && (!p || !q))) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dp(ctx, 0), dq(ctx, 1), dpart(ctx, 2);
-    if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dpart.alloc(sizeof(bn_gt)))) return rc;
+    if (!out || (n && (!p || !q)) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    BnBuf &dp = ctx->stage[0], &dq = ctx->stage[1], &dpart = ctx->stage[2];
+    if ((rc = dp.reserve(n * sizeof(bn_g1))) || (rc = dq.reserve(n * sizeof(bn_g2))) || (rc = dpart.reserve(sizeof(bn_gt)))) return rc;
     if (n) {
         HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
@@ -475,29 +462,25 @@ int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;
 }
-static int mul_host(bn254_ctx *ctx, int g, const void *p, const bn_fr *k, void *out, size_t n) {
-    int rc = get_ctx(ctx); if (rc) return rc;
+int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n) {
     if (n == 0) return BN254_OK;
-    if (!p || !k || !out) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
-    DevBuf dp(ctx, 0), dk(ctx, 1), dout(ctx, 2);
-    if ((rc = dp.alloc(n * ps)) || (rc = dk.alloc(n * sizeof(bn_fr))) || (rc = dout.alloc(n * ps))) return rc;
-    HIP_TRY(hipMemcpyAsync(dp.p, p, n * ps, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(dk.p, k, n * sizeof(bn_fr), hipMemcpyHostToDevice, ctx->stream));
-    rc = mul_dev(ctx, g, dp.p, dk.p, dout.p, n, ctx->stream, 1); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, dout.p, n * ps, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return BN254_OK;
+    if (!p || !k || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    return bn_mul_batch_pipelined(ctx, 1, p, k, out, n);
+}
+int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n) {
+    if (n == 0) return BN254_OK;
+    if (!p || !k || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    return bn_mul_batch_pipelined(ctx, 2, p, k, out, n);
 }
 int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, size_t n) {
-    int rc = get_ctx(ctx); if (rc) return rc;
     if (n == 0) return BN254_OK;
     if (!q || !coeffs) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dq(ctx, 0), dc(ctx, 1);
+    BN_HOST_PROLOGUE();
+    BnBuf &dq = ctx->stage[0], &dc = ctx->stage[1];
     size_t cb = n * 102 * sizeof(bn_ell_coeffs);
-    if ((rc = dq.alloc(n * sizeof(bn_g2))) || (rc = dc.alloc(cb))) return rc;
+    if ((rc = dq.reserve(n * sizeof(bn_g2))) || (rc = dc.reserve(cb))) return rc;
     HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
     rc = bn254_g2_precompute_dev(ctx, dq.p, dc.p, n, ctx->stream); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(coeffs, dc.p, cb, hipMemcpyDeviceToHost, ctx->stream));
@@ -505,13 +488,12 @@ int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, s
     return BN254_OK;
 }
 int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_coeffs *coeffs, int shared, bn_gt *out, size_t n) {
-    int rc = get_ctx(ctx); if (rc) return rc;
     if (n == 0) return BN254_OK;
     if (!p || !coeffs || !out) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf dp(ctx, 0), dc(ctx, 1), dout(ctx, 2);
+    BN_HOST_PROLOGUE();
+    BnBuf &dp = ctx->stage[0], &dc = ctx->stage[1], &dout = ctx->stage[2];
     size_t cb = (shared ? 1 : n) * 102 * sizeof(bn_ell_coeffs);
-    if ((rc = dp.alloc(n * sizeof(bn_g1))) || (rc = dc.alloc(cb)) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
+    if ((rc = dp.reserve(n * sizeof(bn_g1))) || (rc = dc.reserve(cb)) || (rc = dout.reserve(n * sizeof(bn_gt)))) return rc;
     HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dc.p, coeffs, cb, hipMemcpyHostToDevice, ctx->stream));
     rc = bn254_miller_prepared_dev(ctx, dp.p, dc.p, shared, dout.p, n, ctx->stream); if (rc) return rc;
@@ -522,17 +504,16 @@ int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_co
 }
 // wire format: host buffers in, host buffers out
 static int wire_host(bn254_ctx *ctx, int g, int decode, const void *in, void *out, int32_t *status, size_t n) {
-    int rc = get_ctx(ctx); if (rc) return rc;
     if (n == 0) return BN254_OK;
     if (!in || !out || (decode && !status) || n > 0x7fffffffu / 129) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    BN_HOST_PROLOGUE();
     size_t ps = g == 0 ? sizeof(bn_fr) : g == 1 ? sizeof(bn_g1) : sizeof(bn_g2), rs = g == 0 ? BN254_FR_WIRE_BYTES : g == 1 ? BN254_G1_WIRE_BYTES : BN254_G2_WIRE_BYTES;
     size_t in_b = n * (decode ? rs : ps), out_b = n * (decode ? ps : rs);
-    DevBuf din(ctx, 0), dout(ctx, 1), dst(ctx, 2);
-    if ((rc = din.alloc(in_b)) || (rc = dout.alloc(out_b)) || (rc = dst.alloc(n * sizeof(int32_t)))) return rc;
+    BnBuf &din = ctx->stage[0], &dout = ctx->stage[1], &dst = ctx->stage[2];
+    if ((rc = din.reserve(in_b)) || (rc = dout.reserve(out_b)) || (rc = dst.reserve(n * sizeof(int32_t)))) return rc;
     HIP_TRY(hipMemcpyAsync(din.p, in, in_b, hipMemcpyHostToDevice, ctx->stream));
     {
-        Scope sc(ctx, ctx->stream, decode ? "wire_decode" : "wire_encode");
+        BnScope sc(ctx, ctx->stream, decode ? "wire_decode" : "wire_encode");
         dim3 grid(grid_for(n)), block(BLOCK);
         if (g == 0 && !decode) hipLaunchKernelGGL(bn254_fr_encode_k, grid, block, 0, ctx->stream, (const uint32_t *)din.p, (uint8_t *)dout.p, (uint32_t)n);
         if (g == 0 && decode) hipLaunchKernelGGL(bn254_fr_decode_k, grid, block, 0, ctx->stream, (const uint8_t *)din.p, (uint32_t *)dout.p, (int32_t *)dst.p, (uint32_t)n);
@@ -555,17 +536,16 @@ int bn254_g1_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g1 *out, int32_t
 int bn254_g2_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g2 *out, int32_t *status, size_t n) { return wire_host(ctx, 2, 1, in, out, status, n); }
 // G + G / G - G on host buffers
 static int add_host(bn254_ctx *ctx, int g, const void *a, const void *b, void *out, size_t n, int negate_b) {
-    int rc = get_ctx(ctx); if (rc) return rc;
     if (n == 0) return BN254_OK;
     size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
     if (!a || !b || !out || n > 0x7fffffffu / 48) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf da(ctx, 0), db(ctx, 1), dout(ctx, 2);
-    if ((rc = da.alloc(n * ps)) || (rc = db.alloc(n * ps)) || (rc = dout.alloc(n * ps))) return rc;
+    BN_HOST_PROLOGUE();
+    BnBuf &da = ctx->stage[0], &db = ctx->stage[1], &dout = ctx->stage[2];
+    if ((rc = da.reserve(n * ps)) || (rc = db.reserve(n * ps)) || (rc = dout.reserve(n * ps))) return rc;
     HIP_TRY(hipMemcpyAsync(da.p, a, n * ps, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(db.p, b, n * ps, hipMemcpyHostToDevice, ctx->stream));
     {
-        Scope sc(ctx, ctx->stream, g == 1 ? "g1_add" : "g2_add");
+        BnScope sc(ctx, ctx->stream, g == 1 ? "g1_add" : "g2_add");
         rc = g == 1 ? bn254_launch_g1_add_M(da.p, db.p, dout.p, n, negate_b, ctx->stream) : bn254_launch_g2_add_M(da.p, db.p, dout.p, n, negate_b, ctx->stream);
         if (rc) return rc;
     }
@@ -575,50 +555,49 @@ static int add_host(bn254_ctx *ctx, int g, const void *a, const void *b, void *o
 }
 int bn254_g1_add_batch(bn254_ctx *ctx, const bn_g1 *a, const bn_g1 *b, bn_g1 *out, size_t n, int negate_b) { return add_host(ctx, 1, a, b, out, n, negate_b); }
 int bn254_g2_add_batch(bn254_ctx *ctx, const bn_g2 *a, const bn_g2 *b, bn_g2 *out, size_t n, int negate_b) { return add_host(ctx, 2, a, b, out, n, negate_b); }
-static int gt_binop_host(bn254_ctx *ctx, int op, const bn_gt *a, const void *b, size_t bsize, bn_gt *out, size_t n) {
-    int rc = get_ctx(ctx); if (rc) return rc;
+// op 0: a * b, 1: a ^ k, 2: a^-1
+static int gt_op_host(bn254_ctx *ctx, int op, const bn_gt *a, const void *b, size_t bsize, bn_gt *out, size_t n) {
     if (n == 0) return BN254_OK;
-    if (!a || !b || !out) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf da(ctx, 0), db(ctx, 1), dout(ctx, 2);
-    if ((rc = da.alloc(n * sizeof(bn_gt))) || (rc = db.alloc(n * bsize)) || (rc = dout.alloc(n * sizeof(bn_gt)))) return rc;
+    if (!a || (op != 2 && !b) || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    BnBuf &da = ctx->stage[0], &db = ctx->stage[1], &dout = ctx->stage[2];
+    if ((rc = da.reserve(n * sizeof(bn_gt))) || (rc = db.reserve(n * bsize)) || (rc = dout.reserve(n * sizeof(bn_gt)))) return rc;
     HIP_TRY(hipMemcpyAsync(da.p, a, n * sizeof(bn_gt), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(db.p, b, n * bsize, hipMemcpyHostToDevice, ctx->stream));
-    rc = op == 0 ? bn254_gt_mul_batch_dev(ctx, da.p, db.p, dout.p, n, ctx->stream) : bn254_gt_pow_batch_dev(ctx, da.p, db.p, dout.p, n, ctx->stream);
+    if (op != 2) HIP_TRY(hipMemcpyAsync(db.p, b, n * bsize, hipMemcpyHostToDevice, ctx->stream));
+    rc = op == 0 ? bn254_gt_mul_batch_dev(ctx, da.p, db.p, dout.p, n, ctx->stream)
+       : op == 1 ? bn254_gt_pow_batch_dev(ctx, da.p, db.p, dout.p, n, ctx->stream)
+                 : bn254_gt_inverse_batch_dev(ctx, da.p, dout.p, n, ctx->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;
 }
-int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n) { return gt_binop_host(ctx, 0, a, b, sizeof(bn_gt), out, n); }
-int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n) { return gt_binop_host(ctx, 1, a, k, sizeof(bn_fr), out, n); }
-int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n) { return mul_host(ctx, 1, p, k, out, n); }
-int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n) { return mul_host(ctx, 2, p, k, out, n); }
+int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n) { return gt_op_host(ctx, 0, a, b, sizeof(bn_gt), out, n); }
+int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n) { return gt_op_host(ctx, 1, a, k, sizeof(bn_fr), out, n); }
+int bn254_gt_inverse_batch(bn254_ctx *ctx, const bn_gt *a, bn_gt *out, size_t n) { return gt_op_host(ctx, 2, a, nullptr, 0, out, n); }
 
 // ---------------------------------------------------------------------------------------------- measurement
 int bn254_profile_enable(bn254_ctx *ctx, int on) {
-    int rc = get_ctx(ctx); if (rc) return rc;
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
     ctx->profile = on != 0;
     return BN254_OK;
 }
 int bn254_profile_reset(bn254_ctx *ctx) {
-    int rc = get_ctx(ctx); if (rc) return rc;
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->prof_mu);
     for (auto &r : ctx->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     ctx->recs.clear();
+    ctx->folded.clear();
     return BN254_OK;
 }
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
-    int rc = get_ctx(ctx); if (rc) return rc;
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
     if (!kernel || !total_ms || !launches) return BN254_E_BAD_ARG;
-    double tot = 0; uint64_t cnt = 0;
-    for (auto &r : ctx->recs) {
-        if (r.name != kernel) continue;
-        HIP_TRY(hipEventSynchronize(r.b));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
-        tot += ms; ++cnt;
-    }
-    *total_ms = tot; *launches = cnt;
+    std::lock_guard<std::mutex> lk(ctx->prof_mu);
+    fold_records(ctx, 0);                       // consumes the records: their events are destroyed here
+    auto it = ctx->folded.find(kernel);
+    *total_ms = it == ctx->folded.end() ? 0.0 : it->second.first;
+    *launches = it == ctx->folded.end() ? 0 : it->second.second;
     return BN254_OK;
 }
 

@@ -27,7 +27,7 @@
 #ifdef BN_B_INLINE_REDUCTIONS
 #define BN_INLINE_REDUCTIONS 1
 #endif
-// Two waves share a SIMD and the hardware arbitrates OLDEST FIRST: measured with per-wave time stamps (tools/stamp_test.py),
+// Two waves share a SIMD and the hardware arbitrates OLDEST FIRST: measured with per-wave time stamps (tools/wave_stamps.py),
 // wave 0 of every SIMD ran at solo speed and finished the Miller kernel after 3.0 ms while wave 1 crawled (0.3 of the solo
 // rate) and needed 5.2 ms - the SIMD ran ONE wave for the last 40 % of the kernel.  A SIMD with a privileged and a gap-filling
 // wave delivers 1.3x the work of one wave, so keeping both alive to the end is worth 10 % (two concurrent processes, whose
@@ -348,8 +348,36 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     if (live) f12_store(r, out + 96u * pair);
 }
 // out[i] = a[i] ^ k[i]   (Gt::pow, lib.rs:171 -> fields/mod.rs:35-46: 256 x { res = res^2; if bit { res = a * res } } on the scalar
-// taken out of Montgomery form).  Exponent bits differ per element, so the conditional product is a per-pair select.
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n) {
+// taken out of Montgomery form).  The power is a unique field element, so any addition chain returns the reference's bytes:
+// fixed 4-bit windows, MSB first - 256 squarings + 64 table products + a 14-operation table instead of 256 x (square, multiply,
+// select).  General Fq12 squarings (not cyclotomic ones): correct for ANY non-zero Fq12, like the reference's generic pow.
+// The table a^0 .. a^15 lives in global memory, [lane][entry][54 dwords]: every lane reads the entry of ITS OWN digit as one
+// contiguous 216-byte run (the digits differ per lane, so a slot-major layout would scatter every dword load over 64 rows).
+struct PowTableMem {
+    uint32_t *base;          // this lane's 16 x 54 dwords
+    __device__ __forceinline__ void st6(int e, int half, const Fq6<F2> &v) const {
+        uint32_t *p = base + (e * 2 + half) * 27;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { p[i] = v.c0.v.l[i]; p[9 + i] = v.c1.v.l[i]; p[18 + i] = v.c2.v.l[i]; }
+    }
+    __device__ __forceinline__ Fq6<F2> ld6(int e, int half) const {
+        const uint32_t *p = base + (e * 2 + half) * 27;
+        Fq6<F2> v;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { v.c0.v.l[i] = p[i]; v.c1.v.l[i] = p[9 + i]; v.c2.v.l[i] = p[18 + i]; }
+        return v;
+    }
+    __device__ __forceinline__ void put(int e, const Fq12<F2> &v) const { st6(e, 0, v.c0); st6(e, 1, v.c1); }
+    __device__ __forceinline__ Fq12<F2> get(int e) const { return {ld6(e, 0), ld6(e, 1)}; }
+};
+struct PowSlot {             // Fq12 source of f12_mul_src: hands out the halves of table entry `e` on demand
+    const PowTableMem &t;
+    int e;
+    __device__ __forceinline__ Fq6<F2> c0() const { return t.ld6(e, 0); }
+    __device__ __forceinline__ Fq6<F2> c1() const { return t.ld6(e, 1); }
+};
+constexpr size_t POW_TABLE_DWORDS_PER_LANE = 16 * 54;
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table) {
     BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
@@ -359,18 +387,39 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 #pragma unroll
     for (int i = 0; i < 8; ++i) kw[i] = k[8u * pair + i];
     fr_from_mont(kw, raw);
-    Fq12<F2> base = f12_load<F2>(a + 96u * pair);
+    PowTableMem tbl = {table + (size_t)t * POW_TABLE_DWORDS_PER_LANE};
+    {
+        Fq12<F2> base = f12_load<F2>(a + 96u * pair);
+        tbl.put(0, f12_one<F2>());
+        tbl.put(1, base);
+    }
+#pragma unroll 1
+    for (int e = 2; e < 16; ++e) {                 // a^e = (a^(e/2))^2 for even e, a^(e-1) * a for odd e
+        Fq12<F2> v;
+        if ((e & 1) == 0) v = f12_sqr(tbl.get(e >> 1));
+        else v = f12_mul_src(tbl.get(e - 1), PowSlot{tbl, 1}, false);
+        tbl.put(e, v);
+    }
     Fq12<F2> res = f12_one<F2>();
 #pragma unroll 1
-    for (int i = 255; i >= 0; --i) {
-        BN_EXP_HOOK(255 - i, 256);
-        res = f12_sqr(res);
-        Fq12<F2> m = f12_mul(base, res);
-        bool bit = (raw[i >> 5] >> (i & 31)) & 1;
-        res.c0.c0 = f2_select(bit, res.c0.c0, m.c0.c0); res.c0.c1 = f2_select(bit, res.c0.c1, m.c0.c1); res.c0.c2 = f2_select(bit, res.c0.c2, m.c0.c2);
-        res.c1.c0 = f2_select(bit, res.c1.c0, m.c1.c0); res.c1.c1 = f2_select(bit, res.c1.c1, m.c1.c1); res.c1.c2 = f2_select(bit, res.c1.c2, m.c1.c2);
+    for (int w = 63; w >= 0; --w) {
+        BN_EXP_HOOK(63 - w, 64);
+#pragma unroll 1
+        for (int d = 0; d < 4; ++d) res = f12_sqr(res);
+        const int digit = (int)((raw[w >> 3] >> ((w & 7) * 4)) & 15u);          // per lane pair: both lanes hold the same scalar
+        res = f12_mul_src(res, PowSlot{tbl, digit}, false);
     }
     if (live) f12_store(res, out + 96u * pair);
+}
+// out[i] = a[i]^-1   (Gt::inverse, lib.rs:172 -> fq12.rs:284-292; one Fq inversion per element, constant-time divsteps)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_inverse_B(const uint32_t *a, uint32_t *out, uint32_t n) {
+    BN_KERNEL_PROLOGUE();
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;
+    Fq12<F2> r = f12_inverse(f12_load<F2>(a + 96u * pair));
+    if (live) f12_store(r, out + 96u * pair);
 }
 }  // namespace
 
@@ -397,9 +446,18 @@ int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hip
     hipLaunchKernelGGL(bn254_gt_mul_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
-int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, hipStream_t s) {
+size_t bn254_gt_pow_table_bytes_B(size_t n) {
+    size_t grid = (2 * n + BLOCK - 1) / BLOCK;
+    return grid * BLOCK * POW_TABLE_DWORDS_PER_LANE * sizeof(uint32_t);
+}
+int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
+    hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, (uint32_t *)table);
+    return (int)hipGetLastError();
+}
+int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_gt_inverse_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
 int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s) {

@@ -1,0 +1,430 @@
+// Host orchestration of the BN254 engine around the kernels (include/bn254_hip.h):
+//   * the pipelined host-buffer path: a batch handed over in pageable host memory is cut into chunks; every chunk in flight
+//     has its own stream, pinned staging, device staging and exponentiation table, and a host thread that copies into pinned
+//     memory, enqueues H2D -> Miller -> final exponentiation -> D2H on that stream and copies the result out.  Chunks overlap:
+//     while one is on the PCIe link the others occupy the CUs (a chunk alone would only fill a fraction of the 1024 SIMDs);
+//   * the multi-device fan-out of north_star: contiguous shards of independent pairings over the GPUs of one node (no
+//     exchange), and the multi-pairing product: one un-exponentiated Fq12 per GPU, ONE RCCL all-gather of 384 bytes per rank
+//     over xGMI (RCCL has no user-defined reduction), world-1 Fq12 products and a SINGLE final exponentiation - the fold of
+//     the reference's shootout/main.rs:11-16, bit for bit, because the final exponentiation is a homomorphism;
+//   * two small measurement/input kernels: the v_mad_u64_u32 issue-rate microbenchmark behind bench.py's same-run `peak`,
+//     and the on-device generator of the synthetic Fr scalars (SplitMix64 -> 512 bits -> mod r -> Montgomery form).
+// RCCL is resolved with dlopen at the first multi-device call, so the library itself has no link-time dependency on it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+
+#include "host_ctx.hpp"
+#include "bn254_constants.hpp"
+
+// ============================================================================================ pipelined host-buffer path
+namespace {
+
+struct MapJob {
+    bn254_ctx *ctx;
+    const char *in[2];
+    size_t in_stride[2];
+    char *out;
+    size_t out_stride;
+    size_t n, chunk;
+    int nslots;
+    std::function<int(BnSlot &, size_t)> launch;      // enqueue the kernels of one chunk on slot.stream (d_in -> d_out)
+};
+
+int run_slot(const MapJob &j, int w) {
+    bn254_ctx *c = j.ctx;
+    BnSlot &s = c->slot[w];
+    HIP_TRY(hipSetDevice(c->device));
+    if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    for (size_t ci = (size_t)w; ci * j.chunk < j.n; ci += (size_t)j.nslots) {
+        const size_t lo = ci * j.chunk, cnt = std::min(j.chunk, j.n - lo);
+        int rc;
+        for (int k = 0; k < 2; ++k) {
+            const size_t b = cnt * j.in_stride[k];
+            if ((rc = s.h_in[k].reserve(b)) || (rc = s.d_in[k].reserve(b))) return rc;
+            memcpy(s.h_in[k].p, j.in[k] + lo * j.in_stride[k], b);                 // pageable -> pinned (this thread)
+            HIP_TRY(hipMemcpyAsync(s.d_in[k].p, s.h_in[k].p, b, hipMemcpyHostToDevice, s.stream));
+        }
+        const size_t ob = cnt * j.out_stride;
+        if ((rc = s.h_out.reserve(ob)) || (rc = s.d_out.reserve(ob))) return rc;
+        if ((rc = j.launch(s, cnt))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_out.p, s.d_out.p, ob, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        memcpy(j.out + lo * j.out_stride, s.h_out.p, ob);                          // pinned -> the caller's buffer
+    }
+    return BN254_OK;
+}
+
+// chunk size: at least 2048 units (64 waves), at most 2^15, aiming at BN_MAX_SLOTS chunks; a multiple of 32 (one wave of
+// lane pairs) so that no chunk but the last carries a ragged wave
+void plan(size_t n, size_t &chunk, int &nslots) {
+    size_t c = (n + BN_MAX_SLOTS - 1) / BN_MAX_SLOTS;
+    c = std::max<size_t>(2048, std::min<size_t>(c, 32768));
+    c = (c + 31) / 32 * 32;
+    const char *e = getenv("BN254_PIPELINE_CHUNK");                                // experiments
+    if (e && atol(e) > 0) c = (size_t)atol(e);
+    chunk = c;
+    nslots = (int)std::min<size_t>(BN_MAX_SLOTS, (n + c - 1) / c);
+    const char *s = getenv("BN254_PIPELINE_SLOTS");
+    if (s && atoi(s) > 0) nslots = std::min(nslots, atoi(s));
+}
+
+int run_map(MapJob &j) {
+    plan(j.n, j.chunk, j.nslots);
+    if (j.nslots <= 1) return run_slot(j, 0);
+    std::vector<int> rcs(j.nslots, BN254_OK);
+    std::vector<std::thread> th;
+    for (int w = 1; w < j.nslots; ++w) th.emplace_back([&, w] { rcs[w] = run_slot(j, w); });
+    rcs[0] = run_slot(j, 0);
+    for (auto &t : th) t.join();
+    for (int rc : rcs) if (rc) return rc;
+    return BN254_OK;
+}
+
+}  // namespace
+
+// callers hold ctx->mu
+int bn_pairing_batch_pipelined(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
+    MapJob j;
+    j.ctx = ctx; j.n = n;
+    j.in[0] = (const char *)p; j.in_stride[0] = sizeof(bn_g1);
+    j.in[1] = (const char *)q; j.in_stride[1] = sizeof(bn_g2);
+    j.out = (char *)out; j.out_stride = sizeof(bn_gt);
+    j.launch = [ctx](BnSlot &s, size_t cnt) {
+        // Miller values land in the output slots and are exponentiated in place; the table is the slot's own
+        int rc = bn_launch_miller(ctx, s.d_in[0].p, s.d_in[1].p, s.d_out.p, cnt, s.stream, true);
+        if (rc) return rc;
+        return bn_launch_final_exp(ctx, s.d_out.p, s.d_out.p, cnt, s.stream, &s.tbl);
+    };
+    return run_map(j);
+}
+int bn_mul_batch_pipelined(bn254_ctx *ctx, int g, const void *p, const bn_fr *k, void *out, size_t n) {
+    const size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
+    MapJob j;
+    j.ctx = ctx; j.n = n;
+    j.in[0] = (const char *)p; j.in_stride[0] = ps;
+    j.in[1] = (const char *)k; j.in_stride[1] = sizeof(bn_fr);
+    j.out = (char *)out; j.out_stride = ps;
+    j.launch = [ctx, g](BnSlot &s, size_t cnt) { return bn_mul_dev(ctx, g, s.d_in[0].p, s.d_in[1].p, s.d_out.p, cnt, s.stream, 1); };
+    return run_map(j);
+}
+
+// ============================================================================================ multi-device
+namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+
+Rccl &rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.h || g_rccl.ok) return g_rccl;
+    // a process that already runs on PyTorch's bundled HIP runtime must use PyTorch's bundled RCCL (bn_amd/_native.py sets
+    // BN254_RCCL_PATH); a plain C/C++/Rust host gets /opt/rocm's
+    const char *cands[] = {getenv("BN254_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *c : cands) {
+        if (!c || !*c) continue;
+        g_rccl.h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) return g_rccl;
+    auto sym = [&](const char *n) { return dlsym(g_rccl.h, n); };
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl.ok = g_rccl.CommInitAll && g_rccl.CommDestroy && g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd;
+    return g_rccl;
+}
+
+}  // namespace
+
+struct bn254_multi {
+    std::vector<int> devices;
+    std::vector<bn254_ctx *> ctx;
+    std::vector<ncclComm_t> comms;          // one per rank when the exchange is RCCL
+    std::vector<BnBuf> d_partial, d_gather; // 384 B / world x 384 B per rank, on that rank's device
+    int exchange = BN254_EXCHANGE_PEER;
+    std::mutex mu;                          // one multi-device call at a time per handle
+};
+
+extern "C" {
+
+int bn254_multi_create(const int *devices, int ndev, bn254_multi **out) {
+    if (!out || ndev <= 0 || ndev > 64) return BN254_E_BAD_ARG;
+    const int have = bn254_device_count();
+    if (have <= 0) return BN254_E_NO_DEVICE;
+    bn254_multi *m = new bn254_multi();
+    for (int g = 0; g < ndev; ++g) {
+        int d = devices ? devices[g] : g;
+        if (d < 0 || d >= have) { bn254_multi_destroy(m); return BN254_E_NO_DEVICE; }
+        bn254_ctx *c = nullptr;
+        int rc = bn254_ctx_create(d, &c);
+        if (rc) { bn254_multi_destroy(m); return rc; }
+        m->devices.push_back(d);
+        m->ctx.push_back(c);
+    }
+    m->d_partial.resize(ndev); m->d_gather.resize(ndev);
+    for (int g = 0; g < ndev; ++g) {
+        if (hipSetDevice(m->devices[g]) != hipSuccess) { bn254_multi_destroy(m); return BN254_E_NO_DEVICE; }
+        int rc;
+        if ((rc = m->d_partial[g].reserve(sizeof(bn_gt))) || (rc = m->d_gather[g].reserve((size_t)ndev * sizeof(bn_gt)))) { bn254_multi_destroy(m); return rc; }
+    }
+    // RCCL needs one distinct GPU per rank; a device list with repeats (several contexts on one GPU: how the N > 1 control
+    // flow is exercised on a one-GPU box) exchanges the partials with peer copies instead
+    std::vector<int> sorted = m->devices;
+    std::sort(sorted.begin(), sorted.end());
+    const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+    const char *force = getenv("BN254_MULTI_EXCHANGE");
+    const bool want_rccl = distinct && !(force && !strcmp(force, "peer"));
+    if (want_rccl) {
+        Rccl &r = rccl();
+        if (r.ok) {
+            m->comms.resize(ndev);
+            if (r.CommInitAll(m->comms.data(), ndev, m->devices.data()) == ncclSuccess) m->exchange = BN254_EXCHANGE_RCCL;
+            else m->comms.clear();
+        }
+        if (m->exchange != BN254_EXCHANGE_RCCL && force && !strcmp(force, "rccl")) { bn254_multi_destroy(m); return BN254_E_COMM; }
+    }
+    *out = m;
+    return BN254_OK;
+}
+void bn254_multi_destroy(bn254_multi *m) {
+    if (!m) return;
+    if (!m->comms.empty()) for (auto c : m->comms) if (c) rccl().CommDestroy(c);
+    for (size_t g = 0; g < m->devices.size(); ++g) {
+        hipSetDevice(m->devices[g]);
+        if (g < m->d_partial.size()) m->d_partial[g].release();
+        if (g < m->d_gather.size()) m->d_gather[g].release();
+    }
+    for (auto c : m->ctx) bn254_ctx_destroy(c);
+    delete m;
+}
+int bn254_multi_device_count(const bn254_multi *m) { return m ? (int)m->devices.size() : 0; }
+int bn254_multi_exchange_kind(const bn254_multi *m) { return m ? m->exchange : BN254_E_BAD_ARG; }
+bn254_ctx *bn254_multi_ctx(bn254_multi *m, int rank) { return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[rank] : nullptr; }
+
+// contiguous shards lo = n*g/G .. n*(g+1)/G (the rule of bn_amd.distributed.shard_range); no exchange
+int bn254_pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
+    if (!m) return BN254_E_BAD_ARG;
+    if (n == 0) return BN254_OK;
+    if (!p || !q || !out) return BN254_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const size_t G = m->ctx.size();
+    std::vector<int> rcs(G, BN254_OK);
+    std::vector<std::thread> th;
+    auto shard = [&](size_t g) {
+        const size_t lo = n * g / G, hi = n * (g + 1) / G;
+        rcs[g] = bn254_pairing_batch(m->ctx[g], p + lo, q + lo, out + lo, hi - lo);
+    };
+    for (size_t g = 1; g < G; ++g) th.emplace_back(shard, g);
+    shard(0);
+    for (auto &t : th) t.join();
+    for (int rc : rcs) if (rc) return rc;
+    return BN254_OK;
+}
+
+int bn254_pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
+    if (!m || !out || (n && (!p || !q))) return BN254_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const size_t G = m->ctx.size();
+    std::vector<int> rcs(G, BN254_OK);
+    // 1. every rank: its shard's Miller loops and Fq12 product tree -> ONE un-exponentiated Fq12 in d_partial[g]
+    auto local = [&](size_t g) -> int {
+        bn254_ctx *c = m->ctx[g];
+        const size_t lo = n * g / G, cnt = n * (g + 1) / G - lo;
+        std::lock_guard<std::mutex> cl(c->mu);
+        HIP_TRY(hipSetDevice(c->device));
+        BnBuf &dp = c->stage[0], &dq = c->stage[1];
+        int rc;
+        if ((rc = dp.reserve(cnt * sizeof(bn_g1))) || (rc = dq.reserve(cnt * sizeof(bn_g2)))) return rc;
+        if (cnt) {
+            HIP_TRY(hipMemcpyAsync(dp.p, p + lo, cnt * sizeof(bn_g1), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(dq.p, q + lo, cnt * sizeof(bn_g2), hipMemcpyHostToDevice, c->stream));
+        }
+        if ((rc = bn254_miller_product_dev(c, dp.p, dq.p, cnt, m->d_partial[g].p, c->stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return BN254_OK;
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t g = 1; g < G; ++g) th.emplace_back([&, g] { rcs[g] = local(g); });
+        rcs[0] = local(0);
+        for (auto &t : th) t.join();
+        for (int rc : rcs) if (rc) return rc;
+    }
+    // 2. the ONE exchange step: 384 bytes per rank
+    if (m->exchange == BN254_EXCHANGE_RCCL) {
+        Rccl &r = rccl();
+        if (r.GroupStart() != ncclSuccess) return BN254_E_COMM;
+        for (size_t g = 0; g < G; ++g) {
+            hipSetDevice(m->devices[g]);
+            if (r.AllGather(m->d_partial[g].p, m->d_gather[g].p, 48, ncclUint64, m->comms[g], m->ctx[g]->stream) != ncclSuccess) { r.GroupEnd(); return BN254_E_COMM; }
+        }
+        if (r.GroupEnd() != ncclSuccess) return BN254_E_COMM;
+        for (size_t g = 1; g < G; ++g) { HIP_TRY(hipSetDevice(m->devices[g])); HIP_TRY(hipStreamSynchronize(m->ctx[g]->stream)); }
+    } else {
+        HIP_TRY(hipSetDevice(m->devices[0]));
+        for (size_t g = 0; g < G; ++g) {
+            char *dst = (char *)m->d_gather[0].p + g * sizeof(bn_gt);
+            if (m->devices[g] == m->devices[0]) HIP_TRY(hipMemcpyAsync(dst, m->d_partial[g].p, sizeof(bn_gt), hipMemcpyDeviceToDevice, m->ctx[0]->stream));
+            else HIP_TRY(hipMemcpyPeerAsync(dst, m->devices[0], m->d_partial[g].p, m->devices[g], sizeof(bn_gt), m->ctx[0]->stream));
+        }
+    }
+    // 3. rank 0: world-1 multiplications and the single final exponentiation
+    bn254_ctx *c0 = m->ctx[0];
+    std::lock_guard<std::mutex> cl(c0->mu);
+    HIP_TRY(hipSetDevice(c0->device));
+    int rc;
+    if ((rc = bn254_gt_product_dev(c0, m->d_gather[0].p, G, m->d_partial[0].p, c0->stream))) return rc;
+    if ((rc = bn254_final_exp_batch_dev(c0, m->d_partial[0].p, m->d_partial[0].p, 1, c0->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, m->d_partial[0].p, sizeof(bn_gt), hipMemcpyDeviceToHost, c0->stream));
+    HIP_TRY(hipStreamSynchronize(c0->stream));
+    return BN254_OK;
+}
+
+}  // extern "C"
+
+// ============================================================================================ measurement / input kernels
+namespace {
+
+// 16 independent-ish v_mad_u64_u32 per iteration on 8 accumulators: the issue-rate ceiling of the instruction every field
+// multiplication of the engine is built from (tools/ubench.hip is the long form of this experiment)
+__global__ void __launch_bounds__(256) bn254_ubench_mad_k(uint32_t *out, uint32_t seed, int iters) {
+    uint32_t a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
+    uint64_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = a + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[u & 7]) : "v"(a), "v"(b) : "vcc");
+    }
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    if (s == 0x1234567) out[threadIdx.x] = (uint32_t)s;
+}
+
+// ---- Fr (8 x u32, Montgomery radix 2^256) just for the scalar generator: CIOS product, result < r
+__device__ void fr_mont_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) {
+    using namespace bn254;
+    uint32_t t[10] = {};
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+        for (int j = 0; j < 8; ++j) { uint64_t x = (uint64_t)a[j] * b[i] + t[j] + c; t[j] = (uint32_t)x; c = x >> 32; }
+        uint64_t x = (uint64_t)t[8] + c; t[8] = (uint32_t)x; t[9] = (uint32_t)(x >> 32);
+        uint32_t mq = t[0] * k::FR_INV32;
+        c = ((uint64_t)mq * k::FR_MOD32[0] + t[0]) >> 32;
+        for (int j = 1; j < 8; ++j) { uint64_t y = (uint64_t)mq * k::FR_MOD32[j] + t[j] + c; t[j - 1] = (uint32_t)y; c = y >> 32; }
+        x = (uint64_t)t[8] + c; t[7] = (uint32_t)x;
+        t[8] = t[9] + (uint32_t)(x >> 32);
+        t[9] = 0;
+    }
+    // t < 2r: one conditional subtraction
+    uint32_t d[8];
+    int64_t br = 0;
+    for (int i = 0; i < 8; ++i) { int64_t s = (int64_t)t[i] - (int64_t)k::FR_MOD32[i] + br; d[i] = (uint32_t)s; br = s >> 32; }
+    const bool ge = (t[8] != 0) || (br == 0);
+    for (int i = 0; i < 8; ++i) out[i] = ge ? d[i] : t[i];
+}
+__device__ uint64_t splitmix64_next(uint64_t &state) {
+    state += 0x9E3779B97F4A7C15ull;
+    uint64_t z = state;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// out[j] = Montgomery image of (512-bit SplitMix64 draw of stream 2*(lo+j)+which) mod r   (bn_amd.distributed.synthetic_scalars)
+__global__ void __launch_bounds__(64) bn254_synthetic_scalars_k(uint64_t lo, uint32_t n, uint32_t which, uint64_t seed, uint32_t *out) {
+    using namespace bn254;
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n) return;
+    uint64_t state = seed + (((lo + j) * 2 + which) << 32);
+    uint32_t w[16];
+    for (int i = 0; i < 8; ++i) { uint64_t z = splitmix64_next(state); w[2 * i] = (uint32_t)z; w[2 * i + 1] = (uint32_t)(z >> 32); }
+    uint32_t r2[8], r3[8], a[8], b[8];
+    for (int i = 0; i < 8; ++i) r2[i] = k::FR_R2_32[i];
+    fr_mont_mul(r2, r2, r3);                    // R^3 mod r
+    fr_mont_mul(w, r2, a);                      // low half  * R     (operand < 2^256, result < r)
+    fr_mont_mul(w + 8, r3, b);                  // high half * R^2 = high * 2^256 * R
+    uint32_t s[9];
+    uint64_t c = 0;
+    for (int i = 0; i < 8; ++i) { uint64_t x = (uint64_t)a[i] + b[i] + c; s[i] = (uint32_t)x; c = x >> 32; }
+    s[8] = (uint32_t)c;
+    uint32_t d[8];
+    int64_t br = 0;
+    for (int i = 0; i < 8; ++i) { int64_t t = (int64_t)s[i] - (int64_t)k::FR_MOD32[i] + br; d[i] = (uint32_t)t; br = t >> 32; }
+    const bool ge = (s[8] != 0) || (br == 0);
+    for (int i = 0; i < 8; ++i) out[8u * j + i] = ge ? d[i] : s[i];
+}
+// out[i] = src[0]  (tiles one point/record of `words` u32 over n records: the generator bases of the synthetic inputs)
+__global__ void __launch_bounds__(256) bn254_tile_k(const uint32_t *src, uint32_t words, uint64_t total, uint32_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = src[i % words];
+}
+
+}  // namespace
+
+extern "C" {
+
+// G MAC32/s (lane multiply-accumulates per second) of a pure v_mad_u64_u32 stream at `waves_per_simd` resident waves
+int bn254_ubench_mac32(bn254_ctx *ctx, int waves_per_simd, int iters, double *gmac_per_s, double *ms_out) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !gmac_per_s) return BN254_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    const int blocks = prop.multiProcessorCount * waves_per_simd;          // 256 threads = one wave on each of a CU's 4 SIMDs
+    if ((rc = ctx->stage[0].reserve(4096))) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    hipLaunchKernelGGL(bn254_ubench_mad_k, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t *)ctx->stage[0].p, 1u, iters / 8 + 1);   // warm-up
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(bn254_ubench_mad_k, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t *)ctx->stage[0].p, 2u, iters);
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *gmac_per_s = (double)blocks * 256.0 * 16.0 * iters / (ms * 1e-3) / 1e9;
+    if (ms_out) *ms_out = ms;
+    return BN254_OK;
+}
+
+int bn254_synthetic_scalars_dev(bn254_ctx *ctx, uint64_t seed, uint64_t lo, size_t n, int which, void *d_out, void *stream) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_out || n > 0x7fffffffu / 8 || (which != 0 && which != 1)) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(bn254_synthetic_scalars_k, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, lo, (uint32_t)n, (uint32_t)which, seed, (uint32_t *)d_out);
+    return (int)hipGetLastError();
+}
+int bn254_tile_dev(bn254_ctx *ctx, const void *d_record, size_t record_bytes, size_t n, void *d_out, void *stream) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (n == 0) return BN254_OK;
+    if (!d_record || !d_out || record_bytes == 0 || record_bytes % 4) return BN254_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t total = (uint64_t)n * (record_bytes / 4);
+    hipLaunchKernelGGL(bn254_tile_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_record, (uint32_t)(record_bytes / 4), total, (uint32_t *)d_out);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Host-side internals shared by the translation units that implement include/bn254_hip.h (bn254_hip.hip: single-device
+// entry points; bn254_multi.hip: pipelined host-buffer path, multi-device fan-out, RCCL exchange).  Not part of the ABI.
+//
+// Concurrency contract (what the header promises and these structures implement):
+//   * every HOST-BUFFER entry point locks its context for the whole call, so any number of host threads may call into one
+//     context - including the process-wide default contexts behind ctx == NULL (one per HIP device) - and get the
+//     reference's re-entrant behaviour (`pairing` is a pure function, `Group: Send + Sync`, src/lib.rs:55-61);
+//   * the asynchronous *_dev entry points share context-owned scratch (final-exponentiation table, product workspace).
+//     Each use is bracketed by an event: a launch on another stream first waits for the previous user's event, so two
+//     streams on one context serialise on the scratch instead of racing on it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bn254_hip.h"
+
+#define HIP_TRY(expr)                             \
+    do {                                          \
+        hipError_t e__ = (expr);                  \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+constexpr int BN_MAX_SLOTS = 8;            // chunks in flight in the pipelined host-buffer path
+
+// grow-only buffer, device or pinned host
+struct BnBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool pinned = false;
+    int reserve(size_t need) {
+        if (need == 0) need = 1;
+        if (bytes >= need) return BN254_OK;
+        release();
+        hipError_t e = pinned ? hipHostMalloc(&p, need, hipHostMallocDefault) : hipMalloc(&p, need);
+        if (e != hipSuccess) { p = nullptr; return BN254_E_ALLOC; }
+        bytes = need;
+        return BN254_OK;
+    }
+    void release() {
+        if (p) { if (pinned) hipHostFree(p); else hipFree(p); }
+        p = nullptr; bytes = 0;
+    }
+};
+
+// one chunk in flight: its own stream, device staging, pinned host staging and final-exponentiation table
+struct BnSlot {
+    hipStream_t stream = nullptr;
+    BnBuf d_in[2], d_out, tbl;
+    BnBuf h_in[2], h_out;
+    BnSlot() { h_in[0].pinned = h_in[1].pinned = h_out.pinned = true; }
+};
+
+struct bn254_ctx {
+    int device = 0;
+    int mapping = 1;                    // 1: lane-pair mapping (default), 0: one lane per pairing
+    std::mutex mu;                      // host-buffer entry points hold it for the whole call
+    std::mutex scratch_mu;              // guards the scratch bookkeeping below (held only while enqueueing)
+    hipStream_t stream = nullptr;       // the context's own stream (host-buffer entry points)
+    BnBuf ws;                           // workspace (Miller values, product-tree levels)
+    BnBuf exp_tbl;                      // odd-power tables of the windowed exponentiation by u (final_exp_B)
+    BnBuf pow_tbl;                      // window tables of Gt::pow (gt_pow_B)
+    hipEvent_t scratch_ev = nullptr;    // completion of the last launch that used ws / exp_tbl ...
+    hipStream_t scratch_stream = nullptr;   // ... and the stream it ran on
+    bool scratch_used = false;
+    BnBuf stage[3];                     // device staging of the small host-buffer entry points
+    BnSlot slot[BN_MAX_SLOTS];          // pipelined path (bn254_multi.hip)
+    bool profile = false;
+    std::mutex prof_mu;                 // recs / folded (worker threads of the pipelined path launch concurrently)
+    struct Rec { std::string name; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::map<std::string, std::pair<double, uint64_t>> folded;     // totals of records already consumed (events recycled)
+};
+
+// brackets one kernel launch with events when profiling is on
+struct BnScope {
+    bn254_ctx *c; hipStream_t s; bool on; hipEvent_t a, b; const char *name;
+    BnScope(bn254_ctx *c_, hipStream_t s_, const char *n);
+    ~BnScope();
+};
+
+int bn_get_ctx(bn254_ctx *&ctx);                                   // NULL -> the default context of the current device
+// scratch guard: lives across the enqueueing of work that reads/writes ctx->ws / ctx->exp_tbl on stream `s`
+struct BnScratchGuard {
+    bn254_ctx *c; hipStream_t s; int rc;
+    BnScratchGuard(bn254_ctx *c_, hipStream_t s_);       // locks the bookkeeping, makes `s` wait for the previous user
+    ~BnScratchGuard();                                   // records the completion event on `s`, unlocks
+};
+
+// kernel launch helpers (bn254_hip.hip); `table` = caller-provided final-exponentiation table or NULL for the context's own
+int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf);
+int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table);
+int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s);
+size_t bn_product_tmp_bytes(size_t n);
+int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize);
+
+extern "C" {
+// bn254_kernels_b.hip
+int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s);
+int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hipStream_t s);
+size_t bn254_final_exp_table_bytes_B(size_t n);
+int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
+int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
+int bn254_launch_gt_product_B(const void *in, void *out, size_t n, unsigned chunk, hipStream_t s);
+int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
+size_t bn254_gt_pow_table_bytes_B(size_t n);
+int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, hipStream_t s);
+int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s);
+// bn254_kernels_mul.hip
+int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);
+int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);
+int bn254_launch_g1_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s);
+int bn254_launch_g2_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s);
+}

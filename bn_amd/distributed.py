@@ -68,6 +68,11 @@ class TorchEngine:
         self.e.g2_mul_dev(p.data_ptr(), k.data_ptr(), out.data_ptr(), p.shape[0], self._stream(), normalize)
         return out
 
+    def gt_pow(self, a, k):
+        out = self.torch.empty_like(a)
+        self.e.gt_pow_dev(a.data_ptr(), k.data_ptr(), out.data_ptr(), a.shape[0], self._stream())
+        return out
+
 
 def all_gather_partials(partial, group=None):
     """the ONE exchange step of the multi-pairing: (48,) int64 per rank -> (world, 48)"""
@@ -149,15 +154,26 @@ def generator_limbs():
     return np.array(g1, np.uint64), np.array(g2, np.uint64)
 
 
+def synthetic_scalars_device(eng, lo, hi, which):
+    """the same scalars as synthetic_scalars(lo, hi, which), generated in HBM by bn254_synthetic_scalars_dev ((n,4) int64 tensor);
+    word-for-word equality with the numpy version is a GPU test"""
+    out = eng.empty(hi - lo, 4)
+    eng.e.synthetic_scalars_dev(SEED, lo, hi - lo, which, out.data_ptr(), eng._stream())
+    return out
+
+
 def synthetic_points(eng, lo, hi):
-    """device tensors (P (n,12), Q (n,24)) for indices [lo,hi)"""
+    """device tensors (P (n,12), Q (n,24)) for indices [lo,hi): r_i * G1::one(), s_i * G2::one() by the reference's own
+    double-and-add chain (Jacobian, z != 1), scalars and generator tiles produced on the device"""
     torch = eng.torch
     n = hi - lo
     g1, g2 = generator_limbs()
-    k1 = torch.from_numpy(synthetic_scalars(lo, hi, 0).view(np.int64)).to(eng.device)
-    k2 = torch.from_numpy(synthetic_scalars(lo, hi, 1).view(np.int64)).to(eng.device)
-    b1 = torch.from_numpy(np.tile(g1, (n, 1)).view(np.int64)).to(eng.device)
-    b2 = torch.from_numpy(np.tile(g2, (n, 1)).view(np.int64)).to(eng.device)
+    k1 = synthetic_scalars_device(eng, lo, hi, 0)
+    k2 = synthetic_scalars_device(eng, lo, hi, 1)
+    t1 = torch.from_numpy(g1.view(np.int64)).to(eng.device); t2 = torch.from_numpy(g2.view(np.int64)).to(eng.device)
+    b1 = eng.empty(n, 12); b2 = eng.empty(n, 24)
+    eng.e.tile_dev(t1.data_ptr(), 96, n, b1.data_ptr(), eng._stream())
+    eng.e.tile_dev(t2.data_ptr(), 192, n, b2.data_ptr(), eng._stream())
     P = eng.g1_mul(b1, k1, normalize=False)
     Q = eng.g2_mul(b2, k2, normalize=False)
     torch.cuda.synchronize(eng.device)

@@ -22,6 +22,11 @@ def _p(a):
     return C.c_void_p(a.ctypes.data)
 
 
+def _same_len(a, b):
+    if a.shape[0] != b.shape[0]:
+        raise ValueError(f"operands differ in length: {a.shape[0]} vs {b.shape[0]}")
+
+
 class Engine:
     """one context = one GPU (include/bn254_hip.h: bn254_ctx)"""
 
@@ -31,15 +36,22 @@ class Engine:
             raise _native.Bn254Error("no HIP device: bn_amd has no CPU fallback")
         h = C.c_void_p()
         _native.check(self._lib.bn254_ctx_create(int(device), C.byref(h)))
-        self._h = h
+        self._ctx = h
         self.device = int(device)
         if mapping is not None:
             _native.check(self._lib.bn254_ctx_set_mapping(self._h, int(mapping)))
 
     def close(self):
-        if getattr(self, "_h", None):
-            self._lib.bn254_ctx_destroy(self._h)
-            self._h = None
+        if getattr(self, "_ctx", None):
+            self._lib.bn254_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    @property
+    def _h(self):
+        """the context handle; a closed engine raises instead of silently falling back to the C ABI's NULL = default context"""
+        if self._ctx is None:
+            raise _native.Bn254Error("this Engine is closed")
+        return self._ctx
 
     def __del__(self):
         try:
@@ -66,24 +78,24 @@ class Engine:
         return out
 
     def g1_mul_batch(self, p, k):
-        p = _arr(p, G1_WORDS); k = _arr(k, 4)
+        p = _arr(p, G1_WORDS); k = _arr(k, 4); _same_len(p, k)
         out = np.empty_like(p)
         _native.check(self._lib.bn254_g1_mul_batch(self._h, _p(p), _p(k), _p(out), p.shape[0]))
         return out
 
     def g2_mul_batch(self, p, k):
-        p = _arr(p, G2_WORDS); k = _arr(k, 4)
+        p = _arr(p, G2_WORDS); k = _arr(k, 4); _same_len(p, k)
         out = np.empty_like(p)
         _native.check(self._lib.bn254_g2_mul_batch(self._h, _p(p), _p(k), _p(out), p.shape[0]))
         return out
 
     def g1_add_batch(self, a, b, negate_b=False):
         """a + b (a - b): the reference's Jacobian limbs (groups/mod.rs:275-347)"""
-        a = _arr(a, G1_WORDS); b = _arr(b, G1_WORDS); out = np.empty_like(a)
+        a = _arr(a, G1_WORDS); b = _arr(b, G1_WORDS); _same_len(a, b); out = np.empty_like(a)
         _native.check(self._lib.bn254_g1_add_batch(self._h, _p(a), _p(b), _p(out), a.shape[0], 1 if negate_b else 0)); return out
 
     def g2_add_batch(self, a, b, negate_b=False):
-        a = _arr(a, G2_WORDS); b = _arr(b, G2_WORDS); out = np.empty_like(a)
+        a = _arr(a, G2_WORDS); b = _arr(b, G2_WORDS); _same_len(a, b); out = np.empty_like(a)
         _native.check(self._lib.bn254_g2_add_batch(self._h, _p(a), _p(b), _p(out), a.shape[0], 1 if negate_b else 0)); return out
 
     def g2_precompute(self, q):
@@ -133,15 +145,22 @@ class Engine:
         _native.check(self._lib.bn254_g2_decode_batch(self._h, _p(b), _p(out), _p(st), n)); return out, st
 
     def gt_mul_batch(self, a, b):
-        a = _arr(a, GT_WORDS); b = _arr(b, GT_WORDS)
+        a = _arr(a, GT_WORDS); b = _arr(b, GT_WORDS); _same_len(a, b)
         out = np.empty_like(a)
         _native.check(self._lib.bn254_gt_mul_batch(self._h, _p(a), _p(b), _p(out), a.shape[0]))
         return out
 
     def gt_pow_batch(self, a, k):
-        a = _arr(a, GT_WORDS); k = _arr(k, 4)
+        a = _arr(a, GT_WORDS); k = _arr(k, 4); _same_len(a, k)
         out = np.empty_like(a)
         _native.check(self._lib.bn254_gt_pow_batch(self._h, _p(a), _p(k), _p(out), a.shape[0]))
+        return out
+
+    def gt_inverse_batch(self, a):
+        """Gt::inverse (lib.rs:172)"""
+        a = _arr(a, GT_WORDS)
+        out = np.empty_like(a)
+        _native.check(self._lib.bn254_gt_inverse_batch(self._h, _p(a), _p(out), a.shape[0]))
         return out
 
     # ---- device-resident API: raw device pointers (ints) + hipStream_t (int or 0)
@@ -174,7 +193,25 @@ class Engine:
         f = self._lib.bn254_g2_mul_batch_dev if normalize else self._lib.bn254_g2_mul_jacobian_dev
         _native.check(f(self._h, d_p, d_k, d_out, n, stream))
 
+    def gt_mul_dev(self, d_a, d_b, d_out, n, stream=0):
+        _native.check(self._lib.bn254_gt_mul_batch_dev(self._h, d_a, d_b, d_out, n, stream))
+
+    def gt_pow_dev(self, d_a, d_k, d_out, n, stream=0):
+        _native.check(self._lib.bn254_gt_pow_batch_dev(self._h, d_a, d_k, d_out, n, stream))
+
+    def synthetic_scalars_dev(self, seed, lo, n, which, d_out, stream=0):
+        _native.check(self._lib.bn254_synthetic_scalars_dev(self._h, seed, lo, n, which, d_out, stream))
+
+    def tile_dev(self, d_record, record_bytes, n, d_out, stream=0):
+        _native.check(self._lib.bn254_tile_dev(self._h, d_record, record_bytes, n, d_out, stream))
+
     # ---- measurement
+    def ubench_mac32(self, waves_per_simd=8, iters=1 << 15):
+        """(G lane-MAC32 per second of a pure v_mad_u64_u32 stream, kernel ms) - the same-run `roofline.peak` of bench.py"""
+        g = C.c_double(); ms = C.c_double()
+        _native.check(self._lib.bn254_ubench_mac32(self._h, int(waves_per_simd), int(iters), C.byref(g), C.byref(ms)))
+        return g.value, ms.value
+
     def profile(self, on=True):
         _native.check(self._lib.bn254_profile_enable(self._h, 1 if on else 0))
 
@@ -185,3 +222,54 @@ class Engine:
         ms = C.c_double(); cnt = C.c_uint64()
         _native.check(self._lib.bn254_kernel_stats(self._h, kernel.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+
+class MultiEngine:
+    """several GPUs of one node behind ONE host process (include/bn254_hip.h: bn254_multi): contiguous shards of independent
+    pairings, and the multi-pairing product with its single 384-byte-per-rank exchange (RCCL all-gather when every rank has
+    its own GPU, peer copies when a device is listed twice)."""
+
+    def __init__(self, devices):
+        self._lib = _native.lib()
+        if self._lib.bn254_device_count() <= 0:
+            raise _native.Bn254Error("no HIP device: bn_amd has no CPU fallback")
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        _native.check(self._lib.bn254_multi_create(devs, len(devices), C.byref(h)))
+        self._m = h
+        self.devices = list(devices)
+
+    @property
+    def _h(self):
+        if self._m is None:
+            raise _native.Bn254Error("this MultiEngine is closed")
+        return self._m
+
+    @property
+    def exchange(self):
+        return {0: "peer", 1: "rccl"}[self._lib.bn254_multi_exchange_kind(self._h)]
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._lib.bn254_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def pairing_batch(self, p, q):
+        p = _arr(p, G1_WORDS); q = _arr(q, G2_WORDS); _same_len(p, q)
+        out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        _native.check(self._lib.bn254_pairing_batch_multi(self._h, _p(p), _p(q), _p(out), p.shape[0]))
+        return out
+
+    def pairing_product(self, p, q):
+        p = _arr(p, G1_WORDS) if len(p) else np.zeros((0, G1_WORDS), np.uint64)
+        q = _arr(q, G2_WORDS) if len(q) else np.zeros((0, G2_WORDS), np.uint64)
+        _same_len(p, q)
+        out = np.empty(GT_WORDS, np.uint64)
+        _native.check(self._lib.bn254_pairing_product_multi(self._h, _p(p), _p(q), p.shape[0], _p(out)))
+        return out

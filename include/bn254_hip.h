@@ -33,9 +33,16 @@
  * for G1/G2 values; behaviour on other limb patterns is unspecified (but memory safe).
  *
  * Ownership: the caller owns every buffer passed in; the library owns device memory and streams inside a context and keeps
- * no pointer after a call returns.  A context is bound to one GPU; calls on one context are serialised by the caller
- * (use one context per thread / per GPU).  There is NO CPU fallback: without a usable MI355X the calls fail with
- * BN254_E_NO_DEVICE.
+ * no pointer after a call returns.  A context is bound to one GPU.  There is NO CPU fallback: without a usable MI355X the
+ * calls fail with BN254_E_NO_DEVICE.
+ *
+ * Threading (the reference's `pairing` is a pure function and its types are Send + Sync, lib.rs:55-61):
+ *   - every HOST-BUFFER entry point is safe to call from any number of threads on the same context, including ctx == NULL
+ *     (a process-wide default context per HIP device): a context serialises its callers internally for the whole call;
+ *     use one context per calling thread (or bn254_multi_*) when the calls should overlap instead;
+ *   - the *_dev entry points are asynchronous on the caller's stream.  Context-owned scratch (the final-exponentiation table,
+ *     the product workspace) is ordered across streams with events, so calls on different streams of one context are safe
+ *     and serialise on that scratch; the caller still owns the ordering of its OWN buffers between streams.
  */
 #ifndef BN254_HIP_H
 #define BN254_HIP_H
@@ -63,7 +70,8 @@ enum {
     BN254_OK = 0,
     BN254_E_NO_DEVICE = -1,     /* no HIP device / device index out of range */
     BN254_E_BAD_ARG = -2,       /* null pointer with n > 0, n too large */
-    BN254_E_ALLOC = -3          /* device allocation failed */
+    BN254_E_ALLOC = -3,         /* device allocation failed */
+    BN254_E_COMM = -4           /* RCCL / peer exchange of the multi-device product failed */
     /* positive values are hipError_t codes */
 };
 
@@ -92,6 +100,27 @@ int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, s
 int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_coeffs *coeffs, int shared, bn_gt *out, size_t n);
 int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n);
 int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n);
+/* out[i] = a[i]^-1 in Fq12 (Gt::inverse, lib.rs:172 -> fields/fq12.rs:284-292); a[i] must be non-zero, as every Gt value is */
+int bn254_gt_inverse_batch(bn254_ctx *ctx, const bn_gt *a, bn_gt *out, size_t n);
+
+/* ---- one node, several GPUs (north_star: independent batches shard across the GPUs; ONE exchange for the multi-pairing) --- */
+/* `devices[0..ndev)`: HIP device index of every rank (NULL = 0..ndev-1).  One context and one host thread per rank.  A device may
+   be listed more than once (several ranks on one GPU - how the N > 1 path is exercised on a one-GPU box); the exchange of the
+   product is an RCCL all-gather when all devices are distinct and RCCL loads, peer copies otherwise (BN254_MULTI_EXCHANGE=
+   rccl|peer forces one). */
+typedef struct bn254_multi bn254_multi;
+enum { BN254_EXCHANGE_PEER = 0, BN254_EXCHANGE_RCCL = 1 };
+int bn254_multi_create(const int *devices, int ndev, bn254_multi **out);
+void bn254_multi_destroy(bn254_multi *m);
+int bn254_multi_device_count(const bn254_multi *m);
+int bn254_multi_exchange_kind(const bn254_multi *m);                 /* BN254_EXCHANGE_* */
+bn254_ctx *bn254_multi_ctx(bn254_multi *m, int rank);                /* rank's context (owned by m) */
+/* out[i] = pairing(p[i], q[i]); rank g owns the contiguous shard [n*g/G, n*(g+1)/G); no exchange (BASELINE configs[2]) */
+int bn254_pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n);
+/* fold(Gt::one(), acc * pairing(p, q)) over all n pairs (shootout/main.rs:11-16): every rank reduces its shard to one
+   un-exponentiated Fq12, ONE all-gather of 384 bytes per rank, world-1 products and a single final exponentiation on rank 0
+   (BASELINE configs[3]).  Bit-identical to the fold: the final exponentiation is a homomorphism and Gt values are canonical. */
+int bn254_pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out);
 
 /* wire format of the crate's Encodable/Decodable impls for G1/G2 (groups/mod.rs:143-205, fields/fp.rs:24-36, fields/fq2.rs:31-53,
    arith.rs:100-159), as fixed-size batch records: [tag][x][y] with tag 4 and big-endian canonical coordinates (Fq2 = the 512-bit
@@ -123,6 +152,7 @@ int bn254_g2_precompute_dev(bn254_ctx *ctx, const void *d_q, void *d_coeffs, siz
 int bn254_miller_prepared_dev(bn254_ctx *ctx, const void *d_p, const void *d_coeffs, int shared, void *d_f, size_t n, void *stream);
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
 int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream);
+int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, size_t n, void *stream);
 int bn254_g1_mul_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
 int bn254_g2_mul_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
 /* raw Jacobian result of the reference's MSB-first double-and-add (what G::random produces, groups/mod.rs:220-222):
@@ -130,13 +160,24 @@ int bn254_g2_mul_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, voi
 int bn254_g1_mul_jacobian_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
 int bn254_g2_mul_jacobian_dev(bn254_ctx *ctx, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream);
 
+/* synthetic benchmark inputs, generated in HBM (mirrors benches/api.rs: G::random = one * Fr::random):
+   d_out[j] = Montgomery image of (the 512-bit SplitMix64 draw of stream 2*(lo+j)+which, seeded `seed`) mod r - the distribution of
+   arith.rs:195-198; equal to bn_amd.distributed.synthetic_scalars word for word.  bn254_tile_dev repeats one record n times. */
+int bn254_synthetic_scalars_dev(bn254_ctx *ctx, uint64_t seed, uint64_t lo, size_t n, int which, void *d_out, void *stream);
+int bn254_tile_dev(bn254_ctx *ctx, const void *d_record, size_t record_bytes, size_t n, void *d_out, void *stream);
+
 /* ---- measurement ----------------------------------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by hipEvents on its own stream; bn254_kernel_stats then reports the
    accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
 int bn254_profile_enable(bn254_ctx *ctx, int on);
 int bn254_profile_reset(bn254_ctx *ctx);
-/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "wire_encode", "wire_decode".  Synchronises the recorded events. */
+/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
+   Synchronises and consumes the recorded events (totals accumulate until bn254_profile_reset). */
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
+/* issue-rate ceiling of v_mad_u64_u32 (the 32x32+64 multiply-accumulate every field product is built from) at
+   `waves_per_simd` resident waves: G lane-MACs per second over the whole chip and the kernel's duration.  bench.py prints it
+   as the same-run `roofline.peak`. */
+int bn254_ubench_mac32(bn254_ctx *ctx, int waves_per_simd, int iters, double *gmac_per_s, double *ms);
 
 #ifdef __cplusplus
 }

@@ -185,26 +185,32 @@ def test_full_size_batch_properties(oracle):
 
 
 def test_g1_mul_full_size_config5(oracle):
-    """BASELINE.json configs[4]: 2^20 G1 scalar multiplications by random Fr on one GPU (windowed kernel, normalized output):
-    a 16384-index sample against the oracle, and the two device algorithms (windowed vs the reference's own chain) agree on all
-    2^20 after normalization (compared on the GPU through a second normalization-by-one)"""
+    """BASELINE.json configs[4]: 2^20 G1 scalar multiplications of DISTINCT random points by DISTINCT random Fr on one GPU
+    (benches/api.rs:107-111; windowed kernel, normalized output): a 16384-index sample against the oracle, and the two device
+    algorithms (windowed vs the reference's own chain) agree on all 2^20 after normalization"""
     import torch
     import bn_amd
     from bn_amd import distributed as D
     dev = torch.device("cuda", 0)
     te = D.TorchEngine(bn_amd.Engine(0), dev)
     n = 1 << 20
-    base, _ = D.synthetic_points(te, 0, 1 << 14)                      # random base points, z != 1 (benches/api.rs:107-111)
-    P = base.repeat(n >> 14, 1).contiguous()
-    k = torch.from_numpy(D.synthetic_scalars(0, n >> 4, 1).view(np.int64)).to(dev).repeat(16, 1).contiguous()
+    g1, _ = D.generator_limbs()
+    kb = D.synthetic_scalars_device(te, 0, n, 0)
+    base = te.empty(n, 12)
+    te.e.tile_dev(torch.from_numpy(g1.view(np.int64)).to(dev).data_ptr(), 96, n, base.data_ptr(), te._stream())
+    P = te.g1_mul(base, kb, normalize=False)                          # 2^20 distinct random points, Jacobian z != 1
+    k = D.synthetic_scalars_device(te, 1 << 24, (1 << 24) + n, 1)     # 2^20 distinct scalars
     out = te.g1_mul(P, k, normalize=True)
     jac = te.g1_mul(P, k, normalize=False)                            # reference chain, raw Jacobian
-    one = torch.from_numpy(np.tile(oracle.fp_from_int(FR, 1), (n, 1)).view(np.int64)).to(dev)
+    one = te.empty(n, 4)
+    te.e.tile_dev(torch.from_numpy(oracle.fp_from_int(FR, 1).view(np.int64)).to(dev).data_ptr(), 32, n, one.data_ptr(), te._stream())
     out2 = te.g1_mul(jac, one, normalize=True)                        # normalize(chain result) via * 1
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+    kn_all = k.cpu().numpy().view(np.uint64)
+    assert np.unique(kn_all, axis=0).shape[0] == n                    # really 2^20 distinct scalars
     idx = np.random.default_rng(9).choice(n, 16384, replace=False)
-    Pn = P.cpu().numpy().view(np.uint64)[idx]; kn = k.cpu().numpy().view(np.uint64)[idx]
+    Pn = P.cpu().numpy().view(np.uint64)[idx]; kn = kn_all[idx]
     assert np.array_equal(out.cpu().numpy().view(np.uint64)[idx], canon_infinity(oracle.g1_mul_batch(Pn, kn)))
 
 
@@ -349,3 +355,270 @@ def test_group_addition_matches_reference_limbs(oracle, eng):
         assert np.array_equal(s2[i], oracle.g2_add(A2[i], B2[i])) and np.array_equal(d2[i], oracle.g2_add(A2[i], oracle.g2_neg(B2[i])))
     p = bn_amd.G1(A1[0]); q = bn_amd.G1(B1[0])
     assert np.array_equal((-q).limbs, oracle.g1_neg(B1[0])) and (p + q) - q == p and (p - p).is_zero()
+
+
+# ------------------------------------------------------------------------------------------------ round 2: sizes, threads, multi-device
+def test_synthetic_scalars_device_equals_numpy(oracle):
+    """bn254_synthetic_scalars_dev (inputs generated in HBM) == bn_amd.distributed.synthetic_scalars word for word"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    te = D.TorchEngine(bn_amd.Engine(0), dev)
+    for lo, hi, which in ((0, 300, 0), (12345, 12345 + 257, 1), ((1 << 24) + 7, (1 << 24) + 71, 1)):
+        got = D.synthetic_scalars_device(te, lo, hi, which)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), D.synthetic_scalars(lo, hi, which))
+
+
+def test_default_context_is_thread_safe(oracle):
+    """lib.rs:55-61: `pairing` is a pure function, the types are Send + Sync.  6 host threads call the C ABI with ctx == NULL (the
+    process-wide default context) at the same time, with different batch sizes, several times each"""
+    import ctypes as C
+    import threading
+    from bn_amd import _native
+    lib = _native.lib()
+    rng = np.random.default_rng(201)
+    sizes = [3, 70, 129, 33, 250, 64]
+    data = []
+    for n in sizes:
+        P, Q = _points(oracle, rng, n)
+        data.append((P, Q, oracle.pairing_batch(P, Q)))
+    errs = []
+    def work(i):
+        P, Q, want = data[i]
+        for _ in range(4):
+            out = np.zeros((P.shape[0], 48), np.uint64)
+            rc = lib.bn254_pairing_batch(None, C.c_void_p(P.ctypes.data), C.c_void_p(Q.ctypes.data), C.c_void_p(out.ctypes.data), P.shape[0])
+            if rc != 0 or not np.array_equal(out, want):
+                errs.append((i, rc))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(sizes))]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+
+
+def test_two_streams_on_one_context(oracle):
+    """the *_dev entry points share context-owned scratch (final-exponentiation table, product workspace): calls on two streams of
+    ONE context must serialise on it (event-ordered), not race"""
+    import torch
+    import bn_amd
+    dev = torch.device("cuda", 0)
+    e = bn_amd.Engine(0)
+    rng = np.random.default_rng(202)
+    n = 4096
+    P, Q = _points(oracle, rng, 64)
+    P = np.tile(P, (n // 64, 1)); Q = np.tile(Q, (n // 64, 1))
+    P2 = np.ascontiguousarray(P[::-1]); Q2 = np.ascontiguousarray(Q[::-1])
+    want = oracle.pairing_batch(P[:64], Q[:64])
+    tp, tq, tp2, tq2 = (torch.from_numpy(a.view(np.int64)).to(dev) for a in (P, Q, P2, Q2))
+    o1 = torch.empty(n, 48, dtype=torch.int64, device=dev); o2 = torch.empty_like(o1)
+    pr1 = torch.empty(48, dtype=torch.int64, device=dev); pr2 = torch.empty_like(pr1)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        e.pairing_batch_dev(tp.data_ptr(), tq.data_ptr(), o1.data_ptr(), n, s1.cuda_stream)
+        e.pairing_batch_dev(tp2.data_ptr(), tq2.data_ptr(), o2.data_ptr(), n, s2.cuda_stream)
+        e.miller_product_dev(tp.data_ptr(), tq.data_ptr(), n, pr1.data_ptr(), s1.cuda_stream)
+        e.miller_product_dev(tp2.data_ptr(), tq2.data_ptr(), n, pr2.data_ptr(), s2.cuda_stream)
+    torch.cuda.synchronize()
+    a = o1.cpu().numpy().view(np.uint64); b = o2.cpu().numpy().view(np.uint64)
+    assert np.array_equal(a[:64], want) and np.array_equal(a, np.tile(want, (n // 64, 1)))
+    assert np.array_equal(b, a[::-1])
+    assert torch.equal(pr1, pr2)                 # same multiset of pairs -> same product (Fq12 products commute, values canonical)
+
+
+def test_host_buffer_pipeline_matches_device_path(oracle):
+    """bn254_pairing_batch / g*_mul_batch on pageable host buffers run chunked over several streams with pinned staging: a ragged
+    multi-chunk batch equals the single-launch device path everywhere and the oracle on a sample"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    e = bn_amd.Engine(0)
+    te = D.TorchEngine(e, dev)
+    n = 20000 + 37
+    P, Q = D.synthetic_points(te, 5000, 5000 + n)
+    ref = te.pairing_batch(P, Q)
+    torch.cuda.synchronize()
+    Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
+    got = e.pairing_batch(Pn, Qn)
+    assert np.array_equal(got, ref.cpu().numpy().view(np.uint64))
+    idx = np.random.default_rng(7).choice(n, 256, replace=False)
+    assert np.array_equal(got[idx], oracle.pairing_batch(Pn[idx], Qn[idx]))
+    k = D.synthetic_scalars(100, 100 + n, 1)
+    m1 = e.g1_mul_batch(Pn, k)
+    assert np.array_equal(m1, te.g1_mul(P, torch.from_numpy(k.view(np.int64)).to(dev)).cpu().numpy().view(np.uint64))
+    assert np.array_equal(m1[idx], canon_infinity(oracle.g1_mul_batch(Pn[idx], k[idx])))
+
+
+def test_engine_argument_checks(oracle):
+    """binary batch methods must reject operands of different length instead of reading past the shorter buffer; a
+    closed Engine must raise instead of falling through to the C ABI's NULL = default context"""
+    import bn_amd
+    from bn_amd import _native
+    e = bn_amd.Engine(0)
+    rng = np.random.default_rng(203)
+    P, Q = _points(oracle, rng, 4)
+    k = _fr(oracle, _scalars(rng, 3))
+    g = e.pairing_batch(P, Q)
+    for fn, a, b in ((e.g1_mul_batch, P, k), (e.g2_mul_batch, Q, k), (e.g1_add_batch, P, P[:3]), (e.g2_add_batch, Q, Q[:2]),
+                     (e.gt_mul_batch, g, g[:1]), (e.gt_pow_batch, g, k), (e.pairing_batch, P, Q[:3])):
+        with pytest.raises(ValueError):
+            fn(a, b)
+    e.close()
+    with pytest.raises(_native.Bn254Error):
+        e.pairing_batch(P, Q)
+
+
+def test_gt_inverse_and_windowed_pow(oracle, eng):
+    """Gt::inverse (lib.rs:172) and the windowed Gt::pow on edge exponents (0, 1, 15, 16, r-1, 2^252..) vs the oracle's bit-serial pow"""
+    rng = np.random.default_rng(204)
+    n = 40
+    P, Q = _points(oracle, rng, n)
+    g = eng.pairing_batch(P, Q)
+    sv = _scalars(rng, n)
+    sv[:10] = [0, 1, 2, 15, 16, 17, M.R_ORD - 1, 1 << 252, (1 << 253) - 1, 0xf0f0f0f0f0f0f0f0f0f0]
+    s = _fr(oracle, sv)
+    pw = eng.gt_pow_batch(g, s)
+    inv = eng.gt_inverse_batch(g)
+    one = oracle.fq12_one()
+    for i in range(n):
+        assert np.array_equal(pw[i], oracle.gt_pow(g[i], s[i])), i
+        assert np.array_equal(inv[i], oracle.fq12_inverse(g[i]))
+    assert np.array_equal(eng.gt_mul_batch(g, inv), np.tile(one, (n, 1)))
+    # an element OUTSIDE the cyclotomic subgroup (a raw Miller value): the windowed chain uses general squarings, so still exact
+    raw = np.stack([oracle.miller_only(P[i], Q[i]) for i in range(4)])
+    assert np.array_equal(eng.gt_pow_batch(raw, s[10:14]), np.stack([oracle.gt_pow(raw[i], s[10 + i]) for i in range(4)]))
+    import bn_amd
+    a = bn_amd.Gt(g[0])
+    assert a.inverse() * a == bn_amd.Gt.one() and a.inverse() == a.pow(-bn_amd.Fr.one())
+
+
+def test_config3_shard_size_2_17(oracle):
+    """BASELINE.json configs[2]: 2^20 pairings over 8 GPUs = 2^17 per GPU.  The per-GPU shard on one GPU: a 4096-index sample
+    against the oracle, determinism, both lane mappings agree on all 2^17, and the shard equals the same indices of two 2^16 halves"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    n = 1 << 17
+    lo = 3 * n                                   # the shard GPU 3 of 8 would own
+    engB = D.TorchEngine(bn_amd.Engine(0, mapping=1), dev)
+    engA = D.TorchEngine(bn_amd.Engine(0, mapping=0), dev)
+    P, Q = D.synthetic_points(engB, lo, lo + n)
+    outB = engB.pairing_batch(P, Q); outB2 = engB.pairing_batch(P, Q); outA = engA.pairing_batch(P, Q)
+    h0 = engB.pairing_batch(P[:n // 2].contiguous(), Q[:n // 2].contiguous()); h1 = engB.pairing_batch(P[n // 2:].contiguous(), Q[n // 2:].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(outB, outB2) and torch.equal(outA, outB) and torch.equal(torch.cat([h0, h1]), outB)
+    idx = np.sort(np.random.default_rng(11).choice(n, 4096, replace=False))
+    Pn = P.cpu().numpy().view(np.uint64)[idx]; Qn = Q.cpu().numpy().view(np.uint64)[idx]
+    assert np.array_equal(outB.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn, Qn))
+
+
+def test_config4_product_sizes(oracle):
+    """BASELINE.json configs[3]: multi-pairing product of 2^18 pairs (2^15 per GPU on 8).  On one GPU: the 2^18-pair product (ONE
+    final exponentiation) equals the Fq12 product of the 2^18 reduced pairings; the 2^15 shard likewise, and the fold of a
+    512-pair sample equals the oracle's fold of shootout/main.rs:11-16; the 8-way sharded combination (8 partials -> gt_product
+    -> one final exponentiation, what the RCCL path computes after its all-gather) equals the single-GPU product"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    te = D.TorchEngine(bn_amd.Engine(0), dev)
+    n = 1 << 18
+    P, Q = D.synthetic_points(te, 0, n)
+    prod = D.pairing_product_sharded(te, P, Q)                       # world 1: miller_product -> final_exp
+    batch = te.pairing_batch(P, Q)
+    assert torch.equal(prod, te.gt_product(batch))
+    sh = n // 8
+    parts = torch.stack([te.miller_product(P[g * sh:(g + 1) * sh].contiguous(), Q[g * sh:(g + 1) * sh].contiguous()) for g in range(8)])
+    assert torch.equal(te.final_exp(te.gt_product(parts)), prod)
+    p15 = D.pairing_product_sharded(te, P[:sh].contiguous(), Q[:sh].contiguous())
+    assert torch.equal(p15, te.gt_product(batch[:sh].contiguous()))
+    torch.cuda.synchronize()
+    Pn = P[:512].cpu().numpy().view(np.uint64); Qn = Q[:512].cpu().numpy().view(np.uint64)
+    got = D.pairing_product_sharded(te, P[:512].contiguous(), Q[:512].contiguous())
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), oracle.pairing_product(Pn, Qn))
+
+
+def test_multi_device_c_abi(oracle):
+    """include/bn254_hip.h bn254_multi_*: the N > 1 split a Rust/C host gets without Python.  Two ranks on ONE GPU (device list
+    [0, 0]: contexts, host threads, shards, the gather and the single final exponentiation are all real; the exchange is peer
+    copies because RCCL needs one GPU per rank), and one rank through RCCL itself (ncclCommInitAll + ncclAllGather of 48 x u64)."""
+    import bn_amd
+    rng = np.random.default_rng(205)
+    n = 133
+    P, Q = _points(oracle, rng, n)
+    P[5] = oracle.g1_zero()
+    want_b = oracle.pairing_batch(P, Q); want_p = oracle.pairing_product(P, Q)
+    for devs, kind in (([0, 0], "peer"), ([0, 0, 0], "peer"), ([0], None)):
+        m = bn_amd.MultiEngine(devs)
+        if kind:
+            assert m.exchange == kind
+        assert np.array_equal(m.pairing_batch(P, Q), want_b), devs
+        assert np.array_equal(m.pairing_product(P, Q), want_p), devs
+        assert np.array_equal(m.pairing_product(P[:1], Q[:1]), oracle.pairing_product(P[:1], Q[:1]))     # fewer pairs than ranks
+        assert np.array_equal(m.pairing_product(P[:0], Q[:0]), oracle.fq12_one())
+        if devs == [0]:
+            print("exchange with one rank:", m.exchange)
+            assert m.exchange == "rccl", "RCCL did not load / ncclCommInitAll failed on one device"
+        m.close()
+
+
+GPU_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [%(root)r, %(root)r + "/oracle", %(root)r + "/tests"]
+import bn_amd
+from bn_amd import distributed as D
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+dev = torch.device("cuda", 0)
+eng = D.TorchEngine(bn_amd.Engine(0), dev)                       # the real HIP engine, both ranks on the one GPU
+n = %(n)d
+lo, hi = D.shard_range(n, rank, world)
+P, Q = D.synthetic_points(eng, lo, hi)
+gt = D.pairing_product_sharded(eng, P, Q)
+loc = D.pairing_batch_sharded(eng, P, Q)
+torch.cuda.synchronize()
+np.save(%(out)r + f".{rank}.npy", np.concatenate([gt.cpu().numpy().view(np.uint64).reshape(1, 48), loc.cpu().numpy().view(np.uint64).reshape(-1, 48)]))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sharded_world2_with_real_engine(oracle, tmp_path):
+    """the N > 1 host path (bn_amd.distributed: shards, the one all_gather, world-1 products, single final exponentiation) with the
+    HIP engine under it: two processes share the GPU and rendezvous over gloo (RCCL wants one GPU per rank)"""
+    import os, pathlib, subprocess, sys
+    from bn_amd import distributed as D
+    root = pathlib.Path(__file__).resolve().parents[1]
+    n = 300
+    script = tmp_path / "worker.py"
+    script.write_text(GPU_WORKER % {"root": str(root), "n": n, "out": str(tmp_path / "res")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    k1 = D.synthetic_scalars(0, n, 0); k2 = D.synthetic_scalars(0, n, 1)
+    P = oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (n, 1)), k1); Q = oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (n, 1)), k2)
+    got = [np.load(str(tmp_path / f"res.{r}.npy")) for r in range(2)]
+    want = oracle.pairing_product(P, Q)
+    assert np.array_equal(got[0][0], want) and np.array_equal(got[1][0], want)
+    assert np.array_equal(np.concatenate([got[0][1:], got[1][1:]]), oracle.pairing_batch(P, Q))
+
+
+def test_bench_multi_rank_control_flow(tmp_path):
+    """bench.py --gpus 2 started as a PLAIN python command (no torch.distributed.run around it): it re-launches itself, shards
+    BASELINE configs[2] (2^20 total -> 2^19 per rank; shrunk here with --batch) and rank 0 prints one JSON line"""
+    import json, os, pathlib, subprocess, sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = dict(os.environ, BN254_BENCH_SHARE_GPU="1", BN254_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["peak"] > 0 and "frac" in d["roofline"]

@@ -20,8 +20,8 @@ ROOT = pathlib.Path(__file__).resolve().parents[1]
 def test_c_abi_exports_every_declared_symbol():
     from bn_amd import _native
     hdr = (ROOT / "include" / "bn254_hip.h").read_text()
-    declared = set(re.findall(r"^(?:int|void|const char \*)\s*\*?(bn254_\w+)\s*\(", hdr, re.M))
-    assert len(declared) >= 20
+    declared = set(re.findall(r"^(?:int|void|const char \*|bn254_ctx \*)\s*\*?(bn254_\w+)\s*\(", hdr, re.M))
+    assert len(declared) >= 45
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
     _native.build()
     lib = _native.lib()                       # resolves every symbol, AttributeError otherwise
@@ -183,3 +183,26 @@ int main() { dump(bn::G1::one()); dump(bn::G1::zero()); dump(bn::G2::one()); dum
     want = [oracle.g1_one(), oracle.g1_zero(), oracle.g2_one(), oracle.g2_zero(), oracle.fq12_one(), oracle.fp_from_int(FR, 1)]
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+def test_fr_from_str_matches_reference_semantics():
+    """fields/fp.rs:39-59: ASCII decimal digits only (to_digit(10)); the empty string is zero; anything else is None"""
+    import bn_amd
+    assert bn_amd.Fr.from_str("") == bn_amd.Fr.zero()
+    assert bn_amd.Fr.from_str("0012") == bn_amd.Fr(12)
+    assert bn_amd.Fr.from_str(str(M.R_ORD + 5)) == bn_amd.Fr(5)            # reduced mod r like the reference's digit-by-digit Horner loop
+    for bad in ("-1", "1 ", "0x10", "\u00b2", "\u0661\u0662", "1e3", "+7"):
+        assert bn_amd.Fr.from_str(bad) is None, bad
+
+
+def test_bench_relaunches_itself_for_multi_gpu():
+    """`python bench.py --gpus 2` as a plain command (how the driver ran N = 1): with no rendezvous environment it must start 2
+    ranks itself.  Without a GPU each rank stops at the "needs an MI355X" check - which proves both ranks were started."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu-marked bench test")
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs an MI355X") >= 2, out.stderr[-1500:]

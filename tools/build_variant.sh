@@ -7,5 +7,5 @@ cd "$(dirname "$0")/.."
 mkdir -p build_variants
 name=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value "$@" \
-    bn_amd/csrc/bn254_hip.hip bn_amd/csrc/bn254_kernels_b.hip bn_amd/csrc/bn254_kernels_mul.hip -o build_variants/lib_$name.so
+    bn_amd/csrc/bn254_hip.hip bn_amd/csrc/bn254_kernels_b.hip bn_amd/csrc/bn254_kernels_mul.hip bn_amd/csrc/bn254_multi.hip -ldl -lpthread -o build_variants/lib_$name.so
 echo built build_variants/lib_$name.so

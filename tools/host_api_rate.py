@@ -7,7 +7,7 @@ sys.path.insert(0, str(ROOT))
 import numpy as np, torch
 import bn_amd
 from bn_amd import distributed as D
-n = 1 << 16
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16
 dev = torch.device("cuda", 0)
 te = D.TorchEngine(bn_amd.Engine(0), dev)
 P, Q = D.synthetic_points(te, 0, n)
@@ -19,4 +19,4 @@ for _ in range(reps):
     out = e.pairing_batch(Pn, Qn)
 dt = (time.perf_counter() - t0) / reps
 print(f"bn254_pairing_batch host buffers, n = {n}: {dt*1e3:.2f} ms per call = {n/dt/1e6:.3f} M pairings/s "
-      f"(H2D {n*288/1e6:.1f} MB + kernels + D2H {n*384/1e6:.1f} MB, pageable host memory, context-owned staging buffers)")
+      f"(H2D {n*288/1e6:.1f} MB + kernels + D2H {n*384/1e6:.1f} MB, pageable host memory, chunked over pinned staging)")

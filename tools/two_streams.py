@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment: aggregate pairing throughput of S independent streams (one context each) on ONE GPU, each running full batches or
-fractions of the batch; shows how much the kernel-boundary tails cost.  usage: two_stream_test.py [streams] [batch_per_stream]"""
+fractions of the batch; shows how much the kernel-boundary tails cost.  usage: two_streams.py [streams] [batch_per_stream]"""
 import pathlib, sys, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 import torch
