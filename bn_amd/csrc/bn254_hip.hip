@@ -318,8 +318,7 @@ void bn254_ctx_destroy(bn254_ctx *c) {
     for (auto &b : c->stage) b.release();
     for (auto &s : c->slot) {
         for (auto &b : s.d_in) b.release();
-        for (auto &b : s.h_in) b.release();
-        s.d_out.release(); s.h_out.release(); s.tbl.release();
+        s.d_out.release(); s.tbl.release();
         if (s.stream) hipStreamDestroy(s.stream);
     }
     if (c->scratch_ev) hipEventDestroy(c->scratch_ev);

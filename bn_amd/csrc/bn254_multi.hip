@@ -1,8 +1,7 @@
 // Host orchestration of the BN254 engine around the kernels (include/bn254_hip.h):
-//   * the pipelined host-buffer path: a batch handed over in pageable host memory is cut into chunks; every chunk in flight
-//     has its own stream, pinned staging, device staging and exponentiation table, and a host thread that copies into pinned
-//     memory, enqueues H2D -> Miller -> final exponentiation -> D2H on that stream and copies the result out.  Chunks overlap:
-//     while one is on the PCIe link the others occupy the CUs (a chunk alone would only fill a fraction of the 1024 SIMDs);
+//   * the pipelined host-buffer path: a batch handed over in pageable host memory is cut into chunks of 2^16; each of the two
+//     chunks in flight has its own stream, device staging and exponentiation table, and a host thread that enqueues
+//     H2D -> Miller -> final exponentiation -> D2H on that stream.  While one chunk is on the PCIe link the other owns the CUs;
 //   * the multi-device fan-out of north_star: contiguous shards of independent pairings over the GPUs of one node (no
 //     exchange), and the multi-pairing product: one un-exponentiated Fq12 per GPU, ONE RCCL all-gather of 384 bytes per rank
 //     over xGMI (RCCL has no user-defined reduction), world-1 Fq12 products and a SINGLE final exponentiation - the fold of
@@ -24,6 +23,12 @@
 #include "bn254_constants.hpp"
 
 // ============================================================================================ pipelined host-buffer path
+// Measured on the box (profiles/r02b_stream_concurrency.txt, r02b_copy_rates.txt): hipMemcpy from/to PAGEABLE memory already runs at
+// the link rate (51-53 GB/s; the runtime pins the pages on the fly), so no pinned staging copy is needed; and the GPU overlaps the
+// pairing kernels of TWO streams perfectly (2 x 2^15 = 8.29 ms vs 8.40 ms in one launch) but loses with more (4 streams 13.2 ms,
+// 8 streams 16.0 ms: the dispatcher stacks the small grids on the same SIMDs).  Hence: chunks of 2^16 (one full-machine launch),
+// two chunks in flight on two streams, each driven by its own host thread which copies in, launches and copies out; while one chunk
+// is on the PCIe link the other owns the CUs.
 namespace {
 
 struct MapJob {
@@ -47,32 +52,27 @@ int run_slot(const MapJob &j, int w) {
         int rc;
         for (int k = 0; k < 2; ++k) {
             const size_t b = cnt * j.in_stride[k];
-            if ((rc = s.h_in[k].reserve(b)) || (rc = s.d_in[k].reserve(b))) return rc;
-            memcpy(s.h_in[k].p, j.in[k] + lo * j.in_stride[k], b);                 // pageable -> pinned (this thread)
-            HIP_TRY(hipMemcpyAsync(s.d_in[k].p, s.h_in[k].p, b, hipMemcpyHostToDevice, s.stream));
+            if ((rc = s.d_in[k].reserve(b))) return rc;
+            HIP_TRY(hipMemcpyAsync(s.d_in[k].p, j.in[k] + lo * j.in_stride[k], b, hipMemcpyHostToDevice, s.stream));
         }
         const size_t ob = cnt * j.out_stride;
-        if ((rc = s.h_out.reserve(ob)) || (rc = s.d_out.reserve(ob))) return rc;
+        if ((rc = s.d_out.reserve(ob))) return rc;
         if ((rc = j.launch(s, cnt))) return rc;
-        HIP_TRY(hipMemcpyAsync(s.h_out.p, s.d_out.p, ob, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipMemcpyAsync(j.out + lo * j.out_stride, s.d_out.p, ob, hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));
-        memcpy(j.out + lo * j.out_stride, s.h_out.p, ob);                          // pinned -> the caller's buffer
     }
     return BN254_OK;
 }
 
-// chunk size: at least 2048 units (64 waves), at most 2^15, aiming at BN_MAX_SLOTS chunks; a multiple of 32 (one wave of
-// lane pairs) so that no chunk but the last carries a ragged wave
 void plan(size_t n, size_t &chunk, int &nslots) {
-    size_t c = (n + BN_MAX_SLOTS - 1) / BN_MAX_SLOTS;
-    c = std::max<size_t>(2048, std::min<size_t>(c, 32768));
-    c = (c + 31) / 32 * 32;
+    size_t c = 65536;
     const char *e = getenv("BN254_PIPELINE_CHUNK");                                // experiments
     if (e && atol(e) > 0) c = (size_t)atol(e);
     chunk = c;
-    nslots = (int)std::min<size_t>(BN_MAX_SLOTS, (n + c - 1) / c);
+    int want = 2;
     const char *s = getenv("BN254_PIPELINE_SLOTS");
-    if (s && atoi(s) > 0) nslots = std::min(nslots, atoi(s));
+    if (s && atoi(s) > 0) want = std::min(BN_MAX_SLOTS, atoi(s));
+    nslots = (int)std::min<size_t>((size_t)want, (n + c - 1) / c);
 }
 
 int run_map(MapJob &j) {

@@ -24,7 +24,7 @@
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
-constexpr int BN_MAX_SLOTS = 8;            // chunks in flight in the pipelined host-buffer path
+constexpr int BN_MAX_SLOTS = 4;            // chunks in flight in the pipelined host-buffer path (2 used; the rest for experiments)
 
 // grow-only buffer, device or pinned host
 struct BnBuf {
@@ -46,12 +46,10 @@ struct BnBuf {
     }
 };
 
-// one chunk in flight: its own stream, device staging, pinned host staging and final-exponentiation table
+// one chunk in flight: its own stream, device staging and final-exponentiation table
 struct BnSlot {
     hipStream_t stream = nullptr;
     BnBuf d_in[2], d_out, tbl;
-    BnBuf h_in[2], h_out;
-    BnSlot() { h_in[0].pinned = h_in[1].pinned = h_out.pinned = true; }
 };
 
 struct bn254_ctx {

@@ -60,11 +60,16 @@ class Engine:
             pass
 
     # ---- host-buffer API
-    def pairing_batch(self, p, q):
+    def pairing_batch(self, p, q, out=None):
+        """out: optional preallocated (n,48) uint64 array (a long-running caller reuses it; a fresh np.empty pays one page fault
+        per 4 KB inside the D2H copy)"""
         p = _arr(p, G1_WORDS); q = _arr(q, G2_WORDS)
         if p.shape[0] != q.shape[0]:
             raise ValueError("p and q differ in length")
-        out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        if out is None:
+            out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        elif out.shape != (p.shape[0], GT_WORDS) or out.dtype != np.uint64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (n,48) uint64 array")
         _native.check(self._lib.bn254_pairing_batch(self._h, _p(p), _p(q), _p(out), p.shape[0]))
         return out
 
