@@ -66,6 +66,10 @@ BN_FN Fq2A f2_sqr(const Fq2A &a) {
 }
 // a may be lazy (lb <= 6, vb <= 56)
 BN_FN Fq2A f2_scale(const Fq2A &a, const Fe &s) { return {fe_mul(a.c0, s), fe_mul(a.c1, s)}; }
+// a / 2: lazy result for the first operand of a product; and in the form f2_sqr accepts (this mapping's squaring wants vb <= 3,
+// so it keeps the product by 2^-1)
+BN_FN Fq2A f2_half(const Fq2A &a) { return {fe_half(a.c0), fe_half(a.c1)}; }
+BN_FN Fq2A f2_half_for_sqr(const Fq2A &a) { return f2_scale(a, fe_const(k::TWO_INV)); }
 // reduce(CX * xi * x + CY * y), xi = 9 + i:  xi*x = (9 x0 - x1) + (9 x1 + x0) i.   x, y may be lazy.
 template <int CX, int CY>
 BN_FN Fq2A f2_lc_xi(const Fq2A &x, const Fq2A &y) {
@@ -192,6 +196,8 @@ template <class T> BN_FN Fq2B<T> f2_select(bool take_b, const Fq2B<T> &a, const 
 template <class T> BN_FN Fq2B<T> f2_mul(const Fq2B<T> &a, const Fq2B<T> &b) { return {f2b_mul(a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_sqr(const Fq2B<T> &a) { return {f2b_sqr(a.v)}; }
 template <class T> BN_FN Fq2B<T> f2_scale(const Fq2B<T> &a, const T &s) { return {fe_mul(a.v, s)}; }
+template <class T> BN_FN Fq2B<T> f2_half(const Fq2B<T> &a) { return {fe_half(a.v)}; }
+template <class T> BN_FN Fq2B<T> f2_half_for_sqr(const Fq2B<T> &a) { return {fe_norm(fe_half(a.v))}; }      // normalized limbs, vb <= 6
 // reduce(CX*xi*x + CY*y): even lane 9CX*x0 - CX*x1 + CY*y0, odd lane 9CX*x1 + CX*x0 + CY*y1
 template <int CX, int CY, class T>
 BN_FN Fq2B<T> f2_lc_xi(const Fq2B<T> &x, const Fq2B<T> &y) { return {fe_lc3_par<9 * CX, CX, CY>(x.v, lane_partner(x.v), y.v)}; }

@@ -20,11 +20,19 @@ template <class F2> struct Line { F2 ell_0, ell_vw, ell_vv; };  // ell_vw / ell_
 // groups/mod.rs:612-634.   e = 3b' * z^2 folds the reference's d = 3c, e = b'*d into one constant product.
 template <class F2>
 BN_COARSE Line<F2> doubling_step(G2Proj<F2> &r) {
+#ifdef BN_NO_HALF      // experiment switch: the reference's products by 2^-1
     F2 a = f2_scale(f2_mul(r.x, r.y), f2_scalar_const(F2P, k::TWO_INV));
+#else
+    F2 a = f2_half(f2_mul(r.x, r.y));                                    // x y / 2 by a shift, not a product (fe_half)
+#endif
     F2 b = f2_sqr(r.y), c = f2_sqr(r.z);
     F2 e = f2_mul_const(c, k::G2_3B);
     F2 f3 = f2_add(f2_add(e, e), e);                                     // f = 3e, lazy
-    F2 g = f2_scale(f2_add(b, f3), f2_scalar_const(F2P, k::TWO_INV));                // (b + f)/2
+#ifdef BN_NO_HALF
+    F2 g = f2_scale(f2_add(b, f3), f2_scalar_const(F2P, k::TWO_INV));
+#else
+    F2 g = f2_half_for_sqr(f2_add(b, f3));                               // (b + f)/2
+#endif
     F2 h = f2_lc3<1, -1, -1>(f2_sqr(f2_sum_for_mul(r.y, r.z)), b, c);
     F2 j = f2_sqr(r.x), e_sq = f2_sqr(e);
     Line<F2> l;

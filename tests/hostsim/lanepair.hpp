@@ -18,6 +18,7 @@ BN_FN FeP fe_ssub(const FeP &a, const FeP &b) { return {{fe_ssub(a.v[0], b.v[0])
 template <int C1, int C2, int C3>
 BN_FN FeP fe_lc3w(const FeP &x, const FeP &y, const FeP &z) { return {{fe_lc3w<C1, C2, C3>(x.v[0], y.v[0], z.v[0]), fe_lc3w<C1, C2, C3>(x.v[1], y.v[1], z.v[1])}}; }
 BN_FN FeP fe_norm(const FeP &a) { return {{fe_norm(a.v[0]), fe_norm(a.v[1])}}; }
+BN_FN FeP fe_half(const FeP &a) { return {{fe_half(a.v[0]), fe_half(a.v[1])}}; }
 BN_FN FeP fe_std(const FeP &a) { return {{fe_std(a.v[0]), fe_std(a.v[1])}}; }
 template <int C1, int C2, int C3>
 BN_FN FeP fe_lc3(const FeP &x, const FeP &y, const FeP &z) { return {{fe_lc3<C1, C2, C3>(x.v[0], y.v[0], z.v[0]), fe_lc3<C1, C2, C3>(x.v[1], y.v[1], z.v[1])}}; }
