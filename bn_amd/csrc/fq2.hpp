@@ -81,6 +81,8 @@ BN_FN Fq2A f2_lc_xi2(const Fq2A &x, const Fq2A &y, const Fq2A &z) {
     return {fe_lc4_core<9 * CX, -CX, CY, CZ>(x.c0, x.c1, y.c0, z.c0, false), fe_lc4_core<9 * CX, CX, CY, CZ>(x.c1, x.c0, y.c1, z.c1, false)};
 }
 BN_FN Fq2A f2_mul_xi(const Fq2A &x) { return f2_lc_xi<1, 0>(x, x); }
+// (27 - 3i) * x = (27 x0 + 3 x1) + (27 x1 - 3 x0) i: the curve constant 3 b' t^6 of the isomorphic curve (pairing.hpp)
+BN_FN Fq2A f2_mul_iso3b(const Fq2A &x) { return {fe_lc3<27, 3, 0>(x.c0, x.c1, x.c1), fe_lc3<27, -3, 0>(x.c1, x.c0, x.c0)}; }
 // lazy variants for values that go straight into a multiplication as the FIRST operand (lb <= 2 there)
 BN_FN Fq2A f2_neg_lazy(const Fq2A &a) { return {fe_neg<1, 4>(a.c0), fe_neg<1, 4>(a.c1)}; }
 BN_FN Fq2A f2_conj_lazy(const Fq2A &a) { return {a.c0, fe_neg<1, 4>(a.c1)}; }
@@ -204,6 +206,8 @@ BN_FN Fq2B<T> f2_lc_xi(const Fq2B<T> &x, const Fq2B<T> &y) { return {fe_lc3_par<
 template <int CX, int CY, int CZ, class T>
 BN_FN Fq2B<T> f2_lc_xi2(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc4_par<9 * CX, CX, CY, CZ>(x.v, lane_partner(x.v), y.v, z.v)}; }
 template <class T> BN_FN Fq2B<T> f2_mul_xi(const Fq2B<T> &x) { return f2_lc_xi<1, 0>(x, x); }
+// (27 - 3i) * x: even lane 27 x0 + 3 x1, odd lane 27 x1 - 3 x0  (fe_lc3_par negates its middle term on the even lane)
+template <class T> BN_FN Fq2B<T> f2_mul_iso3b(const Fq2B<T> &x) { return {fe_lc3_par<27, -3, 0>(x.v, lane_partner(x.v), x.v)}; }
 template <class T, class TAB>
 BN_FN Fq2B<T> f2_mul_const(const Fq2B<T> &a, const TAB &tab) { return f2_mul(a, f2_const((const Fq2B<T> *)nullptr, tab)); }
 // fq2.rs:125-136: norm = a0^2 + a1^2 (one square per lane, exchanged), ONE Fermat chain for the pair

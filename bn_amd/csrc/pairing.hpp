@@ -18,7 +18,10 @@ template <class F2> struct Line { F2 ell_0, ell_vw, ell_vv; };  // ell_vw / ell_
 #define F2P ((const F2 *)nullptr)
 
 // groups/mod.rs:612-634.   e = 3b' * z^2 folds the reference's d = 3c, e = b'*d into one constant product.
-template <class F2>
+// ISO = true: the step on the isomorphic curve y^2 = x^3 + b' t^6 (t^6 = 82/3, bn254_constants.hpp ISO_T2/ISO_T3), whose constant
+// 3 b' t^6 = 27 - 3i costs a two-term linear combination instead of a product.  Only the pairing kernels use it (with P and Q
+// mapped by (x, y) -> (t^2 x, t^3 y) first): the reduced pairing is invariant under the isomorphism, the Miller value is not.
+template <bool ISO = false, class F2>
 BN_COARSE Line<F2> doubling_step(G2Proj<F2> &r) {
 #ifdef BN_NO_HALF      // experiment switch: the reference's products by 2^-1
     F2 a = f2_scale(f2_mul(r.x, r.y), f2_scalar_const(F2P, k::TWO_INV));
@@ -26,7 +29,9 @@ BN_COARSE Line<F2> doubling_step(G2Proj<F2> &r) {
     F2 a = f2_half(f2_mul(r.x, r.y));                                    // x y / 2 by a shift, not a product (fe_half)
 #endif
     F2 b = f2_sqr(r.y), c = f2_sqr(r.z);
-    F2 e = f2_mul_const(c, k::G2_3B);
+    F2 e;
+    if constexpr (ISO) e = f2_mul_iso3b(c);
+    else e = f2_mul_const(c, k::G2_3B);
     F2 f3 = f2_add(f2_add(e, e), e);                                     // f = 3e, lazy
 #ifdef BN_NO_HALF
     F2 g = f2_scale(f2_add(b, f3), f2_scalar_const(F2P, k::TWO_INV));
@@ -98,8 +103,17 @@ struct MillerStateVars {
 //                from the reference's by a factor that the final exponentiation kills (different line scalings / omitted
 //                verticals, all in proper subfields), so pairing() - the only observable of this path - is bit-identical.
 template <bool NAF, class F2, class S, class Store>
-BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p, const G2Aff<F2> &q, Store &st) {
+BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, Store &st) {
     {
+        G1Aff<S> p = p_in;
+        G2Aff<F2> q = q_in;
+#ifndef BN_NO_ISO
+        if constexpr (NAF) {             // onto the isomorphic curve: (x, y) -> (t^2 x, t^3 y) for both points
+            const S t2 = f2_scalar_const(F2P, k::ISO_T2), t3 = f2_scalar_const(F2P, k::ISO_T3);
+            p = {fe_mul(p.x, t2), fe_mul(p.y, t3)};
+            q = {f2_scale(q.x, t2), f2_scale(q.y, t3)};
+        }
+#endif
         G2Proj<F2> r0 = {q.x, q.y, f2_one(F2P)};
         st.put_r(r0);
         st.put_base(q);
@@ -125,7 +139,11 @@ BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p, const G2Aff<F2> &q, Store &s
                 if (j != 0) f = f12_sqr(f);                                         // f == 1 in the first step
                 BN_COMPILER_FENCE();                                                // R is fetched AFTER the squaring
                 G2Proj<F2> r = st.get_r();
-                l = doubling_step(r);
+#ifndef BN_NO_ISO
+                l = doubling_step<NAF>(r);
+#else
+                l = doubling_step<false>(r);
+#endif
                 st.put_r(r);
             } else {
                 G2Proj<F2> r = st.get_r();
@@ -163,7 +181,7 @@ BN_FN void precompute_lines(const G2Aff<F2> &q, Sink &sink) {
 #pragma unroll 1
         for (int pass = tail ? 1 : 0; pass < (bit ? 2 : 1); ++pass) {
             BN_MILLER_HOOK(2 * j + pass, 2 * 66);
-            Line<F2> l = pass == 0 ? doubling_step(r) : addition_step(r, base);
+            Line<F2> l = pass == 0 ? doubling_step<false>(r) : addition_step(r, base);
             sink(idx++, l);
         }
     }
