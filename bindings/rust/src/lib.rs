@@ -20,7 +20,17 @@ extern "C" {
     fn bn254_g2_add_batch(ctx: *mut c_void, a: *const G2, b: *const G2, out: *mut G2, n: usize, negate_b: c_int) -> c_int;
     fn bn254_g1_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut G1, status: *mut i32, n: usize) -> c_int;
     fn bn254_g2_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut G2, status: *mut i32, n: usize) -> c_int;
+    fn bn254_gt_inverse_batch(ctx: *mut c_void, a: *const Gt, out: *mut Gt, n: usize) -> c_int;
+    // one node, several GPUs (include/bn254_hip.h "bn254_multi"): one context + host thread per device inside the library
+    fn bn254_multi_create(devices: *const c_int, ndev: c_int, out: *mut *mut c_void) -> c_int;
+    fn bn254_multi_destroy(m: *mut c_void);
+    fn bn254_pairing_batch_multi(m: *mut c_void, p: *const G1, q: *const G2, out: *mut Gt, n: usize) -> c_int;
+    fn bn254_pairing_product_multi(m: *mut c_void, p: *const G1, q: *const G2, n: usize, out: *mut Gt) -> c_int;
 }
+
+// Thread safety: every host-buffer entry point of the C ABI serialises the callers of one context internally (including the
+// process-wide default context behind a NULL ctx), so these safe `pub fn`s may be called from any number of threads, like the
+// crate's own `pairing` (its types are `Send + Sync`, src/lib.rs:55-61).
 
 /// Error code of the HIP engine: negative `BN254_E_*`, positive `hipError_t`.  There is no CPU fallback.
 #[derive(Debug, Clone, Copy, PartialEq, Eq)]
@@ -127,4 +137,44 @@ mod tests {
         assert!(pairing_product(&ps, &qs).unwrap() == acc);
         assert!(pairing_batch(&ps, &qs).unwrap().into_iter().fold(Gt::one(), |x, y| x * y) == acc);
     }
+}
+
+
+/// `out[i] = a[i].inverse()` (src/lib.rs:172)
+pub fn gt_inverse_batch(a: &[Gt]) -> Result<Vec<Gt>, GpuError> {
+    let mut out = a.to_vec();
+    check(unsafe { bn254_gt_inverse_batch(std::ptr::null_mut(), a.as_ptr(), out.as_mut_ptr(), a.len()) })?;
+    Ok(out)
+}
+
+/// All (or some) GPUs of one node behind one handle: independent pairings are sharded by contiguous ranges, the multi-pairing
+/// product exchanges ONE 384-byte partial per GPU (RCCL all-gather over xGMI) and runs a single final exponentiation.
+pub struct MultiGpu(*mut c_void);
+unsafe impl Send for MultiGpu {}
+unsafe impl Sync for MultiGpu {}          // the handle locks internally: one multi-device call at a time
+
+impl MultiGpu {
+    /// `devices`: HIP device index of every rank, e.g. `&[0, 1, 2, 3, 4, 5, 6, 7]`
+    pub fn new(devices: &[i32]) -> Result<MultiGpu, GpuError> {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { bn254_multi_create(devices.as_ptr(), devices.len() as c_int, &mut h) })?;
+        Ok(MultiGpu(h))
+    }
+    /// `out[i] = bn::pairing(p[i], q[i])`, 2^20 pairings over 8 GPUs = BASELINE configs[2]
+    pub fn pairing_batch(&self, p: &[G1], q: &[G2]) -> Result<Vec<Gt>, GpuError> {
+        assert_eq!(p.len(), q.len());
+        let mut out = vec![Gt::one(); p.len()];
+        check(unsafe { bn254_pairing_batch_multi(self.0, p.as_ptr(), q.as_ptr(), out.as_mut_ptr(), p.len()) })?;
+        Ok(out)
+    }
+    /// the fold of shootout/main.rs:11-16 over all pairs (BASELINE configs[3])
+    pub fn pairing_product(&self, p: &[G1], q: &[G2]) -> Result<Gt, GpuError> {
+        assert_eq!(p.len(), q.len());
+        let mut out = Gt::one();
+        check(unsafe { bn254_pairing_product_multi(self.0, p.as_ptr(), q.as_ptr(), p.len(), &mut out) })?;
+        Ok(out)
+    }
+}
+impl Drop for MultiGpu {
+    fn drop(&mut self) { unsafe { bn254_multi_destroy(self.0) } }
 }

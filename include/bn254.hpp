@@ -69,6 +69,7 @@ struct Gt {
     static Gt one() { Gt r; std::memset(&r.v, 0, sizeof r.v); std::memcpy(r.v.c, FQ_ONE, 32); return r; }     // lib.rs:169
     Gt operator*(const Gt &o) const { Gt r; check(bn254_gt_mul_batch(nullptr, &v, &o.v, &r.v, 1)); return r; }      // lib.rs:175-179
     Gt pow(const Fr &k) const { Gt r; check(bn254_gt_pow_batch(nullptr, &v, &k.v, &r.v, 1)); return r; }            // lib.rs:171
+    Gt inverse() const { Gt r; check(bn254_gt_inverse_batch(nullptr, &v, &r.v, 1)); return r; }                     // lib.rs:172
     bool operator==(const Gt &o) const { return std::memcmp(&v, &o.v, sizeof v) == 0; }
     bool operator!=(const Gt &o) const { return !(*this == o); }
 };
@@ -91,5 +92,30 @@ inline Gt pairing_product(const std::vector<G1> &p, const std::vector<G2> &q) {
     check(bn254_pairing_product(nullptr, reinterpret_cast<const bn_g1 *>(p.data()), reinterpret_cast<const bn_g2 *>(q.data()), p.size(), &r.v));
     return r;
 }
+
+// several GPUs of one node behind one handle (bn254_multi_*): shards of independent pairings, and the multi-pairing product with
+// its single 384-byte-per-GPU exchange (RCCL all-gather over xGMI) and ONE final exponentiation
+class MultiGpu {
+    bn254_multi *m_ = nullptr;
+public:
+    explicit MultiGpu(const std::vector<int> &devices) { check(bn254_multi_create(devices.data(), (int)devices.size(), &m_)); }
+    ~MultiGpu() { bn254_multi_destroy(m_); }
+    MultiGpu(const MultiGpu &) = delete;
+    MultiGpu &operator=(const MultiGpu &) = delete;
+    bool uses_rccl() const { return bn254_multi_exchange_kind(m_) == BN254_EXCHANGE_RCCL; }
+    std::vector<Gt> pairing_batch(const std::vector<G1> &p, const std::vector<G2> &q) {
+        if (p.size() != q.size()) throw std::invalid_argument("pairing_batch: length mismatch");
+        std::vector<Gt> out(p.size());
+        check(bn254_pairing_batch_multi(m_, reinterpret_cast<const bn_g1 *>(p.data()), reinterpret_cast<const bn_g2 *>(q.data()),
+                                        reinterpret_cast<bn_gt *>(out.data()), p.size()));
+        return out;
+    }
+    Gt pairing_product(const std::vector<G1> &p, const std::vector<G2> &q) {
+        if (p.size() != q.size()) throw std::invalid_argument("pairing_product: length mismatch");
+        Gt r;
+        check(bn254_pairing_product_multi(m_, reinterpret_cast<const bn_g1 *>(p.data()), reinterpret_cast<const bn_g2 *>(q.data()), p.size(), &r.v));
+        return r;
+    }
+};
 
 }  // namespace bn

@@ -622,3 +622,46 @@ def test_bench_multi_rank_control_flow(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["peak"] > 0 and "frac" in d["roofline"]
+
+
+def test_cpp_host_drives_multi_device_entry_points(oracle, tmp_path):
+    """a compiled host program (g++, no Python in the loop) on include/bn254.hpp: bn::pairing, Gt::inverse, and bn::MultiGpu with two
+    ranks on device 0 - pairing_batch and pairing_product equal the oracle's fold of shootout/main.rs:11-16"""
+    import pathlib, subprocess
+    root = pathlib.Path(__file__).resolve().parents[1]
+    src = tmp_path / "host.cpp"
+    src.write_text(r'''
+#include "bn254.hpp"
+#include <cstdio>
+template <class T> void dump(const T &t) { const uint64_t *w = reinterpret_cast<const uint64_t *>(&t); for (size_t i = 0; i < sizeof(T) / 8; ++i) std::printf("%llu ", (unsigned long long)w[i]); std::printf("\n"); }
+int main() {
+    using namespace bn;
+    std::vector<G1> p; std::vector<G2> q;
+    G1 a = G1::one(); G2 b = G2::one();
+    for (int i = 0; i < 5; ++i) { p.push_back(a); q.push_back(b); a = a + G1::one(); b = b + b; }      // (i+1) G1, 2^i G2: Jacobian z != 1
+    p[3] = G1::zero();
+    MultiGpu m({0, 0});
+    std::vector<Gt> out = m.pairing_batch(p, q);
+    for (auto &g : out) dump(g);
+    dump(m.pairing_product(p, q));
+    Gt e = pairing(p[1], q[1]);
+    dump(e.inverse() * e);
+    std::printf("%d\n", m.uses_rccl() ? 1 : 0);
+    return 0;
+}
+''')
+    exe = tmp_path / "host"
+    subprocess.check_call(["g++", "-std=c++17", "-I", str(root / "include"), str(src), "-o", str(exe),
+                           "-L", str(root / "bn_amd"), "-lbn254_hip", "-Wl,-rpath," + str(root / "bn_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    lines = subprocess.check_output([str(exe)], timeout=600).decode().strip().split("\n")
+    got = [np.array([int(x) for x in l.split()], np.uint64) for l in lines[:7]]
+    P = np.stack([oracle.g1_one()] * 5); Q = np.stack([oracle.g2_one()] * 5)
+    for i in range(1, 5):
+        P[i] = oracle.g1_add(P[i - 1], oracle.g1_one()); Q[i] = oracle.g2_add(Q[i - 1], Q[i - 1])
+    P[3] = oracle.g1_zero()
+    want = oracle.pairing_batch(P, Q)
+    for i in range(5):
+        assert np.array_equal(got[i], want[i]), i
+    assert np.array_equal(got[5], oracle.pairing_product(P, Q))
+    assert np.array_equal(got[6], oracle.fq12_one())
+    assert lines[7].strip() == "0"                     # two ranks on one device: peer-copy exchange, not RCCL
