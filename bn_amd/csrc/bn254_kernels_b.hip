@@ -314,7 +314,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
         Line<F2> l = {f2_load((const F2 *)nullptr, c), f2_load((const F2 *)nullptr, c + 16), f2_load((const F2 *)nullptr, c + 32)};
         return l;
     };
-    Fq12<F2> f = miller_loop_prepared<F2>(p, source);
+    __shared__ uint32_t park[18 * BLOCK];
+    MillerStateLds st = {park + threadIdx.x};            // only slots 0, 1 are used here: P.x, P.y
+    st.st_fe(0, p.x); st.st_fe(1, p.y);
+    struct PInLds { const MillerStateLds &s; __device__ __forceinline__ G1Aff<Fe> get_p() const { return {s.ld_fe(0), s.ld_fe(1)}; } } ps = {st};
+    Fq12<F2> f = miller_loop_prepared<F2>(ps, source);
     Fq12<F2> one = f12_one<F2>();
     f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
     f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);

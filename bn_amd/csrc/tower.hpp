@@ -162,6 +162,7 @@ BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &
     const F2 &z0 = f.c0.c0, &z1 = f.c0.c1, &z2 = f.c0.c2, &z3 = f.c1.c0, &z4 = f.c1.c1, &z5 = f.c1.c2;
     const F2 &x0 = ell_0, &x2 = ell_vv, &x4 = ell_vw;
     Fq12<F2> r;
+#ifdef BN_MUL024_OLD_ORDER
     F2 d0 = f2_mul(z0, x0), d4 = f2_mul(z4, x4);
     F2 s1 = f2_mul(z1, x2);                                              // running sum of the six cross products (lazy)
     r.c0.c0 = f2_lc_xi<1, 1>(f2_add(s1, d4), d0);                        // xi (z1 x2 + z4 x4) + z0 x0
@@ -188,6 +189,52 @@ BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &
     }
     F2 ms = f2_mul(f2_sum3_for_mul(z1, z3, z5), f2_sum3_for_mul(x0, x2, x4));
     r.c1.c2 = f2_lc3w<1, -1, 0>(ms, s1, s1);                              // (z1+z3+z5)(x0+x2+x4) - s1
+#else
+    // Register-pressure order (the spills of this function cost the Miller loop ~10 %, profiles/r02k_*): the four Karatsuba sums
+    // of f's coefficients are formed FIRST, so that every z_i dies right after its own products instead of living to the end;
+    // peak ~17 nine-register values instead of ~21.
+    const F2 z135 = f2_sum3_for_mul(z1, z3, z5);
+    const F2 z02 = f2_add(z0, z2), z24 = f2_add(z2, z4), z04 = f2_add(z0, z4);
+    BN_COMPILER_FENCE();
+    const F2 d0 = f2_mul(z0, x0), d2 = f2_mul(z2, x2), d4 = f2_mul(z4, x4);          // z0, z2, z4 dead
+    F2 s1;                                                                           // running sum of the six cross products (lazy)
+    F2 z1x0;
+    {
+        F2 z1x2 = f2_mul(z1, x2);
+        z1x0 = f2_mul(z1, x0);                                                       // z1 dead
+        r.c0.c0 = f2_lc_xi<1, 1>(f2_add(z1x2, d4), d0);                              // xi (z1 x2 + z4 x4) + z0 x0
+        s1 = f2_add(z1x2, z1x0);
+    }
+    BN_COMPILER_FENCE();
+    F2 z5x2;
+    {
+        F2 z5x4 = f2_mul(z5, x4);
+        z5x2 = f2_mul(z5, x2);                                                       // z5 dead
+        r.c0.c1 = f2_lc_xi<1, 1>(f2_add(z5x4, d2), z1x0);                            // xi (z5 x4 + z2 x2) + z1 x0
+        s1 = f2_add(f2_add(s1, z5x4), z5x2);
+    }
+    BN_COMPILER_FENCE();
+    F2 z3x0;
+    {
+        F2 z3x4 = f2_mul(z3, x4);
+        z3x0 = f2_mul(z3, x0);                                                       // z3 dead
+        s1 = f2_add(f2_add(s1, z3x4), z3x0);
+        F2 m02 = f2_mul(z02, f2_norm(f2_add(x0, x2)));
+        r.c0.c2 = f2_lc3<1, -1, -1>(f2_add(m02, z3x4), d0, d2);                      // (z0+z2)(x0+x2) - d0 - d2 + z3 x4
+    }
+    BN_COMPILER_FENCE();
+    {
+        F2 m24 = f2_mul(z24, f2_norm(f2_add(x2, x4)));
+        r.c1.c0 = f2_lc_xi<1, 1>(f2_ssub(f2_ssub(m24, d2), d4), z3x0);               // xi ((z2+z4)(x2+x4) - d2 - d4) + z3 x0
+    }
+    {
+        F2 m04 = f2_mul(z04, f2_norm(f2_add(x0, x4)));
+        r.c1.c1 = f2_lc_xi<1, 1>(z5x2, f2_ssub(f2_ssub(m04, d0), d4));               // xi z5 x2 + (z0+z4)(x0+x4) - d0 - d4
+    }
+    BN_COMPILER_FENCE();
+    F2 ms = f2_mul(z135, f2_sum3_for_mul(x0, x2, x4));
+    r.c1.c2 = f2_lc3w<1, -1, 0>(ms, s1, s1);                                          // (z1+z3+z5)(x0+x2+x4) - s1
+#endif
     return r;
 }
 
