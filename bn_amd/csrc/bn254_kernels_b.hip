@@ -236,7 +236,6 @@ struct ExpTableMem {
     uint32_t *table;         // wave-uniform base (SGPRs)
     uint32_t lane;           // this lane's column
     uint32_t stride;         // lanes in the launch
-    int round;               // which of the three exponentiations is running (progress reporting of the loop hook)
     __device__ __forceinline__ uint32_t *row(int slot, int half) const {          // uniform: scalar address arithmetic
         return table + (size_t)(uint32_t)((slot * 2 + half) * 27) * stride;
     }
@@ -273,7 +272,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
-    ExpTableMem tbl = {table, t, gridDim.x * BLOCK, 0};
+    ExpTableMem tbl = {table, t, gridDim.x * BLOCK};
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair), tbl);
     if (live) f12_store(f, out + 96u * pair);
     BN_STAMP_END();

@@ -210,13 +210,12 @@ BN_FN Fq12<F2> miller_loop_prepared(const PStore &pstore, Source &source) {
     return f;
 }
 
-// Table of the windowed exponentiation below: EXP_SLOTS Fq12 values per pairing.  Default: ordinary variables (host
-// simulation); the lane-pair kernel keeps it in global memory (54 dwords per lane and slot, coalesced), which also takes the
-// multiplier of the exponentiation loop out of the register file.
+// Table of the exponentiation machine below: EXP_SLOTS Fq12 values per pairing.  Default: ordinary variables (host
+// simulation, one-lane mapping); the lane-pair kernel keeps it in global memory (54 dwords per lane and slot, coalesced), which
+// also takes the multiplier of the loop out of the register file.
 template <class F2>
 struct ExpTableVars {
     Fq12<F2> s_[k::EXP_SLOTS];
-    int round = 0;                      // which of the three exponentiations of the hard part is running (progress reporting)
     BN_FN void put(int i, const Fq12<F2> &v) { s_[i] = v; }
     BN_FN Fq6<F2> c0(int i) const { return s_[i].c0; }
     BN_FN Fq6<F2> c1(int i) const { return s_[i].c1; }
@@ -229,30 +228,38 @@ struct Fq12Slot {
     BN_FN Fq6<F2> c1() const { return t.c1(i); }
 };
 
+// One step of the exponentiation machine on the cyclotomic subgroup.  Control word (tools/gen_device_constants.py, which also
+// executes every program symbolically): load res from a slot | cyclotomic squaring | multiply by a slot (or its conjugate) |
+// conjugate / Frobenius map | store res.  Every branch is wave-uniform; each step body exists once in the instruction stream.
+template <class F2, class Tbl>
+BN_FN void fe_step(Fq12<F2> &res, const int w, Tbl &tbl) {
+    const int get = (w >> 10) & 15, mul = (w >> 1) & 15, put = (w >> 6) & 15, post = (w >> 14) & 7;
+    if (get) res = Fq12<F2>{tbl.c0(get - 1), tbl.c1(get - 1)};
+    if (w & 1) res = f12_cyclotomic_sqr(res);
+    if (mul) res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, mul - 1}, ((w >> 5) & 1) != 0);
+    if (post == 1) {
+        res.c1 = f6_neg(res.c1);                                                    // fq12.rs:103-105
+    } else if (post) {
+        // the maps are out of line; they get a COPY (a reference to the loop-carried value would pin it to a stack slot)
+        const Fq12<F2> cur = res;
+        res = post == 2 ? f12_frobenius<1>(cur) : post == 3 ? f12_frobenius<2>(cur) : f12_frobenius<3>(cur);
+    }
+    if (put) tbl.put(put - 1, res);
+}
+
 // fq12.rs:229-246 + 97-101: f^u, then conjugate.  The reference walks the 63 bits of u (62 cyclotomic squarings, 27
-// multiplications).  On the cyclotomic subgroup f^-1 = conj(f) is free, so the same group element is reached through the
-// width-4 non-adjacent form of u over the odd powers f, f^3, f^5, f^7 (63 squarings, 16 multiplications including the table);
-// the value - and therefore every output byte - is identical.  k::EXP_SCHED holds one control word per step, so the squaring
-// and the product each exist once in the instruction stream.
-// Only valid for f in the cyclotomic subgroup, which is where final_exponentiation calls it (after the easy part).
+// multiplications).  On the cyclotomic subgroup f^-1 = conj(f) is free, so the same group element is reached through the signed
+// digits +-17, +-35 of u (62 squarings, 13 multiplications including the table; tools/gen_device_constants.py); the value - and
+// therefore every output byte - is identical.  Only valid for f in the cyclotomic subgroup.
 template <class F2, class Tbl>
 BN_OUTER Fq12<F2> exp_by_neg_z(const Fq12<F2> &f, Tbl &tbl) {
     Fq12<F2> res = f;
 #pragma unroll 1
     for (int s = 0; s < k::EXP_STEPS; ++s) {
-        BN_EXP_HOOK(tbl.round * k::EXP_STEPS + s, 3 * k::EXP_STEPS);
-        const int w = k::EXP_SCHED[s];
-        const int get = (w >> 8) & 7, mul = (w >> 1) & 7, put = (w >> 5) & 7;
-        if (get) res = Fq12<F2>{tbl.c0(get - 1), tbl.c1(get - 1)};
-        if (w & 1) res = f12_cyclotomic_sqr(res);
-        if (mul) res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, mul - 1}, ((w >> 4) & 1) != 0);
-        if (put) tbl.put(put - 1, res);
+        BN_EXP_HOOK(s, k::EXP_STEPS);
+        fe_step(res, k::EXP_SCHED[s], tbl);
     }
-    tbl.round = tbl.round + 1;
-    // hand a COPY to the out-of-line conjugation: a reference to `res` itself would pin the loop-carried value to a stack
-    // slot (its address escapes), and every iteration would go through private memory
-    const Fq12<F2> last = res;
-    return f12_conj(last);
+    return res;
 }
 template <class F2>
 BN_FN Fq12<F2> exp_by_neg_z(const Fq12<F2> &f) {
@@ -278,30 +285,18 @@ BN_FN Fq12<F2> final_exp_first_chunk(const Fq12<F2> &f) {
     Fq12<F2> c = f12_mul_o(f12_conj(f), b);
     return f12_mul_o(f12_frobenius<2>(c), c);
 }
-// fq12.rs:54-84
+// fq12.rs:54-84: the whole hard part (three exponentiations by u and the products, squarings, conjugations and Frobenius maps
+// a .. u between them) as ONE program of the machine above (k::FE_PROG, checked symbolically against the reference's sequence):
+// the running value stays in registers, the nine values that must be kept live in the table, nothing goes through private memory.
 template <class F2, class Tbl>
 BN_FN Fq12<F2> final_exp_last_chunk(const Fq12<F2> &s, Tbl &tbl) {
-    Fq12<F2> a = exp_by_neg_z(s, tbl);
-    Fq12<F2> b = f12_cyclotomic_sqr_o(a);
-    Fq12<F2> c = f12_cyclotomic_sqr_o(b);
-    Fq12<F2> d = f12_mul_o(c, b);
-    Fq12<F2> e = exp_by_neg_z(d, tbl);
-    Fq12<F2> f = f12_cyclotomic_sqr_o(e);
-    Fq12<F2> g = exp_by_neg_z(f, tbl);
-    Fq12<F2> h = f12_conj(d);
-    Fq12<F2> i = f12_conj(g);
-    Fq12<F2> j = f12_mul_o(i, e);
-    Fq12<F2> kk = f12_mul_o(j, h);
-    Fq12<F2> l = f12_mul_o(kk, b);
-    Fq12<F2> m = f12_mul_o(kk, e);
-    Fq12<F2> n = f12_mul_o(s, m);
-    Fq12<F2> o = f12_frobenius<1>(l);
-    Fq12<F2> p = f12_mul_o(o, n);
-    Fq12<F2> q = f12_frobenius<2>(kk);
-    Fq12<F2> r = f12_mul_o(q, p);
-    Fq12<F2> t = f12_mul_o(f12_conj(s), l);
-    Fq12<F2> u = f12_frobenius<3>(t);
-    return f12_mul_o(u, r);
+    Fq12<F2> res = s;
+#pragma unroll 1
+    for (int i = 0; i < k::FE_STEPS; ++i) {
+        BN_EXP_HOOK(i, k::FE_STEPS);
+        fe_step(res, k::FE_PROG[i], tbl);
+    }
+    return res;
 }
 template <class F2, class Tbl>
 BN_FN Fq12<F2> final_exponentiation(const Fq12<F2> &f, Tbl &tbl) { return final_exp_last_chunk(final_exp_first_chunk(f), tbl); }
