@@ -14,6 +14,7 @@
 #define BN_MUL_WAVES 2        // resident waves per SIMD the G1 kernel is compiled for
 #endif
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "curve.hpp"
 #include "io.hpp"
 
@@ -29,7 +30,10 @@ __device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km,
 #pragma unroll
     for (int i = 0; i < 8; ++i) kw[i] = km[i];
     fr_from_mont(kw, raw);
-    if (normalize) return jac_normalize<F>(scalar_mul_windowed<F>(p, raw));
+    if (normalize) {
+        if constexpr (std::is_same<F, FqField>::value) return jac_normalize<F>(scalar_mul_glv(p, raw));      // G1: GLV + signed windows
+        else return jac_normalize<F>(scalar_mul_windowed<F>(p, raw));
+    }
     return scalar_mul_reference_chain<F>(p, raw);
 }
 

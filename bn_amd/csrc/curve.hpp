@@ -26,6 +26,7 @@ struct FqField {
     static BN_FN T one() { return fe_one(); }
     static BN_FN T select(bool b, const T &x, const T &y) { return fe_select(b, x, y); }
     static BN_FN bool is_zero(const T &a) { return fe_is_zero(a); }
+    static BN_FN bool is_zero_std(const T &a) { return fe_is_zero_std(a); }        // normalized, below 4q
     static BN_FN T inverse(const T &a) { return fe_inverse(a); }
 };
 template <class F2>
@@ -41,6 +42,7 @@ struct Fq2Field {
     static BN_FN T one() { return f2_one((const F2 *)nullptr); }
     static BN_FN T select(bool b, const T &x, const T &y) { return f2_select(b, x, y); }
     static BN_FN bool is_zero(const T &a) { return f2_is_zero(a); }
+    static BN_FN bool is_zero_std(const T &a) { return f2_is_zero_std(a); }
     static BN_FN T inverse(const T &a) { return f2_inverse(a); }
 };
 
@@ -73,7 +75,7 @@ BN_COARSE Jac<F> jac_add_flags(const Jac<F> &p, const Jac<F> &q, bool pz, bool q
     T u1 = F::mul(p.x, z2s), u2 = F::mul(q.x, z1s);
     T s1 = F::mul(p.y, F::mul(q.z, z2s)), s2 = F::mul(q.y, F::mul(p.z, z1s));
     T h = F::template lc3<1, -1, 0>(u2, u1, u1), sd = F::template lc3<1, -1, 0>(s2, s1, s1);
-    bool same = F::is_zero(h) && F::is_zero(sd) && !pz && !qz;
+    bool same = F::is_zero_std(h) && F::is_zero_std(sd) && !pz && !qz;          // h, sd are fused reductions: normalized, < 2q
     T i = F::sqr(F::sum(h, h));
     T j = F::mul(h, i);
     T rr = F::sum(sd, sd);
@@ -174,6 +176,121 @@ BN_FN Jac<F> scalar_mul_windowed(const Jac<F> &p, const uint32_t *k_raw) {
     }
     return res;
 }
+// ---- G1 only: GLV.  phi(x, y) = (beta x, y) is multiplication by lambda on the order-r subgroup of E(Fq) (beta^3 = 1, lambda^3 = 1),
+// so k P = k1 P + k2 phi(P) with k = k1 + k2 lambda (mod r) and |k1|, |k2| < 2^129: 128 doublings instead of 252, the additions of
+// the two half-length scalars interleaved on one accumulator.  Same group element as groups/mod.rs:250-270, different Jacobian
+// coordinates - callers normalize.  Constants and a word-for-word model of glv_decompose: tools/gen_device_constants.py.
+struct GlvSplit {
+    uint32_t m1[5], m2[5];       // |k1|, |k2| (160-bit little-endian words; < 2^129)
+    bool neg1, neg2;
+};
+// out[0..NO) = low NO words of a[0..NA) * b[0..NB)
+template <int NA, int NB, int NO>
+BN_FN void words_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) {
+    uint32_t t[NA + NB];
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            uint64_t x = (uint64_t)a[i] * b[j] + t[i + j] + c;
+            t[i + j] = (uint32_t)x; c = x >> 32;
+        }
+        t[i + NB] = (uint32_t)c;
+    }
+#pragma unroll
+    for (int i = 0; i < NO; ++i) out[i] = t[i];
+}
+BN_FN GlvSplit glv_decompose(const uint32_t *k_raw) {
+    // c1 = floor(k * floor(2^256 b2 / r) / 2^256),  c2 = floor(k * floor(2^256 |b1| / r) / 2^256)
+    uint32_t p1[11], p2[13];
+    words_mul<8, 3, 11>(k_raw, k::GLV_G1, p1);
+    words_mul<8, 5, 13>(k_raw, k::GLV_G2, p2);
+    const uint32_t *c1 = p1 + 8, *c2 = p2 + 8;               // 3 and 5 words
+    // modulo 2^192, two's complement:  k1 = k - c1 a1 - c2 a2,   k2 = c1 |b1| - c2 b2
+    uint32_t t1[6], t2[6], t3[6], t4[6];
+    words_mul<3, 2, 5>(c1, k::GLV_A1, t1); t1[5] = 0;
+    words_mul<5, 4, 6>(c2, k::GLV_A2, t2);
+    words_mul<3, 4, 6>(c1, k::GLV_B1N, t3);
+    words_mul<5, 2, 6>(c2, k::GLV_B2, t4);
+    uint32_t k1[6], k2[6];
+    int64_t b1 = 0, b2 = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int64_t s = (int64_t)k_raw[i] - (int64_t)t1[i] - (int64_t)t2[i] + b1;
+        k1[i] = (uint32_t)s; b1 = s >> 32;
+        int64_t u = (int64_t)t3[i] - (int64_t)t4[i] + b2;
+        k2[i] = (uint32_t)u; b2 = u >> 32;
+    }
+    GlvSplit g;
+    g.neg1 = (k1[5] >> 31) != 0; g.neg2 = (k2[5] >> 31) != 0;
+    uint32_t cy1 = g.neg1 ? 1u : 0u, cy2 = g.neg2 ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {                             // magnitude: conditional two's-complement negation
+        uint64_t a = (uint64_t)(g.neg1 ? ~k1[i] : k1[i]) + cy1; g.m1[i] = (uint32_t)a; cy1 = (uint32_t)(a >> 32);
+        uint64_t b = (uint64_t)(g.neg2 ? ~k2[i] : k2[i]) + cy2; g.m2[i] = (uint32_t)b; cy2 = (uint32_t)(b >> 32);
+    }
+    return g;
+}
+// radix-16 Booth digit i of a non-negative magnitude (5 words): -8 b[4i+3] + 4 b[4i+2] + 2 b[4i+1] + b[4i] + b[4i-1], in [-8, 8];
+// sum digit_i 16^i = magnitude when the window above the top one is empty (no carries to propagate: MSB-first evaluation)
+BN_FN int booth_digit(const uint32_t *mag, int i) {
+    const int pos = 4 * i - 1;
+    uint32_t x;
+    if (pos < 0) {
+        x = (mag[0] << 1) & 31u;
+    } else {
+        const int w = pos >> 5, sh = pos & 31;
+        uint64_t two = (uint64_t)mag[w] | (w + 1 < 5 ? ((uint64_t)mag[w + 1] << 32) : 0);
+        x = (uint32_t)(two >> sh) & 31u;
+    }
+    return (int)((x >> 1) & 7u) + (int)(x & 1u) - (int)((x >> 4) << 3);
+}
+constexpr int GLV_WINDOWS = 33;          // 4 * 33 = 132 bits >= 129 + the Booth sign bit
+
+BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) {
+    using F = FqField;
+    const GlvSplit g = glv_decompose(k_raw);
+    const bool p_inf = F::is_zero(p.z);
+    Jac<F> tab[9];                                            // tab[j] = j P, tab[0] = infinity
+    tab[1] = p;
+    tab[2] = jac_double(tab[1]);
+    tab[4] = jac_double(tab[2]);
+    tab[8] = jac_double(tab[4]);
+    tab[3] = jac_add_flags(tab[2], p, p_inf, p_inf);
+    tab[6] = jac_double(tab[3]);
+    tab[5] = jac_add_flags(tab[4], p, p_inf, p_inf);
+    tab[7] = jac_add_flags(tab[6], p, p_inf, p_inf);
+    tab[0] = {F::zero(), F::one(), F::zero()};
+    const Fe beta = fe_const(k::GLV_BETA);
+    Jac<F> res = {F::zero(), F::one(), F::zero()};
+    bool res_inf = true;
+#pragma unroll 1
+    for (int w = GLV_WINDOWS - 1; w >= 0; --w) {
+        if (w != GLV_WINDOWS - 1) {
+#pragma unroll 1
+            for (int d = 0; d < 4; ++d) res = jac_double(res);    // infinity stays infinity (z = 0)
+        }
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int d = booth_digit(half ? g.m2 : g.m1, w);
+            const int ad = d < 0 ? -d : d;
+            const bool negate = (d < 0) != (half ? g.neg2 : g.neg1);
+            Jac<F> q = tab[ad];
+            if (half) q.x = fe_mul(q.x, beta);                    // phi(j P)
+            q.y = F::select(negate, q.y, F::template lc3<-1, 0, 0>(q.y, q.y, q.y));
+            const bool q_inf = p_inf || ad == 0;
+            res = jac_add_flags(res, q, res_inf, q_inf);
+            // the sum of two finite points may be infinity (opposite points: z = Z1 Z2 H = 0), and partial sums of the two
+            // interleaved scalars can cancel for crafted inputs - so the flag is read off z (a product: normalized, < 2q)
+            res_inf = F::is_zero_std(res.z);
+        }
+    }
+    return res;
+}
+
 // lib.rs:88-95 (normalize): (x/z^2, y/z^3, 1).  Infinity is returned as G::zero() = (0, 1, 0) (groups/mod.rs:208-214): that is
 // what the reference holds for every valid input that multiplies to zero (k = 0 or p = 0; k < r excludes the rest), while
 // the windowed chain above may reach z = 0 with other x, y.

@@ -602,6 +602,29 @@ BN_FN bool fe_is_zero(const Fe &a) {
     for (int i = 0; i < 9; ++i) o |= t.l[i];
     return o == 0;
 }
+// a == 0 (mod q) for a NORMALIZED value below 4q (every product, fused reduction and carry-propagated sum of two of them): the
+// value is 0 exactly when it equals 0, q, 2q or 3q, so four limb-wise comparisons replace the Montgomery product +
+// canonicalisation of fe_is_zero.  (The equal-point test of every group addition runs this twice.)
+struct QMultiples {
+    uint32_t m[4][9];
+    constexpr QMultiples() : m{} {
+        for (int kk = 0; kk < 4; ++kk) {
+            uint64_t carry = 0;
+            for (int i = 0; i < 9; ++i) {
+                uint64_t t = (uint64_t)k::Q[i] * (uint64_t)kk + carry;
+                if (i < 8) { m[kk][i] = (uint32_t)(t & MASK29); carry = t >> 29; } else { m[kk][i] = (uint32_t)t; }
+            }
+        }
+    }
+};
+BN_FN bool fe_is_zero_std(const Fe &a) {
+    BN_REQUIRE(!a.sg && a.lb == 1 && a.vb <= 4, "fe_is_zero_std expects normalized limbs and a value below 4q");
+    constexpr QMultiples QM{};
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { d0 |= a.l[i]; d1 |= a.l[i] ^ QM.m[1][i]; d2 |= a.l[i] ^ QM.m[2][i]; d3 |= a.l[i] ^ QM.m[3][i]; }
+    return (d0 == 0) | (d1 == 0) | (d2 == 0) | (d3 == 0);
+}
 // per-lane select without divergence
 BN_FN Fe fe_select(bool take_b, const Fe &a, const Fe &b) {
     BN_COUNT(select);

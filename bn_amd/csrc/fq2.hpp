@@ -50,6 +50,7 @@ BN_FN Fq2A f2_one(const Fq2A *) { return {fe_one(), fe_zero()}; }
 template <class T>
 BN_FN Fq2A f2_const(const Fq2A *, const T &tab) { return {fe_const(tab[0]), fe_const(tab[1])}; }
 BN_FN bool f2_is_zero(const Fq2A &a) { return fe_is_zero(a.c0) & fe_is_zero(a.c1); }
+BN_FN bool f2_is_zero_std(const Fq2A &a) { return fe_is_zero_std(a.c0) & fe_is_zero_std(a.c1); }
 BN_FN Fq2A f2_select(bool take_b, const Fq2A &a, const Fq2A &b) { return {fe_select(take_b, a.c0, b.c0), fe_select(take_b, a.c1, b.c1)}; }
 
 // a: lb <= 2, vb <= 6;  b: S
@@ -133,6 +134,7 @@ BN_FN Fe lane_const_pick(const Fe *, const TAB &even_tab, const TAB &odd_tab) {
 BN_FN Fe lane_load_pair(const Fe *, const uint32_t *w0, const uint32_t *w1) { return fe_from_u32x8(lane_is_odd() ? w1 : w0); }
 BN_FN void lane_store_pair(const Fe &a, uint32_t *w0, uint32_t *w1) { fe_to_u32x8(a, lane_is_odd() ? w1 : w0); }
 BN_FN bool lane_pair_all_zero(const Fe &a) { bool z = fe_is_zero(a); return z && lane_partner_flag(z); }
+BN_FN bool lane_pair_all_zero_std(const Fe &a) { bool z = fe_is_zero_std(a); return z && lane_partner_flag(z); }
 // reduce(C1*x + s*C2*y + C3*z), s = -1 on even lanes, +1 on odd lanes
 template <int C1, int C2, int C3>
 BN_FN Fe fe_lc3_par_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3>(x, y, z, !lane_is_odd()); }
@@ -220,6 +222,7 @@ BN_FN Fq2B<T> f2_inverse(const Fq2B<T> &a) {
     return {lane_pick(r, fe_lc3<-1, 0, 0>(r, r, r))};
 }
 template <class T> BN_FN bool f2_is_zero(const Fq2B<T> &a) { return lane_pair_all_zero(a.v); }
+template <class T> BN_FN bool f2_is_zero_std(const Fq2B<T> &a) { return lane_pair_all_zero_std(a.v); }
 template <class T> BN_FN Fq2B<T> f2_load(const Fq2B<T> *, const uint32_t *w) { return {lane_load_pair(TP, w, w + 8)}; }
 template <class T> BN_FN void f2_store(const Fq2B<T> &a, uint32_t *w) { lane_store_pair(a.v, w, w + 8); }
 template <class T> BN_FN T f2_scalar_load(const Fq2B<T> *, const uint32_t *w) { return lane_load_pair(TP, w, w); }

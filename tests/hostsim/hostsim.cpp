@@ -101,6 +101,21 @@ static void st1(const Fe &a, uint32_t *w) { fe_to_u32x8(a, w); }
 static F2 ld2(const uint32_t *w) { return f2_load((F2 *)0, w); }
 static void st2(const F2 &a, uint32_t *w) { f2_store(a, w); }
 EXPORT void hs_g1_mul(const uint32_t *p, const uint32_t *k, int normalize, uint32_t *o) { hs_mul_generic<FqField, 8>(p, k, o, normalize, ld1, st1); }
+// G1 through the GLV chain (what bn254_g1_mul_batch runs), normalized; and the decomposition itself: |k1|, |k2| (5 words each), signs
+EXPORT void hs_g1_mul_glv(const uint32_t *pt, const uint32_t *k, uint32_t *o) {
+    Jac<FqField> p = {ld1(pt), ld1(pt + 8), ld1(pt + 16)};
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    Jac<FqField> r = jac_normalize<FqField>(scalar_mul_glv(p, raw));
+    st1(r.x, o); st1(r.y, o + 8); st1(r.z, o + 16);
+}
+EXPORT void hs_glv_decompose(const uint32_t *k, uint32_t *o) {
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    GlvSplit g = glv_decompose(raw);
+    for (int i = 0; i < 5; ++i) { o[i] = g.m1[i]; o[6 + i] = g.m2[i]; }
+    o[5] = g.neg1; o[11] = g.neg2;
+}
 EXPORT void hs_g2_mul(const uint32_t *p, const uint32_t *k, int normalize, uint32_t *o) { hs_mul_generic<Fq2Field<F2>, 16>(p, k, o, normalize, ld2, st2); }
 EXPORT void hs_fr_from_mont(const uint32_t *k, uint32_t *o) { fr_from_mont(k, o); }
 

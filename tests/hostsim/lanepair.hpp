@@ -42,4 +42,5 @@ BN_FN FeP fe_select(bool take_b, const FeP &a, const FeP &b) { return {{fe_selec
 BN_FN FeP lane_load_pair(const FeP *, const uint32_t *w0, const uint32_t *w1) { return {{fe_from_u32x8(w0), fe_from_u32x8(w1)}}; }
 BN_FN void lane_store_pair(const FeP &a, uint32_t *w0, uint32_t *w1) { fe_to_u32x8(a.v[0], w0); fe_to_u32x8(a.v[1], w1); }
 BN_FN bool lane_pair_all_zero(const FeP &a) { return fe_is_zero(a.v[0]) && fe_is_zero(a.v[1]); }
+BN_FN bool lane_pair_all_zero_std(const FeP &a) { return fe_is_zero_std(a.v[0]) && fe_is_zero_std(a.v[1]); }
 }  // namespace bn254

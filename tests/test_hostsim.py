@@ -187,6 +187,32 @@ def test_scalar_mul_reference_chain(oracle, hs):
             assert np.array_equal(hs.call(fn, base, k, 2, out_words=2 * w), canon_infinity(on(want)))   # windowed algorithm, normalized
 
 
+def test_g1_glv_scalar_mul(oracle, hs, ref_consts):
+    """bn254_g1_mul_batch's chain: k = k1 + k2 lambda (mod r) with |k1|, |k2| < 2^129, Booth radix-16 digits, phi(x, y) = (beta x, y);
+    the normalized result equals the reference's G * Fr for edge and random scalars and base points (incl. infinity)"""
+    import re, pathlib
+    txt = (pathlib.Path(__file__).resolve().parents[1] / "bn_amd" / "csrc" / "bn254_constants.hpp").read_text()
+    lam = sum(int(x, 16) << (32 * i) for i, x in enumerate(re.findall(r"0x[0-9a-f]+", re.search(r"GLV_LAMBDA\[8\] = \{(.*?)\}", txt).group(1))))
+    assert (lam * lam + lam + 1) % M.R_ORD == 0
+    rng = np.random.default_rng(23)
+    ks = [0, 1, 2, 15, 16, 17, M.R_ORD - 1, M.R_ORD - 2, lam, lam - 1, M.R_ORD - lam, 1 << 127, (1 << 128) - 1, 1 << 253] + \
+         [int.from_bytes(rng.bytes(40), "little") % M.R_ORD for _ in range(12)]
+    b1 = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, 31337))
+    for kv in ks:
+        k = oracle.fp_from_int(FR, kv)
+        d = hs.call("hs_glv_decompose", k, out_words=12).view(np.uint32)
+        m1 = sum(int(d[i]) << (32 * i) for i in range(5)); m2 = sum(int(d[6 + i]) << (32 * i) for i in range(5))
+        assert m1 < (1 << 129) and m2 < (1 << 129)
+        assert ((-m1 if d[5] else m1) + (-m2 if d[11] else m2) * lam - kv) % M.R_ORD == 0
+        for base in (b1, oracle.g1_one(), oracle.g1_zero()):
+            want = canon_infinity(oracle.g1_normalize(oracle.g1_mul(base, k)))
+            assert np.array_equal(hs.call("hs_g1_mul_glv", base, k, out_words=24), want), kv
+    # P and -P style cancellations inside the interleaved chain: k1 P + k2 phi(P) where k = lambda (k1 = 0, k2 = 1) and k = r - lambda
+    for kv in (lam, M.R_ORD - lam, (lam + 1) % M.R_ORD):
+        k = oracle.fp_from_int(FR, kv)
+        assert np.array_equal(hs.call("hs_g1_mul_glv", b1, k, out_words=24), canon_infinity(oracle.g1_normalize(oracle.g1_mul(b1, k))))
+
+
 def test_many_random_pairings_with_bound_verification(oracle, hs):
     """200 random pairings through BOTH lane mappings of the device code on the CPU, every operation checked against its claimed
     limb/value bounds (actual limbs, not just worst cases) and every result against the oracle"""
