@@ -71,19 +71,22 @@ BN_OUTER Jac<F> jac_double_cold(const Jac<F> &p) { return jac_double(p); }
 template <class F>
 BN_COARSE Jac<F> jac_add_flags(const Jac<F> &p, const Jac<F> &q, bool pz, bool qz) {
     using T = typename F::T;
-    T z1s = F::sqr(p.z), z2s = F::sqr(q.z);
-    T u1 = F::mul(p.x, z2s), u2 = F::mul(q.x, z1s);
-    T s1 = F::mul(p.y, F::mul(q.z, z2s)), s2 = F::mul(q.y, F::mul(p.z, z1s));
+    // ordered for short live ranges: the z-dependent values first, Z3 as soon as H exists (the operands stay live to the end only
+    // for the selects of the special cases below)
+    T z1s = F::sqr(p.z);
+    T u2 = F::mul(q.x, z1s), s2 = F::mul(q.y, F::mul(p.z, z1s));
+    T z2s = F::sqr(q.z);
+    T u1 = F::mul(p.x, z2s), s1 = F::mul(p.y, F::mul(q.z, z2s));
     T h = F::template lc3<1, -1, 0>(u2, u1, u1), sd = F::template lc3<1, -1, 0>(s2, s1, s1);
     bool same = F::is_zero_std(h) && F::is_zero_std(sd) && !pz && !qz;          // h, sd are fused reductions: normalized, < 2q
+    Jac<F> r;
+    r.z = F::mul(F::template lc3<1, -1, -1>(F::sqr(F::template lc3<1, 1, 0>(p.z, q.z, q.z)), z1s, z2s), h);
     T i = F::sqr(F::sum(h, h));
     T j = F::mul(h, i);
-    T rr = F::sum(sd, sd);
     T v = F::mul(u1, i);
-    Jac<F> r;
+    T rr = F::sum(sd, sd);
     r.x = F::template lc3<1, -1, -2>(F::sqr(rr), j, v);
     r.y = F::template lc3<1, -2, 0>(F::mul(rr, F::template lc3<1, -1, 0>(v, r.x, v)), F::mul(s1, j), j);
-    r.z = F::mul(F::template lc3<1, -1, -1>(F::sqr(F::template lc3<1, 1, 0>(p.z, q.z, q.z)), z1s, z2s), h);
     if (same) {                                    // groups/mod.rs:291-292
         const Jac<F> pc = p;                       // a copy: `p` itself must not escape by reference (it would live in memory)
         Jac<F> d = jac_double_cold(pc);
