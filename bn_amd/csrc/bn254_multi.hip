@@ -65,7 +65,10 @@ int run_slot(const MapJob &j, int w) {
 }
 
 void plan(size_t n, size_t &chunk, int &nslots) {
-    size_t c = 65536;
+    // as few chunks as possible with none above 2^16, all of (nearly) the same size: a ragged tail of a few pairings would cost a
+    // whole kernel latency (one wave takes as long as a full machine)
+    const size_t nchunks = (n + 65535) / 65536;
+    size_t c = ((n + nchunks - 1) / nchunks + 31) / 32 * 32;
     const char *e = getenv("BN254_PIPELINE_CHUNK");                                // experiments
     if (e && atol(e) > 0) c = (size_t)atol(e);
     chunk = c;
