@@ -445,6 +445,14 @@ def test_host_buffer_pipeline_matches_device_path(oracle):
     assert np.array_equal(got, ref.cpu().numpy().view(np.uint64))
     idx = np.random.default_rng(7).choice(n, 256, replace=False)
     assert np.array_equal(got[idx], oracle.pairing_batch(Pn[idx], Qn[idx]))
+    # just above one chunk: two equal chunks on the two streams (no ragged one-wave tail launch); result buffer supplied
+    n2 = 65536 + 40
+    P2, Q2 = D.synthetic_points(te, 70000, 70000 + n2)
+    ref2 = te.pairing_batch(P2, Q2)
+    torch.cuda.synchronize()
+    out2 = np.zeros((n2, 48), np.uint64)
+    assert e.pairing_batch(P2.cpu().numpy().view(np.uint64), Q2.cpu().numpy().view(np.uint64), out2) is out2
+    assert np.array_equal(out2, ref2.cpu().numpy().view(np.uint64))
     k = D.synthetic_scalars(100, 100 + n, 1)
     m1 = e.g1_mul_batch(Pn, k)
     assert np.array_equal(m1, te.g1_mul(P, torch.from_numpy(k.view(np.int64)).to(dev)).cpu().numpy().view(np.uint64))
