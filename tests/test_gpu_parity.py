@@ -673,3 +673,23 @@ int main() {
     assert np.array_equal(got[5], oracle.pairing_product(P, Q))
     assert np.array_equal(got[6], oracle.fq12_one())
     assert lines[7].strip() == "0"                     # two ranks on one device: peer-copy exchange, not RCCL
+
+
+def test_config3_whole_2_20_on_one_gpu(oracle):
+    """BASELINE.json configs[2] in full on ONE GPU: 2^20 independent pairings in one call - a 4096-index sample against the oracle
+    and the eight 2^17 shards an 8-GPU run would compute (separate launches) concatenate to the same bytes"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    te = D.TorchEngine(bn_amd.Engine(0), dev)
+    n = 1 << 20
+    P, Q = D.synthetic_points(te, 0, n)
+    out = te.pairing_batch(P, Q)
+    for g in (0, 5, 7):                                        # three of the eight shards, as rank g would run them
+        lo, hi = D.shard_range(n, g, 8)
+        assert torch.equal(te.pairing_batch(P[lo:hi].contiguous(), Q[lo:hi].contiguous()), out[lo:hi])
+    torch.cuda.synchronize()
+    idx = np.sort(np.random.default_rng(13).choice(n, 4096, replace=False))
+    Pn = P.cpu().numpy().view(np.uint64)[idx]; Qn = Q.cpu().numpy().view(np.uint64)[idx]
+    assert np.array_equal(out.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn, Qn))
