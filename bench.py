@@ -344,7 +344,10 @@ def main():
                          scaling, workload, {"roofline": rf},
                          {"pairings_per_gpu": n, "inputs": "r*G1 / s*G2 (Jacobian, z != 1) resident in HBM", "parallelism": f"dp{world} (sharded, no collective)",
                           "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
-                          "mapping": 1 if args.mapping is None else args.mapping})
+                          "mapping": 1 if args.mapping is None else args.mapping,
+                          # 2^16 pairings are exactly two waves on each of 1024 SIMDs: a box that exposes fewer than 256 CUs runs the
+                          # remainder in a second round (one box of round 2 ran every 2048-wave kernel 33-100 % slower)
+                          "cus": torch.cuda.get_device_properties(dev).multi_processor_count})
             if world == 1:
                 Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
                 if not args.no_host_api:
