@@ -180,6 +180,9 @@ struct MillerStateLds {
     __device__ __forceinline__ G2Aff<F2> get_base() const { return {{ld_fe(3)}, {ld_fe(4)}}; }
     __device__ __forceinline__ void put_p(const G1Aff<Fe> &v) const { st_fe(5, v.x); st_fe(6, v.y); }
     __device__ __forceinline__ G1Aff<Fe> get_p() const { return {ld_fe(5), ld_fe(6)}; }
+    // a line waits in R's slots while R itself is in registers (miller_loop_naf_merged)
+    __device__ __forceinline__ void park_line(const F2 &a, const F2 &b, const F2 &c) const { st_fe(0, a.v); st_fe(1, b.v); st_fe(2, c.v); }
+    __device__ __forceinline__ void unpark_line(F2 &a, F2 &b, F2 &c) const { a.v = ld_fe(0); b.v = ld_fe(1); c.v = ld_fe(2); }
 };
 
 #ifdef BN_STAMP   // experiment: per-wave start/end wall-clock stamps (100 MHz) + XCC id, read back with bn254_debug_stamps
@@ -211,7 +214,13 @@ __device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t
                       f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32), p, q);
     __shared__ uint32_t park[PARK_DWORDS * BLOCK];
     MillerStateLds st = {park + threadIdx.x};
-    Fq12<F2> f = miller_loop_sched<NAF>(p, q, st);
+    Fq12<F2> f;
+#ifdef BN_MILLER_MERGE_LINES
+    if constexpr (NAF) f = miller_loop_naf_merged(p, q, st);
+    else f = miller_loop_sched<NAF>(p, q, st);
+#else
+    f = miller_loop_sched<NAF>(p, q, st);
+#endif
     Fq12<F2> one = f12_one<F2>();
     f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
     f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);

@@ -510,7 +510,7 @@ BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
     BN_COUNT(mul2);
     BN_REQUIRE(!a.sg && !u.sg && !c.sg && !v.sg, "fe_mul2 on a signed lazy value");
     BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 6, "fe_mul2 column overflow");
-    BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 169, "fe_mul2 value bound");
+    BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 338, "fe_mul2 value bound");           // <= 169: result < 2q;  <= 338: result < 3q
     uint64_t acc = 0;
     uint32_t m[9];
     Fe r;
@@ -540,7 +540,7 @@ BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
         acc >>= 29;
     }
     r.l[8] = (uint32_t)acc;
-    BN_SETB(r, 1, 2);
+    BN_SETB(r, 1, (a.vb * u.vb + c.vb * v.vb <= 169 ? 2 : 3));
     BN_VERIFY(r, "fe_mul2");
     return r;
 }

@@ -92,6 +92,10 @@ struct MillerStateVars {
     BN_FN G2Aff<F2> get_base() const { return base_; }
     BN_FN void put_p(const G1Aff<S> &v) { p_ = v; }
     BN_FN G1Aff<S> get_p() const { return p_; }
+    // three Fq2 values kept while the running point is in registers (the LDS store reuses R's slots for them)
+    F2 line_[3];
+    BN_FN void park_line(const F2 &a, const F2 &b, const F2 &c) { line_[0] = a; line_[1] = b; line_[2] = c; }
+    BN_FN void unpark_line(F2 &a, F2 &b, F2 &c) const { a = line_[0]; b = line_[1]; c = line_[2]; }
 };
 
 // groups/mod.rs:486-519 fused with :557-588.  The schedule (6u+2 with the top bit skipped: 64 doublings, an addition of Q
@@ -156,6 +160,73 @@ BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, St
             // control flow costs the register allocation of the whole loop more than the 0.5 % of multiplications it saves)
             f = apply_line(f, l, st.get_p());
         }
+    }
+    return f;
+}
+// The NAF schedule with the two lines of a step that adds +-Q multiplied together BEFORE they meet f:
+//     f <- f^2 * l_dbl * l_add  =  f^2 * (l_dbl l_add):   6 (line x line) + 17 (f x five-slot element) instead of 13 + 13 Fq2 products
+// on the 21 steps with a non-zero digit.  The doubling line waits in the store while the addition step runs (in the LDS store it
+// takes R's slots: R is in registers then).  Same value as miller_loop_sched<true> up to the order of Fq12 products, i.e. identical.
+// MEASURED SLOWER and therefore off by default (-DBN_MILLER_MERGE_LINES): 2.4 % fewer multiply-adds, but f (54 VGPRs) must wait in
+// registers through the addition step AND the line product, the allocator spills ~100 VGPRs of it (3 without the merge), and the
+// Miller kernel runs 3.98 -> 4.07 ms (profiles/r02x_ab_merge_lines.txt).  LDS has 17 spare dwords per lane, a half of f is 27.
+template <class F2, class S, class Store>
+BN_FN Fq12<F2> miller_loop_naf_merged(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, Store &st) {
+    {
+        const S t2 = f2_scalar_const(F2P, k::ISO_T2), t3 = f2_scalar_const(F2P, k::ISO_T3);      // isomorphic curve (doubling_step<true>)
+        G1Aff<S> p = {fe_mul(p_in.x, t2), fe_mul(p_in.y, t3)};
+        G2Aff<F2> q = {f2_scale(q_in.x, t2), f2_scale(q_in.y, t3)};
+        G2Proj<F2> r0 = {q.x, q.y, f2_one(F2P)};
+        st.put_r(r0);
+        st.put_base(q);
+        st.put_p(p);
+    }
+    Fq12<F2> f = f12_one<F2>();
+    constexpr int ND = k::ATE_NAF_LEN - 1;
+#pragma unroll 1
+    for (int j = 0; j < ND; ++j) {
+        const int digit = k::ATE_NAF[ND - 1 - j];
+        BN_MILLER_HOOK(2 * j, 2 * (ND + 2));
+        if (j != 0) f = f12_sqr(f);
+        BN_COMPILER_FENCE();
+        G2Proj<F2> r = st.get_r();
+        F2 x0, x4, x2;
+        {
+            Line<F2> l = doubling_step<true>(r);
+            const G1Aff<S> pp = st.get_p();
+            x0 = l.ell_0; x4 = f2_scale(l.ell_vw, pp.y); x2 = f2_scale(l.ell_vv, pp.x);
+        }
+        if (digit == 0) {
+            st.put_r(r);
+            f = f12_mul_by_024(f, x0, x4, x2);
+        } else {
+            BN_MILLER_HOOK(2 * j + 1, 2 * (ND + 2));
+            st.park_line(x0, x4, x2);                                // the doubling line waits in R's slots (R is in registers now)
+            G2Aff<F2> b = st.get_base();
+            if (digit < 0) b.y = f2_neg(b.y);
+            F2 y0, y4, y2;
+            {
+                Line<F2> l = addition_step(r, b);
+                const G1Aff<S> pp = st.get_p();
+                y0 = l.ell_0; y4 = f2_scale(l.ell_vw, pp.y); y2 = f2_scale(l.ell_vv, pp.x);
+            }
+            st.unpark_line(x0, x4, x2);
+            st.put_r(r);
+            const LinePair<F2> lp = f12_line_product(x0, x4, x2, y0, y4, y2);
+            f = f12_mul_by_01234(f, lp);
+        }
+    }
+    // the two additions of pi(Q) and -pi^2(Q) (groups/mod.rs:578-582), one line at a time
+#pragma unroll 1
+    for (int j = ND; j < ND + 2; ++j) {
+        BN_MILLER_HOOK(2 * j + 1, 2 * (ND + 2));
+        G2Aff<F2> b = mul_by_q(st.get_base());
+        if (j == ND + 1) b.y = f2_neg(b.y);
+        st.put_base(b);
+        G2Proj<F2> r = st.get_r();
+        Line<F2> l = addition_step(r, b);
+        st.put_r(r);
+        f = apply_line(f, l, st.get_p());
     }
     return f;
 }
