@@ -297,8 +297,10 @@ int bn254_ctx_create(int device, bn254_ctx **out) {
     if (!out) return BN254_E_BAD_ARG;
     int n = bn254_device_count();
     if (n <= 0 || device < 0 || device >= n) return BN254_E_NO_DEVICE;
+    BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(device));
-    bn254_ctx *c = new bn254_ctx();
+    bn254_ctx *c = new (std::nothrow) bn254_ctx();
+    if (!c) return BN254_E_ALLOC;
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return (int)e; }
@@ -311,6 +313,7 @@ void bn254_ctx_destroy(bn254_ctx *c) {
         std::lock_guard<std::mutex> lk(g_default_mu);          // a default context handed out by bn_get_ctx must not dangle
         for (auto &d : g_default) if (d == c) d = nullptr;
     }
+    BnDeviceGuard dev_guard;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (auto &r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -332,6 +335,7 @@ const char *bn254_error_string(int code) {
         case BN254_E_BAD_ARG: return "bad argument";
         case BN254_E_ALLOC: return "device allocation failed";
         case BN254_E_COMM: return "RCCL / peer exchange failed";
+        case BN254_E_INTERNAL: return "internal error (C++ exception stopped at the C boundary)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -347,6 +351,7 @@ int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;                                     \
     if (n == 0) return BN254_OK;                                                     \
     if ((null_check) || n > (limit)) return BN254_E_BAD_ARG;                         \
+    BnDeviceGuard dev_guard;                                                         \
     HIP_TRY(hipSetDevice(ctx->device));                                              \
     hipStream_t s = (hipStream_t)stream
 
@@ -369,6 +374,7 @@ int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, vo
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;
     if (!d_out || (n && !d_in) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {       // empty product = one
@@ -386,6 +392,7 @@ int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, s
     int rc = bn_get_ctx(ctx); if (rc) return rc;
     if (!d_partial || (n && (!d_p || !d_q)) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     if (n == 0) return bn254_gt_product_dev(ctx, nullptr, 0, d_partial, stream);
+    BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
@@ -437,13 +444,14 @@ int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, siz
 #define BN_HOST_PROLOGUE()                                                           \
     int rc = bn_get_ctx(ctx); if (rc) return rc;                                     \
     std::lock_guard<std::mutex> host_lock(ctx->mu);                                  \
+    BnDeviceGuard dev_guard;                                                         \
     HIP_TRY(hipSetDevice(ctx->device))
 
 int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
     if (n == 0) return BN254_OK;
     if (!p || !q || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     BN_HOST_PROLOGUE();
-    return bn_pairing_batch_pipelined(ctx, p, q, out, n);
+    return bn_no_throw([&] { return bn_pairing_batch_pipelined(ctx, p, q, out, n); });
 }
 int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
     if (!out || (n && (!p || !q)) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
@@ -465,13 +473,13 @@ int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *ou
     if (n == 0) return BN254_OK;
     if (!p || !k || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     BN_HOST_PROLOGUE();
-    return bn_mul_batch_pipelined(ctx, 1, p, k, out, n);
+    return bn_no_throw([&] { return bn_mul_batch_pipelined(ctx, 1, p, k, out, n); });
 }
 int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n) {
     if (n == 0) return BN254_OK;
     if (!p || !k || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     BN_HOST_PROLOGUE();
-    return bn_mul_batch_pipelined(ctx, 2, p, k, out, n);
+    return bn_no_throw([&] { return bn_mul_batch_pipelined(ctx, 2, p, k, out, n); });
 }
 int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, size_t n) {
     if (n == 0) return BN254_OK;

@@ -170,7 +170,22 @@ struct bn254_multi {
 
 extern "C" {
 
+static int multi_create(const int *devices, int ndev, bn254_multi **out);
+static int pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n);
+static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out);
 int bn254_multi_create(const int *devices, int ndev, bn254_multi **out) {
+    BnDeviceGuard dev_guard;
+    return bn_no_throw([&] { return multi_create(devices, ndev, out); });
+}
+int bn254_pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
+    BnDeviceGuard dev_guard;
+    return bn_no_throw([&] { return pairing_batch_multi(m, p, q, out, n); });
+}
+int bn254_pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
+    BnDeviceGuard dev_guard;
+    return bn_no_throw([&] { return pairing_product_multi(m, p, q, n, out); });
+}
+static int multi_create(const int *devices, int ndev, bn254_multi **out) {
     if (!out || ndev <= 0 || ndev > 64) return BN254_E_BAD_ARG;
     const int have = bn254_device_count();
     if (have <= 0) return BN254_E_NO_DEVICE;
@@ -211,6 +226,7 @@ int bn254_multi_create(const int *devices, int ndev, bn254_multi **out) {
 }
 void bn254_multi_destroy(bn254_multi *m) {
     if (!m) return;
+    BnDeviceGuard dev_guard;
     if (!m->comms.empty()) for (auto c : m->comms) if (c) rccl().CommDestroy(c);
     for (size_t g = 0; g < m->devices.size(); ++g) {
         hipSetDevice(m->devices[g]);
@@ -225,7 +241,7 @@ int bn254_multi_exchange_kind(const bn254_multi *m) { return m ? m->exchange : B
 bn254_ctx *bn254_multi_ctx(bn254_multi *m, int rank) { return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[rank] : nullptr; }
 
 // contiguous shards lo = n*g/G .. n*(g+1)/G (the rule of bn_amd.distributed.shard_range); no exchange
-int bn254_pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
+static int pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
     if (!m) return BN254_E_BAD_ARG;
     if (n == 0) return BN254_OK;
     if (!p || !q || !out) return BN254_E_BAD_ARG;
@@ -244,7 +260,7 @@ int bn254_pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn
     return BN254_OK;
 }
 
-int bn254_pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
+static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
     if (!m || !out || (n && (!p || !q))) return BN254_E_BAD_ARG;
     std::lock_guard<std::mutex> lk(m->mu);
     const size_t G = m->ctx.size();
@@ -392,6 +408,7 @@ int bn254_ubench_mac32(bn254_ctx *ctx, int waves_per_simd, int iters, double *gm
     int rc = bn_get_ctx(ctx); if (rc) return rc;
     if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !gmac_per_s) return BN254_E_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));

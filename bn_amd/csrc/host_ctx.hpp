@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <new>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,6 +24,18 @@
         hipError_t e__ = (expr);                  \
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
+
+// restores the calling thread's current HIP device when an entry point returns (the library switches to the context's device)
+struct BnDeviceGuard {
+    int prev = -1;
+    BnDeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~BnDeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+// nothing may unwind across the C ABI: entry points that create threads / containers run their body through this
+template <class Fn>
+int bn_no_throw(Fn &&fn) {
+    try { return fn(); } catch (const std::bad_alloc &) { return BN254_E_ALLOC; } catch (...) { return BN254_E_INTERNAL; }
+}
 
 constexpr int BN_MAX_SLOTS = 4;            // chunks in flight in the pipelined host-buffer path (2 used; the rest for experiments)
 

@@ -71,7 +71,8 @@ enum {
     BN254_E_NO_DEVICE = -1,     /* no HIP device / device index out of range */
     BN254_E_BAD_ARG = -2,       /* null pointer with n > 0, n too large */
     BN254_E_ALLOC = -3,         /* device allocation failed */
-    BN254_E_COMM = -4           /* RCCL / peer exchange of the multi-device product failed */
+    BN254_E_COMM = -4,          /* RCCL / peer exchange of the multi-device product failed */
+    BN254_E_INTERNAL = -5       /* an unexpected C++ exception was stopped at the boundary (nothing unwinds across it) */
     /* positive values are hipError_t codes */
 };
 
