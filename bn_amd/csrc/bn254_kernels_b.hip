@@ -239,15 +239,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     miller_B_body<true>(g1, g2, f_out, n);
 }
 
-// Table of odd powers of the windowed exponentiation (pairing.hpp ExpTableVars) in global memory: slot-major, then the 54
-// dwords of this lane's half of an Fq12, then the lane - every access of a wave is one coalesced 256-byte row.
+// Table of the exponentiation machine (pairing.hpp ExpTableVars) in global memory.  One Fq6 half of a slot is 27 dwords per lane,
+// stored as 7 groups of 4 dwords (one pad dword): group-major, then the lane - every access of a wave is ONE global_load/store_dwordx4
+// over 1 KB of contiguous memory (a dword-per-instruction layout costs 27 memory instructions per half; at two waves per SIMD every
+// memory instruction costs the SIMD ~40 cycles, measured on the spills of the Miller kernel).
+#ifdef BN_EXP_TABLE_DWORD            // experiment switch: the round-1 layout, one dword per instruction
 struct ExpTableMem {
     uint32_t *table;         // wave-uniform base (SGPRs)
     uint32_t lane;           // this lane's column
     uint32_t stride;         // lanes in the launch
-    __device__ __forceinline__ uint32_t *row(int slot, int half) const {          // uniform: scalar address arithmetic
-        return table + (size_t)(uint32_t)((slot * 2 + half) * 27) * stride;
-    }
+    __device__ __forceinline__ uint32_t *row(int slot, int half) const { return table + (size_t)(uint32_t)((slot * 2 + half) * 27) * stride; }
     __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
         uint32_t *p = row(slot, half);
 #pragma unroll
@@ -273,6 +274,40 @@ struct ExpTableMem {
     __device__ __forceinline__ Fq6<F2> c1(int i) const { return ld6(i, 1); }
 };
 constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 54;
+#else
+struct ExpTableMem {
+    uint4 *table;            // wave-uniform base (SGPRs)
+    uint32_t lane;           // this lane's column
+    uint32_t stride;         // lanes in the launch
+    __device__ __forceinline__ uint4 *row(int slot, int half) const { return table + (size_t)(uint32_t)((slot * 2 + half) * 7) * stride; }
+    __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
+        uint4 *p = row(slot, half);
+        uint32_t w[28];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { w[i] = v.c0.v.l[i]; w[9 + i] = v.c1.v.l[i]; w[18 + i] = v.c2.v.l[i]; }
+        w[27] = 0;
+#pragma unroll
+        for (int g = 0; g < 7; ++g) (p + (size_t)g * stride)[lane] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+    }
+    __device__ __forceinline__ Fq6<F2> ld6(int slot, int half) const {
+        const uint4 *p = row(slot, half);
+        uint32_t w[28];
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+            const uint4 x = (p + (size_t)g * stride)[lane];
+            w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w;
+        }
+        Fq6<F2> v;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { v.c0.v.l[i] = w[i]; v.c1.v.l[i] = w[9 + i]; v.c2.v.l[i] = w[18 + i]; }
+        return v;
+    }
+    __device__ __forceinline__ void put(int i, const Fq12<F2> &v) const { st6(i, 0, v.c0); st6(i, 1, v.c1); }
+    __device__ __forceinline__ Fq6<F2> c0(int i) const { return ld6(i, 0); }
+    __device__ __forceinline__ Fq6<F2> c1(int i) const { return ld6(i, 1); }
+};
+constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 2 * 7 * 4;
+#endif
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n, uint32_t *table) {
     BN_KERNEL_PROLOGUE();
@@ -281,7 +316,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
+#ifdef BN_EXP_TABLE_DWORD
     ExpTableMem tbl = {table, t, gridDim.x * BLOCK};
+#else
+    ExpTableMem tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
+#endif
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair), tbl);
     if (live) f12_store(f, out + 96u * pair);
     BN_STAMP_END();
