@@ -693,3 +693,23 @@ def test_config3_whole_2_20_on_one_gpu(oracle):
     idx = np.sort(np.random.default_rng(13).choice(n, 4096, replace=False))
     Pn = P.cpu().numpy().view(np.uint64)[idx]; Qn = Q.cpu().numpy().view(np.uint64)[idx]
     assert np.array_equal(out.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn, Qn))
+
+
+def test_full_size_bilinearity_on_gpu():
+    """groups/mod.rs:798-823 (test_binlinearity) at BASELINE size, entirely on the GPU and with no oracle in the loop: for 2^16 random
+    (P, Q, s): e(sP, Q) == e(P, sQ) == e(P, Q)^s - three independent kernels (GLV G1 multiplication, windowed G2 multiplication,
+    windowed Gt::pow) must agree with the pairing kernels on every one of the 2^16 results, byte for byte"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    te = D.TorchEngine(bn_amd.Engine(0), dev)
+    n = 1 << 16
+    P, Q = D.synthetic_points(te, 1 << 21, (1 << 21) + n)
+    s = D.synthetic_scalars_device(te, 1 << 25, (1 << 25) + n, 0)
+    sP = te.g1_mul(P, s); sQ = te.g2_mul(Q, s)
+    a = te.pairing_batch(sP, Q); b = te.pairing_batch(P, sQ); c = te.gt_pow(te.pairing_batch(P, Q), s)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    one = torch.zeros(48, dtype=torch.int64, device=dev)
+    assert not bool((a == a[0]).all())                          # not a constant output
