@@ -450,7 +450,9 @@ int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, siz
 int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
     if (n == 0) return BN254_OK;
     if (!p || !q || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    BN_HOST_PROLOGUE();
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    BnDeviceGuard dev_guard;                 // concurrency is arbitrated per pipeline slot (BnSlotLease), not by the context mutex
+    HIP_TRY(hipSetDevice(ctx->device));
     return bn_no_throw([&] { return bn_pairing_batch_pipelined(ctx, p, q, out, n); });
 }
 int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
@@ -472,13 +474,17 @@ int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t
 int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n) {
     if (n == 0) return BN254_OK;
     if (!p || !k || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    BN_HOST_PROLOGUE();
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    BnDeviceGuard dev_guard;                 // concurrency is arbitrated per pipeline slot (BnSlotLease), not by the context mutex
+    HIP_TRY(hipSetDevice(ctx->device));
     return bn_no_throw([&] { return bn_mul_batch_pipelined(ctx, 1, p, k, out, n); });
 }
 int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n) {
     if (n == 0) return BN254_OK;
     if (!p || !k || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    BN_HOST_PROLOGUE();
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    BnDeviceGuard dev_guard;                 // concurrency is arbitrated per pipeline slot (BnSlotLease), not by the context mutex
+    HIP_TRY(hipSetDevice(ctx->device));
     return bn_no_throw([&] { return bn_mul_batch_pipelined(ctx, 2, p, k, out, n); });
 }
 int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, size_t n) {

@@ -42,9 +42,10 @@ struct MapJob {
     std::function<int(BnSlot &, size_t)> launch;      // enqueue the kernels of one chunk on slot.stream (d_in -> d_out)
 };
 
-int run_slot(const MapJob &j, int w) {
+// worker `w` of `j.nslots` handles chunks w, w + nslots, ... on pipeline slot `slot_index`
+int run_slot(const MapJob &j, int w, int slot_index) {
     bn254_ctx *c = j.ctx;
-    BnSlot &s = c->slot[w];
+    BnSlot &s = c->slot[slot_index];
     HIP_TRY(hipSetDevice(c->device));
     if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     for (size_t ci = (size_t)w; ci * j.chunk < j.n; ci += (size_t)j.nslots) {
@@ -80,11 +81,15 @@ void plan(size_t n, size_t &chunk, int &nslots) {
 
 int run_map(MapJob &j) {
     plan(j.n, j.chunk, j.nslots);
-    if (j.nslots <= 1) return run_slot(j, 0);
+    if (j.nslots <= 1) {                                      // one chunk: one slot, on the calling thread; a second caller overlaps
+        BnSlotLease lease(j.ctx, false);
+        return run_slot(j, 0, lease.first);
+    }
+    BnSlotLease lease(j.ctx, true);
     std::vector<int> rcs(j.nslots, BN254_OK);
     std::vector<std::thread> th;
-    for (int w = 1; w < j.nslots; ++w) th.emplace_back([&, w] { rcs[w] = run_slot(j, w); });
-    rcs[0] = run_slot(j, 0);
+    for (int w = 1; w < j.nslots; ++w) th.emplace_back([&, w] { rcs[w] = run_slot(j, w, w); });
+    rcs[0] = run_slot(j, 0, 0);
     for (auto &t : th) t.join();
     for (int rc : rcs) if (rc) return rc;
     return BN254_OK;
@@ -92,7 +97,7 @@ int run_map(MapJob &j) {
 
 }  // namespace
 
-// callers hold ctx->mu
+// thread-safe by slot leases (no context mutex): up to two single-chunk callers run concurrently
 int bn_pairing_batch_pipelined(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
     MapJob j;
     j.ctx = ctx; j.n = n;

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <map>
 #include <new>
 #include <mutex>
@@ -79,11 +80,40 @@ struct bn254_ctx {
     bool scratch_used = false;
     BnBuf stage[3];                     // device staging of the small host-buffer entry points
     BnSlot slot[BN_MAX_SLOTS];          // pipelined path (bn254_multi.hip)
+    // leases of those slots: a batch of up to one chunk takes ONE of the first two (two callers overlap on the GPU - the number
+    // of streams the hardware overlaps without loss), a multi-chunk batch takes all of them
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    unsigned slot_busy = 0;             // bit i: slot i is leased
+    int slot_waiting_all = 0;           // callers waiting for every slot (new single leases queue behind them)
     bool profile = false;
     std::mutex prof_mu;                 // recs / folded (worker threads of the pipelined path launch concurrently)
     struct Rec { std::string name; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::map<std::string, std::pair<double, uint64_t>> folded;     // totals of records already consumed (events recycled)
+};
+
+// lease of pipeline slots for one host-buffer call (see bn254_ctx::slot_busy)
+struct BnSlotLease {
+    bn254_ctx *c; unsigned mask; int first;
+    BnSlotLease(bn254_ctx *c_, bool all) : c(c_), mask(0), first(0) {
+        std::unique_lock<std::mutex> lk(c->slot_mu);
+        if (all) {
+            ++c->slot_waiting_all;
+            c->slot_cv.wait(lk, [&] { return c->slot_busy == 0; });
+            --c->slot_waiting_all;
+            mask = (1u << BN_MAX_SLOTS) - 1;
+        } else {
+            c->slot_cv.wait(lk, [&] { return c->slot_waiting_all == 0 && (c->slot_busy & 3u) != 3u; });
+            first = (c->slot_busy & 1u) ? 1 : 0;
+            mask = 1u << first;
+        }
+        c->slot_busy |= mask;
+    }
+    ~BnSlotLease() {
+        { std::lock_guard<std::mutex> lk(c->slot_mu); c->slot_busy &= ~mask; }
+        c->slot_cv.notify_all();
+    }
 };
 
 // brackets one kernel launch with events when profiling is on

@@ -38,8 +38,10 @@
  *
  * Threading (the reference's `pairing` is a pure function and its types are Send + Sync, lib.rs:55-61):
  *   - every HOST-BUFFER entry point is safe to call from any number of threads on the same context, including ctx == NULL
- *     (a process-wide default context per HIP device): a context serialises its callers internally for the whole call;
- *     use one context per calling thread (or bn254_multi_*) when the calls should overlap instead;
+ *     (a process-wide default context per HIP device).  bn254_pairing_batch and bn254_g{1,2}_mul_batch arbitrate per pipeline
+ *     slot: two callers with batches of up to 2^16 run concurrently on two streams (the number of streams the GPU overlaps
+ *     without loss), further callers and multi-chunk batches queue; every other entry point serialises its callers on the
+ *     context.  Use one context per thread (or bn254_multi_*) for more overlap;
  *   - the *_dev entry points are asynchronous on the caller's stream.  Context-owned scratch (the final-exponentiation table,
  *     the product workspace) is ordered across streams with events, so calls on different streams of one context are safe
  *     and serialise on that scratch; the caller still owns the ordering of its OWN buffers between streams.
