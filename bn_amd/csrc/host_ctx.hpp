@@ -2,9 +2,10 @@
 // entry points; bn254_multi.hip: pipelined host-buffer path, multi-device fan-out, RCCL exchange).  Not part of the ABI.
 //
 // Concurrency contract (what the header promises and these structures implement):
-//   * every HOST-BUFFER entry point locks its context for the whole call, so any number of host threads may call into one
-//     context - including the process-wide default contexts behind ctx == NULL (one per HIP device) - and get the
-//     reference's re-entrant behaviour (`pairing` is a pure function, `Group: Send + Sync`, src/lib.rs:55-61);
+//   * any number of host threads may call the HOST-BUFFER entry points of one context - including the process-wide default
+//     contexts behind ctx == NULL (one per HIP device) - and get the reference's re-entrant behaviour (`pairing` is a pure
+//     function, `Group: Send + Sync`, src/lib.rs:55-61): the batch entry points (pairing_batch, g*_mul_batch) lease one of two
+//     pipeline slots per call (own stream, staging and table; multi-chunk batches lease all slots), the others lock the context;
 //   * the asynchronous *_dev entry points share context-owned scratch (final-exponentiation table, product workspace).
 //     Each use is bracketed by an event: a launch on another stream first waits for the previous user's event, so two
 //     streams on one context serialise on the scratch instead of racing on it.
