@@ -32,6 +32,10 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_g2_encode_batch": [_VP, _VP, _VP, _SZ],
     "bn254_g1_decode_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_g2_decode_batch": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_g1_encode_stream": [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)],
+    "bn254_g2_encode_stream": [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(_SZ)],
+    "bn254_g1_decode_stream": [_VP, _VP, _SZ, _VP, _VP, _SZ, C.POINTER(_SZ), C.POINTER(_SZ)],
+    "bn254_g2_decode_stream": [_VP, _VP, _SZ, _VP, _VP, _SZ, C.POINTER(_SZ), C.POINTER(_SZ)],
     "bn254_g2_precompute": [_VP, _VP, _VP, _SZ],
     "bn254_pairing_prepared_batch": [_VP, _VP, _VP, C.c_int, _VP, _SZ],
     "bn254_g2_precompute_dev": [_VP, _VP, _VP, _SZ, _VP],

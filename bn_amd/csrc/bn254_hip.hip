@@ -547,6 +547,56 @@ int bn254_g1_encode_batch(bn254_ctx *ctx, const bn_g1 *p, uint8_t *out, size_t n
 int bn254_g2_encode_batch(bn254_ctx *ctx, const bn_g2 *p, uint8_t *out, size_t n) { return wire_host(ctx, 2, 0, p, out, nullptr, n); }
 int bn254_g1_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g1 *out, int32_t *status, size_t n) { return wire_host(ctx, 1, 1, in, out, status, n); }
 int bn254_g2_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g2 *out, int32_t *status, size_t n) { return wire_host(ctx, 2, 1, in, out, status, n); }
+// ---- the crate's actual byte STREAM (groups/mod.rs:143-205): a point at infinity is the lone byte 0, a finite point is 4 followed by
+// its coordinates - records of variable length.  The stream is cut into records on the host (a tag decides the length), the fixed
+// records go through the batch kernels above.
+static int stream_encode(bn254_ctx *ctx, int g, const void *p, size_t n, uint8_t *out, size_t cap, size_t *written) {
+    if (!written || (n && (!p || !out))) return BN254_E_BAD_ARG;
+    const size_t rs = g == 1 ? BN254_G1_WIRE_BYTES : BN254_G2_WIRE_BYTES;
+    return bn_no_throw([&]() -> int {
+        std::vector<uint8_t> fixed(n * rs);
+        int rc = g == 1 ? bn254_g1_encode_batch(ctx, (const bn_g1 *)p, fixed.data(), n) : bn254_g2_encode_batch(ctx, (const bn_g2 *)p, fixed.data(), n);
+        if (rc) return rc;
+        size_t w = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const uint8_t *r = fixed.data() + i * rs;
+            const size_t len = r[0] == 0 ? 1 : rs;
+            if (w + len > cap) return BN254_E_BAD_ARG;
+            memcpy(out + w, r, len);
+            w += len;
+        }
+        *written = w;
+        return BN254_OK;
+    });
+}
+static int stream_decode(bn254_ctx *ctx, int g, const uint8_t *in, size_t len, void *out, int32_t *status, size_t max_points, size_t *count, size_t *consumed) {
+    if (!count || !consumed || (len && !in) || (max_points && (!out || !status))) return BN254_E_BAD_ARG;
+    const size_t rs = g == 1 ? BN254_G1_WIRE_BYTES : BN254_G2_WIRE_BYTES;
+    return bn_no_throw([&]() -> int {
+        std::vector<uint8_t> fixed;
+        size_t pos = 0, n = 0;
+        while (pos < len && n < max_points) {
+            // tag 0: one byte; tag 4: a full record; any other tag is the crate's "invalid leading byte" - it consumes the byte it read
+            const size_t rec = in[pos] == 4 ? rs : 1;
+            if (pos + rec > len) break;                         // truncated record: stop in front of it
+            fixed.resize((n + 1) * rs, 0);
+            memcpy(fixed.data() + n * rs, in + pos, rec);
+            pos += rec; ++n;
+        }
+        int rc = g == 1 ? bn254_g1_decode_batch(ctx, fixed.data(), (bn_g1 *)out, status, n) : bn254_g2_decode_batch(ctx, fixed.data(), (bn_g2 *)out, status, n);
+        if (rc) return rc;
+        *count = n; *consumed = pos;
+        return BN254_OK;
+    });
+}
+int bn254_g1_encode_stream(bn254_ctx *ctx, const bn_g1 *p, size_t n, uint8_t *out, size_t cap, size_t *written) { return stream_encode(ctx, 1, p, n, out, cap, written); }
+int bn254_g2_encode_stream(bn254_ctx *ctx, const bn_g2 *p, size_t n, uint8_t *out, size_t cap, size_t *written) { return stream_encode(ctx, 2, p, n, out, cap, written); }
+int bn254_g1_decode_stream(bn254_ctx *ctx, const uint8_t *in, size_t len, bn_g1 *out, int32_t *status, size_t max_points, size_t *count, size_t *consumed) {
+    return stream_decode(ctx, 1, in, len, out, status, max_points, count, consumed);
+}
+int bn254_g2_decode_stream(bn254_ctx *ctx, const uint8_t *in, size_t len, bn_g2 *out, int32_t *status, size_t max_points, size_t *count, size_t *consumed) {
+    return stream_decode(ctx, 2, in, len, out, status, max_points, count, consumed);
+}
 // G + G / G - G on host buffers
 static int add_host(bn254_ctx *ctx, int g, const void *a, const void *b, void *out, size_t n, int negate_b) {
     if (n == 0) return BN254_OK;

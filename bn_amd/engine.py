@@ -149,6 +149,32 @@ class Engine:
         out = np.empty((n, G2_WORDS), np.uint64); st = np.empty(n, np.int32)
         _native.check(self._lib.bn254_g2_decode_batch(self._h, _p(b), _p(out), _p(st), n)); return out, st
 
+    # ---- the crate's variable-length byte stream (infinity = the lone byte 0)
+    def _encode_stream(self, fn, p, rec):
+        out = np.empty(p.shape[0] * rec, np.uint8); w = C.c_size_t()
+        _native.check(fn(self._h, _p(p), p.shape[0], _p(out), out.size, C.byref(w)))
+        return out[:w.value].copy()
+
+    def g1_encode_stream(self, p):
+        return self._encode_stream(self._lib.bn254_g1_encode_stream, _arr(p, G1_WORDS), 65)
+
+    def g2_encode_stream(self, p):
+        return self._encode_stream(self._lib.bn254_g2_encode_stream, _arr(p, G2_WORDS), 129)
+
+    def _decode_stream(self, fn, b, words, max_points):
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1)
+        cap = b.size if max_points is None else int(max_points)
+        out = np.zeros((max(cap, 1), words), np.uint64); st = np.zeros(max(cap, 1), np.int32); cnt = C.c_size_t(); used = C.c_size_t()
+        _native.check(fn(self._h, _p(b), b.size, _p(out), _p(st), cap, C.byref(cnt), C.byref(used)))
+        return out[:cnt.value], st[:cnt.value], used.value
+
+    def g1_decode_stream(self, b, max_points=None):
+        """bytes -> (points, status, bytes consumed)"""
+        return self._decode_stream(self._lib.bn254_g1_decode_stream, b, G1_WORDS, max_points)
+
+    def g2_decode_stream(self, b, max_points=None):
+        return self._decode_stream(self._lib.bn254_g2_decode_stream, b, G2_WORDS, max_points)
+
     def gt_mul_batch(self, a, b):
         a = _arr(a, GT_WORDS); b = _arr(b, GT_WORDS); _same_len(a, b)
         out = np.empty_like(a)

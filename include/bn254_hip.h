@@ -140,6 +140,14 @@ int bn254_g1_encode_batch(bn254_ctx *ctx, const bn_g1 *p, uint8_t *out, size_t n
 int bn254_g2_encode_batch(bn254_ctx *ctx, const bn_g2 *p, uint8_t *out, size_t n);
 int bn254_g1_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g1 *out, int32_t *status, size_t n);
 int bn254_g2_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g2 *out, int32_t *status, size_t n);
+/* the crate's own byte stream (what bincode/rustc_serialize produce for a sequence of points, groups/mod.rs:143-205): a point at
+   infinity is the lone byte 0, a finite point is 4 + coordinates, so records have variable length.  encode: `written` bytes are
+   produced (BN254_E_BAD_ARG if `cap` is too small).  decode: up to `max_points` points are parsed from `len` bytes; `count` points
+   and `consumed` bytes are reported (a truncated trailing record is left unconsumed); status[i] as for the batch decoders. */
+int bn254_g1_encode_stream(bn254_ctx *ctx, const bn_g1 *p, size_t n, uint8_t *out, size_t cap, size_t *written);
+int bn254_g2_encode_stream(bn254_ctx *ctx, const bn_g2 *p, size_t n, uint8_t *out, size_t cap, size_t *written);
+int bn254_g1_decode_stream(bn254_ctx *ctx, const uint8_t *in, size_t len, bn_g1 *out, int32_t *status, size_t max_points, size_t *count, size_t *consumed);
+int bn254_g2_decode_stream(bn254_ctx *ctx, const uint8_t *in, size_t len, bn_g2 *out, int32_t *status, size_t max_points, size_t *count, size_t *consumed);
 
 /* ---- device-resident entry points (inputs/outputs already in HBM; `stream` is a hipStream_t or NULL) ------------------ */
 /* Same layouts (array of structs) in device memory.  Asynchronous on `stream`; the caller synchronises. */

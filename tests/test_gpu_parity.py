@@ -713,3 +713,32 @@ def test_full_size_bilinearity_on_gpu():
     assert torch.equal(a, b) and torch.equal(a, c)
     one = torch.zeros(48, dtype=torch.int64, device=dev)
     assert not bool((a == a[0]).all())                          # not a constant output
+
+
+def test_wire_stream_format_on_gpu(oracle, eng):
+    """the crate's real byte stream (groups/mod.rs:143-205): infinity is the LONE byte 0, finite points are 4 + coordinates - records of
+    variable length.  encode == concatenation of the oracle's records with infinities shortened to one byte; decode inverts it,
+    reports a bad tag per record and leaves a truncated trailing record unconsumed"""
+    rng = np.random.default_rng(301)
+    n = 40
+    P, Q = _points(oracle, rng, n)
+    for i in (0, 7, 8, 39):
+        P[i] = oracle.g1_zero()
+    for i in (3, 39):
+        Q[i] = oracle.g2_zero()
+    for pts, enc1, encs, decs, zero, norm in ((P, oracle.g1_encode, eng.g1_encode_stream, eng.g1_decode_stream, oracle.g1_zero(), oracle.g1_normalize),
+                                              (Q, oracle.g2_encode, eng.g2_encode_stream, eng.g2_decode_stream, oracle.g2_zero(), oracle.g2_normalize)):
+        want = np.concatenate([(r[:1] if r[0] == 0 else r) for r in (enc1(p) for p in pts)])
+        got = encs(pts)
+        assert np.array_equal(got, want)
+        out, st, used = decs(got)
+        assert used == got.size and out.shape[0] == n and not st.any()
+        for i in range(n):
+            assert np.array_equal(out[i], zero if not pts[i][2 * len(zero) // 3:].any() else norm(pts[i]))
+        # truncated tail: the last complete record boundary is reported; a bad tag costs one byte and status 3
+        cut = got[:-5] if got[-1] != 0 or got.size < 2 else got
+        out2, st2, used2 = decs(np.concatenate([np.array([9], np.uint8), got[:200]]))
+        assert st2[0] == 3 and used2 <= 201 and out2.shape[0] >= 2 and not st2[1:].any()
+        assert np.array_equal(out2[1:], out[:out2.shape[0] - 1])
+        out3, st3, used3 = decs(got, max_points=5)
+        assert out3.shape[0] == 5 and np.array_equal(out3, out[:5])
