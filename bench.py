@@ -333,8 +333,9 @@ def main():
         elapsed = _max_over_ranks(dist, dev, elapsed)
 
         if rank == 0:
-            stats = {k: eng.e.kernel_stats(k) for k in ("miller", "final_exp")}
-            rf = roofline(eng, stats, n, MAC32_PER_PAIRING, KERNEL_SHARE, traffic_key=True)
+            stats = {k: eng.e.kernel_stats(k) for k in ("miller", "final_exp", "pairing_fused")}
+            stats = {k: v for k, v in stats.items() if v[1]}            # "pairing_fused": the BN254_FUSED=1 experiment (one kernel)
+            rf = roofline(eng, stats, n, MAC32_PER_PAIRING, dict(KERNEL_SHARE, pairing_fused=1.0), traffic_key=True)
             rf["algorithmic_hbm_bytes_per_launch"] = n * ALGO_BYTES_PER_PAIRING
             if n != BATCH:
                 rf["traffic"] = rf["traffic_source"] = None          # the PMC figures in profiles/ were taken at 2^16 per launch

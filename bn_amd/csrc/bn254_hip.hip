@@ -10,6 +10,7 @@
 // (scratch) traffic for the Fq12-sized temporaries; see DESIGN.md for the measured numbers.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -367,6 +368,12 @@ int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size
 int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_out, size_t n, void *stream) {
     BN_DEV_PROLOGUE(!d_p || !d_q || !d_out, 0x7fffffffu / 96);
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
+    static const bool fused = getenv("BN254_FUSED") && atoi(getenv("BN254_FUSED")) != 0;      // experiment, see bn254_pairing_fused_B
+    if (fused && ctx->mapping == 1) {
+        rc = ctx->exp_tbl.reserve(bn254_final_exp_table_bytes_B(n)); if (rc) return rc;
+        BnScope sc(ctx, s, "pairing_fused");
+        return bn254_launch_pairing_fused_B(d_p, d_q, d_out, n, ctx->exp_tbl.p, s);
+    }
     // the Miller values are written to d_out and exponentiated in place (same 384-byte slots)
     rc = bn_launch_miller(ctx, d_p, d_q, d_out, n, s, true); if (rc) return rc;
     return bn_launch_final_exp(ctx, d_out, d_out, n, s, nullptr);

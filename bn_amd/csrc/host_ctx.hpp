@@ -143,6 +143,7 @@ extern "C" {
 // bn254_kernels_b.hip
 int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s);
 int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hipStream_t s);
+int bn254_launch_pairing_fused_B(const void *p, const void *q, void *out, size_t n, void *table, hipStream_t s);
 size_t bn254_final_exp_table_bytes_B(size_t n);
 int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
 int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
