@@ -223,12 +223,31 @@ __device__ __forceinline__ Fq12<F2> miller_B_value(const uint32_t *g1, const uin
 }
 template <bool NAF>
 __device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
+    // (deliberately not expressed through miller_B_value: the register allocation of this kernel is sensitive to its exact shape -
+    //  3 spilled VGPRs in this form, 14 through the helper)
     BN_STAMP_BEGIN();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;                       // keep both lanes of every pair active for the DPP exchanges
-    Fq12<F2> f = miller_B_value<NAF>(g1, g2, pair);
+    const uint32_t *w1 = g1 + 24u * pair, *w2 = g2 + 48u * pair;
+    bool inf = words_all_zero(w1 + 16, 8) || words_all_zero(w2 + 32, 16);        // groups/mod.rs:766
+    G1Aff<Fe> p;
+    G2Aff<F2> q;
+    pair_prologue<Fe>(f2_scalar_load((const F2 *)nullptr, w1), f2_scalar_load((const F2 *)nullptr, w1 + 8), f2_scalar_load((const F2 *)nullptr, w1 + 16),
+                      f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32), p, q);
+    __shared__ uint32_t park[PARK_DWORDS * BLOCK];
+    MillerStateLds st = {park + threadIdx.x};
+    Fq12<F2> f;
+#ifdef BN_MILLER_MERGE_LINES
+    if constexpr (NAF) f = miller_loop_naf_merged(p, q, st);
+    else f = miller_loop_sched<NAF>(p, q, st);
+#else
+    f = miller_loop_sched<NAF>(p, q, st);
+#endif
+    Fq12<F2> one = f12_one<F2>();
+    f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
+    f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);
     if (live) f12_store(f, f_out + 96u * pair);
     BN_STAMP_END();
 }
