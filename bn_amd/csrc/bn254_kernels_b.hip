@@ -460,13 +460,8 @@ struct PowTableMem {
         return v;
     }
     __device__ __forceinline__ void put(int e, const Fq12<F2> &v) const { st6(e, 0, v.c0); st6(e, 1, v.c1); }
-    __device__ __forceinline__ Fq12<F2> get(int e) const { return {ld6(e, 0), ld6(e, 1)}; }
-};
-struct PowSlot {             // Fq12 source of f12_mul_src: hands out the halves of table entry `e` on demand
-    const PowTableMem &t;
-    int e;
-    __device__ __forceinline__ Fq6<F2> c0() const { return t.ld6(e, 0); }
-    __device__ __forceinline__ Fq6<F2> c1() const { return t.ld6(e, 1); }
+    __device__ __forceinline__ Fq6<F2> c0(int e) const { return ld6(e, 0); }
+    __device__ __forceinline__ Fq6<F2> c1(int e) const { return ld6(e, 1); }
 };
 constexpr size_t POW_TABLE_DWORDS_PER_LANE = 16 * 54;
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table) {
@@ -480,27 +475,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     for (int i = 0; i < 8; ++i) kw[i] = k[8u * pair + i];
     fr_from_mont(kw, raw);
     PowTableMem tbl = {table + (size_t)t * POW_TABLE_DWORDS_PER_LANE};
-    {
-        Fq12<F2> base = f12_load<F2>(a + 96u * pair);
-        tbl.put(0, f12_one<F2>());
-        tbl.put(1, base);
-    }
-#pragma unroll 1
-    for (int e = 2; e < 16; ++e) {                 // a^e = (a^(e/2))^2 for even e, a^(e-1) * a for odd e
-        Fq12<F2> v;
-        if ((e & 1) == 0) v = f12_sqr(tbl.get(e >> 1));
-        else v = f12_mul_src(tbl.get(e - 1), PowSlot{tbl, 1}, false);
-        tbl.put(e, v);
-    }
-    Fq12<F2> res = f12_one<F2>();
-#pragma unroll 1
-    for (int w = 63; w >= 0; --w) {
-        BN_EXP_HOOK(63 - w, 64);
-#pragma unroll 1
-        for (int d = 0; d < 4; ++d) res = f12_sqr(res);
-        const int digit = (int)((raw[w >> 3] >> ((w & 7) * 4)) & 15u);          // per lane pair: both lanes hold the same scalar
-        res = f12_mul_src(res, PowSlot{tbl, digit}, false);
-    }
+    Fq12<F2> res = gt_pow_windowed(f12_load<F2>(a + 96u * pair), raw, tbl);          // pairing.hpp
     if (live) f12_store(res, out + 96u * pair);
 }
 // out[i] = a[i]^-1   (Gt::inverse, lib.rs:172 -> fq12.rs:284-292; one Fq inversion per element, constant-time divsteps)

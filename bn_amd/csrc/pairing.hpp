@@ -377,6 +377,40 @@ BN_FN Fq12<F2> final_exponentiation(const Fq12<F2> &f) {
     return final_exponentiation(f, tbl);
 }
 
+// Gt::pow (lib.rs:171 -> fields/mod.rs:35-46: 256 x { res = res^2; if bit { res = a * res } } on the scalar taken out of Montgomery
+// form).  The power is a unique field element, so any addition chain returns the reference's bytes: fixed 4-bit windows, MSB first -
+// 256 squarings + 64 table products + a 14-operation table.  General Fq12 squarings (not cyclotomic ones): correct for ANY Fq12.
+// `tbl`: 16 Fq12 entries with put(e, v) / c0(e) / c1(e) (per-lane global memory in the kernel, plain variables in the host simulation).
+template <class F2, class Tbl>
+BN_FN Fq12<F2> gt_pow_windowed(const Fq12<F2> &base, const uint32_t *k_raw, Tbl &tbl) {
+    tbl.put(0, f12_one<F2>());
+    tbl.put(1, base);
+#pragma unroll 1
+    for (int e = 2; e < 16; ++e) {                 // a^e = (a^(e/2))^2 for even e, a^(e-1) * a for odd e
+        Fq12<F2> v;
+        if ((e & 1) == 0) v = f12_sqr<true>(Fq12<F2>{tbl.c0(e >> 1), tbl.c1(e >> 1)});
+        else v = f12_mul_src(Fq12<F2>{tbl.c0(e - 1), tbl.c1(e - 1)}, Fq12Slot<F2, Tbl>{tbl, 1}, false);
+        tbl.put(e, v);
+    }
+    Fq12<F2> res = f12_one<F2>();
+#pragma unroll 1
+    for (int w = 63; w >= 0; --w) {
+        BN_EXP_HOOK(63 - w, 64);
+#pragma unroll 1
+        for (int d = 0; d < 4; ++d) res = f12_sqr<true>(res);
+        const int digit = (int)((k_raw[w >> 3] >> ((w & 7) * 4)) & 15u);          // per lane pair: both lanes hold the same scalar
+        res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, digit}, false);
+    }
+    return res;
+}
+template <class F2>
+struct PowTableVars {
+    Fq12<F2> s_[16];
+    BN_FN void put(int i, const Fq12<F2> &v) { s_[i] = v; }
+    BN_FN Fq6<F2> c0(int i) const { return s_[i].c0; }
+    BN_FN Fq6<F2> c1(int i) const { return s_[i].c1; }
+};
+
 // groups/mod.rs:113-130 for G2 (z == 1 needs no special case: the general path returns the same canonical values)
 template <class F2>
 BN_FN G2Aff<F2> g2_to_affine(const F2 &x, const F2 &y, const F2 &z) {

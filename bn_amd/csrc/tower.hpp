@@ -116,7 +116,11 @@ BN_FN Fq12<F2> f12_mul_src(const Fq12<F2> &a, const BSrc &b, bool conj_b) {
 template <class F2>
 BN_COARSE Fq12<F2> f12_mul(const Fq12<F2> &a, const Fq12<F2> &b) { return f12_mul_src(a, Fq12Ref<F2>{b}, false); }
 // fq12.rs:275-282 (complex squaring over Fq6)
-template <class F2>
+// REDUCED_C1: return c1 = 2ab as a fused reduction (value < 2q) instead of a carry-propagated sum (< 4q).  The Miller loop feeds
+// every square straight into a sparse product, which takes the cheaper form; chains of squarings (Gt::pow) need the reduced one -
+// with c1 < 4q the Karatsuba sums of the NEXT squaring can exceed the 9q bias of the lane-pair product (found by the host
+// simulation's bound checks; actual values stay far below, but the bound must hold by construction).
+template <bool REDUCED_C1 = false, class F2>
 BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     Fq6<F2> ab = f6_mul(a.c0, a.c1);
     Fq6<F2> u;                                                // v*c1 + c0
@@ -128,7 +132,8 @@ BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     r.c0.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_ssub(t.c0, ab.c0));      // t - ab - v*ab
     r.c0.c1 = f2_lc3<1, -1, -1>(t.c1, ab.c1, ab.c0);
     r.c0.c2 = f2_lc3<1, -1, -1>(t.c2, ab.c2, ab.c1);
-    r.c1 = f6_add_norm(ab, ab);                                // 2ab as a plain sum (carries propagated)
+    if constexpr (REDUCED_C1) r.c1 = f6_lc3<2, 0, 0>(ab, ab, ab);
+    else r.c1 = f6_add_norm(ab, ab);                           // 2ab as a plain sum (carries propagated)
     return r;
 }
 // fq12.rs:103-105

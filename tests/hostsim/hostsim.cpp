@@ -183,6 +183,13 @@ EXPORT void hsb_pairing_naf_merged(const uint32_t *g1, const uint32_t *g2, uint3
     if (inf) f = f12_one<F2B>();
     f12_store(f, o);
 }
+// Gt::pow through the windowed chain of bn254_gt_pow_B (lane-pair mapping)
+EXPORT void hsb_gt_pow(const uint32_t *a, const uint32_t *k, uint32_t *o) {
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    PowTableVars<F2B> tbl;
+    f12_store(gt_pow_windowed(f12_load<F2B>(a), raw, tbl), o);
+}
 EXPORT void hsb_miller(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
     G1Aff<FeP> p; G2Aff<F2B> q;
     pair_prologue<FeP>(f2_scalar_load((F2B *)0, g1), f2_scalar_load((F2B *)0, g1 + 8), f2_scalar_load((F2B *)0, g1 + 16),

@@ -190,6 +190,18 @@ def test_scalar_mul_reference_chain(oracle, hs):
             assert np.array_equal(hs.call(fn, base, k, 2, out_words=2 * w), canon_infinity(on(want)))   # windowed algorithm, normalized
 
 
+def test_gt_pow_windowed_chain(oracle, hs):
+    """Gt::pow as bn254_gt_pow_B computes it (4-bit windows, general squarings), every limb/value bound enforced: pairing values, an
+    element outside the cyclotomic subgroup (a raw Miller value) and edge exponents against the oracle's bit-serial pow"""
+    rng = np.random.default_rng(29)
+    P = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)); Q = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng))
+    g = oracle.pairing(P, Q); raw = oracle.miller_only(P, Q)
+    for kv in (0, 1, 2, 15, 16, M.R_ORD - 1, (1 << 253) + 12345, int.from_bytes(rng.bytes(40), "little") % M.R_ORD):
+        k = oracle.fp_from_int(FR, kv)
+        for a in (g, raw):
+            assert np.array_equal(hs.call("hsb_gt_pow", a, k, out_words=96), oracle.gt_pow(a, k)), kv
+
+
 def test_g1_glv_scalar_mul(oracle, hs, ref_consts):
     """bn254_g1_mul_batch's chain: k = k1 + k2 lambda (mod r) with |k1|, |k2| < 2^129, Booth radix-16 digits, phi(x, y) = (beta x, y);
     the normalized result equals the reference's G * Fr for edge and random scalars and base points (incl. infinity)"""
