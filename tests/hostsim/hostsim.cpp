@@ -198,6 +198,30 @@ EXPORT void hsb_miller(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
 }
 
 
+// prepared-G2 mode as the kernels run it: precompute_lines -> 102 coefficients (stored in the reference image) -> miller_loop_prepared
+EXPORT void hsb_prepared_pairing(const uint32_t *g1, const uint32_t *g2, uint32_t *coeffs_out, uint32_t *o) {
+    G2Aff<F2B> q = g2_to_affine(f2_load((F2B *)0, g2), f2_load((F2B *)0, g2 + 16), f2_load((F2B *)0, g2 + 32));
+    auto sink = [&](int idx, const Line<F2B> &l) {
+        uint32_t *c = coeffs_out + idx * 48;
+        f2_store(l.ell_0, c); f2_store(l.ell_vw, c + 16); f2_store(l.ell_vv, c + 32);
+    };
+    precompute_lines(q, sink);
+    FeP zi = fe_inverse(f2_scalar_load((F2B *)0, g1 + 16)), zi2 = fe_sqr(zi);
+    G1Aff<FeP> p = {fe_mul(f2_scalar_load((F2B *)0, g1), zi2), fe_mul(f2_scalar_load((F2B *)0, g1 + 8), fe_mul(zi2, zi))};
+    struct PStore { G1Aff<FeP> p_; G1Aff<FeP> get_p() const { return p_; } } ps = {p};
+    auto source = [&](int idx) {
+        const uint32_t *c = coeffs_out + idx * 48;
+        Line<F2B> l = {f2_load((F2B *)0, c), f2_load((F2B *)0, c + 16), f2_load((F2B *)0, c + 32)};
+        return l;
+    };
+    f12_store(final_exponentiation(miller_loop_prepared<F2B>(ps, source)), o);
+}
+// the product tree step of the multi-pairing: acc = acc * x repeatedly (bn254_gt_product_B)
+EXPORT void hsb_gt_product(const uint32_t *in, int n, uint32_t *o) {
+    Fq12<F2B> acc = f12_load<F2B>(in);
+    for (int j = 1; j < n; ++j) acc = f12_mul_o(acc, f12_load<F2B>(in + 96 * j));
+    f12_store(acc, o);
+}
 #ifdef BN_BOUNDS
 EXPORT void hs_counts_reset() { op_counts() = OpCounts{}; }
 EXPORT void hs_counts_get(unsigned long *o) { OpCounts c = op_counts(); o[0] = c.mul; o[1] = c.mul2; o[2] = c.lc3; o[3] = c.lc3w; o[4] = c.norm; o[5] = c.addsub; o[6] = c.reduce; o[7] = c.select; }

@@ -190,6 +190,29 @@ def test_scalar_mul_reference_chain(oracle, hs):
             assert np.array_equal(hs.call(fn, base, k, 2, out_words=2 * w), canon_infinity(on(want)))   # windowed algorithm, normalized
 
 
+def test_prepared_mode_and_product_chain(oracle, hs, kats):
+    """the prepared-G2 kernels' code path (precompute_lines -> stored coefficients -> miller_loop_prepared -> final exponentiation) and
+    the product chain of the multi-pairing tree, with bound enforcement: coefficients equal the oracle's precompute, the pairing
+    equals pairing(), the chain equals the oracle's fold"""
+    rng = np.random.default_rng(31)
+    P = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)); Q = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng))
+    coeffs = np.zeros(102 * 24, np.uint64)
+    lib = hs.lib
+    import ctypes as C
+    U32 = C.POINTER(C.c_uint32)
+    out = np.zeros(48, np.uint64)
+    lib.hsb_prepared_pairing(P.ctypes.data_as(U32), Q.ctypes.data_as(U32), coeffs.ctypes.data_as(U32), out.ctypes.data_as(U32))
+    assert np.array_equal(coeffs.reshape(102, 3, 8), oracle.g2_precompute(oracle.g2_to_affine(Q)))
+    assert np.array_equal(out, oracle.pairing(P, Q))
+    vals = np.stack([oracle.pairing(oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)), Q) for _ in range(5)] + [oracle.miller_only(P, Q)])
+    want = vals[0]
+    for v in vals[1:]:
+        want = oracle.fq12_mul(want, v)
+    got = np.zeros(48, np.uint64)
+    lib.hsb_gt_product(np.ascontiguousarray(vals).ctypes.data_as(U32), C.c_int(len(vals)), got.ctypes.data_as(U32))
+    assert np.array_equal(got, want)
+
+
 def test_gt_pow_windowed_chain(oracle, hs):
     """Gt::pow as bn254_gt_pow_B computes it (4-bit windows, general squarings), every limb/value bound enforced: pairing values, an
     element outside the cyclotomic subgroup (a raw Miller value) and edge exponents against the oracle's bit-serial pow"""
