@@ -229,21 +229,56 @@ int bn_get_ctx(bn254_ctx *&ctx) {
     return BN254_OK;
 }
 
+// Launch granularity of the lane-pair kernels.  One "round" = 256 pairings per CU = two resident waves on every SIMD: the shape the
+// s_setprio hand-over of bn254_kernels_b.hip is tuned for (inside a 2^18 launch every 2^16 cost 6 % more than alone, and a box with
+// fewer than 256 CUs ran a fixed 2^16 launch as 1 + a fraction rounds: profiles/r02r_*).  Larger batches are issued as equal
+// sub-launches of at most one round, which also bounds the context-owned tables (final exponentiation: 4 KB, Gt::pow: 6.9 KB per
+// pairing OF ONE SUB-LAUNCH, not of the batch).  BN254_ROUND_PAIRS overrides (experiments).
+size_t bn_round_pairs(const bn254_ctx *c) {
+    static const long forced = getenv("BN254_ROUND_PAIRS") ? atol(getenv("BN254_ROUND_PAIRS")) : 0;
+    if (forced > 0) return (size_t)forced;
+    return (size_t)256 * (size_t)(c->cus > 0 ? c->cus : 256);
+}
+// as few sub-launches as possible with none above one round, all of (nearly) the same size: a ragged tail of a few pairings
+// would cost a whole kernel latency (one wave takes as long as a full machine)
+size_t bn_sub_launch(const bn254_ctx *c, size_t n) {
+    const size_t round = bn_round_pairs(c);
+    const size_t parts = (n + round - 1) / round;
+    return parts <= 1 ? n : ((n + parts - 1) / parts + 31) / 32 * 32;
+}
+
 // naf: the value is only consumed by a final exponentiation, so the shorter NAF schedule may be used (pairing.hpp)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf) {
+    if (c->mapping.load() == 1) {
+        const size_t step = bn_sub_launch(c, n);
+        for (size_t lo = 0; lo < n; lo += step) {
+            const size_t cnt = n - lo < step ? n - lo : step;
+            BnScope sc(c, s, "miller");
+            int rc = bn254_launch_miller_B((const char *)p + lo * sizeof(bn_g1), (const char *)q + lo * sizeof(bn_g2), (char *)f + lo * sizeof(bn_gt), cnt, naf ? 1 : 0, s);
+            if (rc) return rc;
+        }
+        return BN254_OK;
+    }
+    if (n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;          // mapping A (test double): one launch, 32-bit word offsets
     BnScope sc(c, s, "miller");
-    if (c->mapping == 1) return bn254_launch_miller_B(p, q, f, n, naf ? 1 : 0, s);
     hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
 // table: the caller's own table buffer (pipelined path: one per chunk in flight) or NULL for the context's (under a BnScratchGuard)
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table) {
-    if (c->mapping == 1) {
+    if (c->mapping.load() == 1) {
         BnBuf *t = table ? table : &c->exp_tbl;
-        int rc = t->reserve(bn254_final_exp_table_bytes_B(n)); if (rc) return rc;
-        BnScope sc(c, s, "final_exp");
-        return bn254_launch_final_exp_B(f, out, n, t->p, s);
+        const size_t step = bn_sub_launch(c, n);
+        int rc = t->reserve(bn254_final_exp_table_bytes_B(step)); if (rc) return rc;       // ONE table, reused by every sub-launch (stream order)
+        for (size_t lo = 0; lo < n; lo += step) {
+            const size_t cnt = n - lo < step ? n - lo : step;
+            BnScope sc(c, s, "final_exp");
+            rc = bn254_launch_final_exp_B((const char *)f + lo * sizeof(bn_gt), (char *)out + lo * sizeof(bn_gt), cnt, t->p, s);
+            if (rc) return rc;
+        }
+        return BN254_OK;
     }
+    if (n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
     BnScope sc(c, s, "final_exp");
     hipLaunchKernelGGL(bn254_final_exp_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
@@ -276,15 +311,32 @@ int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *t
 }
 size_t bn_product_tmp_bytes(size_t n) { return 2 * ((n + 3) / 4) * 384 + 384; }
 
+// sub-launches of at most `step` units: fn(lo, cnt) enqueues one
+template <class Fn>
+static int bn_for_parts(size_t n, size_t step, Fn fn) {
+    for (size_t lo = 0; lo < n; lo += step) {
+        int rc = fn(lo, n - lo < step ? n - lo : step);
+        if (rc) return rc;
+    }
+    return BN254_OK;
+}
+constexpr size_t BN_LAUNCH_MAX = (size_t)1 << 22;       // units per launch where no table is involved (32-bit word offsets inside a kernel)
+
 int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize) {
-    BnScope sc(ctx, s, g == 1 ? "g1_mul" : "g2_mul");
-    if (ctx->mapping == 1)          // registers-resident chains; G2 in the lane-pair mapping (bn254_kernels_mul.hip)
-        return g == 1 ? bn254_launch_g1_mul_M(d_p, d_k, d_out, n, normalize, s) : bn254_launch_g2_mul_M(d_p, d_k, d_out, n, normalize, s);
-    if (g == 1)
-        hipLaunchKernelGGL(bn254_g1_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
-    else
-        hipLaunchKernelGGL(bn254_g2_mul_k, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)d_p, (const uint32_t *)d_k, (uint32_t *)d_out, (uint32_t)n, normalize);
-    return (int)hipGetLastError();
+    const size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
+    const bool mapping_b = ctx->mapping.load() == 1;
+    return bn_for_parts(n, BN_LAUNCH_MAX, [&](size_t lo, size_t cnt) -> int {
+        const void *p = (const char *)d_p + lo * ps, *k = (const char *)d_k + lo * sizeof(bn_fr);
+        void *o = (char *)d_out + lo * ps;
+        BnScope sc(ctx, s, g == 1 ? "g1_mul" : "g2_mul");
+        if (mapping_b)          // registers-resident chains; G2 in the lane-pair mapping (bn254_kernels_mul.hip)
+            return g == 1 ? bn254_launch_g1_mul_M(p, k, o, cnt, normalize, s) : bn254_launch_g2_mul_M(p, k, o, cnt, normalize, s);
+        if (g == 1)
+            hipLaunchKernelGGL(bn254_g1_mul_k, dim3(grid_for(cnt)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)o, (uint32_t)cnt, normalize);
+        else
+            hipLaunchKernelGGL(bn254_g2_mul_k, dim3(grid_for(cnt)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)o, (uint32_t)cnt, normalize);
+        return (int)hipGetLastError();
+    });
 }
 
 extern "C" {
@@ -303,6 +355,7 @@ int bn254_ctx_create(int device, bn254_ctx **out) {
     bn254_ctx *c = new (std::nothrow) bn254_ctx();
     if (!c) return BN254_E_ALLOC;
     c->device = device;
+    if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->cus = 256;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return (int)e; }
     *out = c;
@@ -342,12 +395,12 @@ const char *bn254_error_string(int code) {
 }
 int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping) {
     if (!ctx || (mapping != 0 && mapping != 1)) return BN254_E_BAD_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->mapping = mapping;
+    ctx->mapping.store(mapping);        // atomic: calls already in flight keep the mapping they read at their first launch
     return BN254_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- device-resident API
+constexpr size_t BN_N_MAX = (size_t)1 << 40;          // sanity bound on a batch; launches are cut to size internally
 #define BN_DEV_PROLOGUE(null_check, limit)                                           \
     int rc = bn_get_ctx(ctx); if (rc) return rc;                                     \
     if (n == 0) return BN254_OK;                                                     \
@@ -357,23 +410,17 @@ int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping) {
     hipStream_t s = (hipStream_t)stream
 
 int bn254_miller_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_f, size_t n, void *stream) {
-    BN_DEV_PROLOGUE(!d_p || !d_q || !d_f, 0x7fffffffu / 96);
+    BN_DEV_PROLOGUE(!d_p || !d_q || !d_f, BN_N_MAX);
     return bn_launch_miller(ctx, d_p, d_q, d_f, n, s, false);
 }
 int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size_t n, void *stream) {
-    BN_DEV_PROLOGUE(!d_f || !d_out, 0x7fffffffu / 96);
+    BN_DEV_PROLOGUE(!d_f || !d_out, BN_N_MAX);
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
     return bn_launch_final_exp(ctx, d_f, d_out, n, s, nullptr);
 }
 int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_out, size_t n, void *stream) {
-    BN_DEV_PROLOGUE(!d_p || !d_q || !d_out, 0x7fffffffu / 96);
+    BN_DEV_PROLOGUE(!d_p || !d_q || !d_out, BN_N_MAX);
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
-    static const bool fused = getenv("BN254_FUSED") && atoi(getenv("BN254_FUSED")) != 0;      // experiment, see bn254_pairing_fused_B
-    if (fused && ctx->mapping == 1) {
-        rc = ctx->exp_tbl.reserve(bn254_final_exp_table_bytes_B(n)); if (rc) return rc;
-        BnScope sc(ctx, s, "pairing_fused");
-        return bn254_launch_pairing_fused_B(d_p, d_q, d_out, n, ctx->exp_tbl.p, s);
-    }
     // the Miller values are written to d_out and exponentiated in place (same 384-byte slots)
     rc = bn_launch_miller(ctx, d_p, d_q, d_out, n, s, true); if (rc) return rc;
     return bn_launch_final_exp(ctx, d_out, d_out, n, s, nullptr);
@@ -409,7 +456,7 @@ int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, s
     return bn_launch_product(ctx, ctx->ws.p, n, d_partial, (char *)ctx->ws.p + fbytes, s);
 }
 static int mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream, int normalize) {
-    BN_DEV_PROLOGUE(!d_p || !d_k || !d_out, 0x7fffffffu / 96);
+    BN_DEV_PROLOGUE(!d_p || !d_k || !d_out, BN_N_MAX);
     return bn_mul_dev(ctx, g, d_p, d_k, d_out, n, s, normalize);
 }
 int bn254_g1_mul_batch_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 1, p, k, o, n, s, 1); }
@@ -428,21 +475,30 @@ int bn254_miller_prepared_dev(bn254_ctx *ctx, const void *d_p, const void *d_coe
     return bn254_launch_miller_prepared_B(d_p, d_coeffs, shared, d_f, n, s);
 }
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream) {
-    BN_DEV_PROLOGUE(!d_a || !d_b || !d_out, 0x7fffffffu / 96);
-    BnScope sc(ctx, s, "gt_mul");
-    return bn254_launch_gt_mul_B(d_a, d_b, d_out, n, s);
+    BN_DEV_PROLOGUE(!d_a || !d_b || !d_out, BN_N_MAX);
+    return bn_for_parts(n, BN_LAUNCH_MAX, [&](size_t lo, size_t cnt) -> int {
+        BnScope sc(ctx, s, "gt_mul");
+        return bn254_launch_gt_mul_B((const char *)d_a + lo * sizeof(bn_gt), (const char *)d_b + lo * sizeof(bn_gt), (char *)d_out + lo * sizeof(bn_gt), cnt, s);
+    });
 }
 int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream) {
-    BN_DEV_PROLOGUE(!d_a || !d_k || !d_out, 0x7fffffffu / 96);
+    BN_DEV_PROLOGUE(!d_a || !d_k || !d_out, BN_N_MAX);
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
-    rc = ctx->pow_tbl.reserve(bn254_gt_pow_table_bytes_B(n)); if (rc) return rc;
-    BnScope sc(ctx, s, "gt_pow");
-    return bn254_launch_gt_pow_B(d_a, d_k, d_out, n, ctx->pow_tbl.p, s);
+    // ONE window table (16 x 216 B per lane of a sub-launch), reused by every sub-launch in stream order: 450 MB at a full round
+    // whatever the batch size (round 2 allocated 6.9 KB x n)
+    const size_t step = bn_sub_launch(ctx, n);
+    rc = ctx->pow_tbl.reserve(bn254_gt_pow_table_bytes_B(step)); if (rc) return rc;
+    return bn_for_parts(n, step, [&](size_t lo, size_t cnt) -> int {
+        BnScope sc(ctx, s, "gt_pow");
+        return bn254_launch_gt_pow_B((const char *)d_a + lo * sizeof(bn_gt), (const char *)d_k + lo * sizeof(bn_fr), (char *)d_out + lo * sizeof(bn_gt), cnt, ctx->pow_tbl.p, s);
+    });
 }
 int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, size_t n, void *stream) {
-    BN_DEV_PROLOGUE(!d_a || !d_out, 0x7fffffffu / 96);
-    BnScope sc(ctx, s, "gt_inverse");
-    return bn254_launch_gt_inverse_B(d_a, d_out, n, s);
+    BN_DEV_PROLOGUE(!d_a || !d_out, BN_N_MAX);
+    return bn_for_parts(n, BN_LAUNCH_MAX, [&](size_t lo, size_t cnt) -> int {
+        BnScope sc(ctx, s, "gt_inverse");
+        return bn254_launch_gt_inverse_B((const char *)d_a + lo * sizeof(bn_gt), (char *)d_out + lo * sizeof(bn_gt), cnt, s);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------- host-buffer API
@@ -456,7 +512,7 @@ int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, siz
 
 int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
     if (n == 0) return BN254_OK;
-    if (!p || !q || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    if (!p || !q || !out || n > BN_N_MAX) return BN254_E_BAD_ARG;
     int rc = bn_get_ctx(ctx); if (rc) return rc;
     BnDeviceGuard dev_guard;                 // concurrency is arbitrated per pipeline slot (BnSlotLease), not by the context mutex
     HIP_TRY(hipSetDevice(ctx->device));
@@ -480,7 +536,7 @@ int bn254_pairing_product(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, size_t
 }
 int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *out, size_t n) {
     if (n == 0) return BN254_OK;
-    if (!p || !k || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    if (!p || !k || !out || n > BN_N_MAX) return BN254_E_BAD_ARG;
     int rc = bn_get_ctx(ctx); if (rc) return rc;
     BnDeviceGuard dev_guard;                 // concurrency is arbitrated per pipeline slot (BnSlotLease), not by the context mutex
     HIP_TRY(hipSetDevice(ctx->device));
@@ -488,7 +544,7 @@ int bn254_g1_mul_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_fr *k, bn_g1 *ou
 }
 int bn254_g2_mul_batch(bn254_ctx *ctx, const bn_g2 *p, const bn_fr *k, bn_g2 *out, size_t n) {
     if (n == 0) return BN254_OK;
-    if (!p || !k || !out || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    if (!p || !k || !out || n > BN_N_MAX) return BN254_E_BAD_ARG;
     int rc = bn_get_ctx(ctx); if (rc) return rc;
     BnDeviceGuard dev_guard;                 // concurrency is arbitrated per pipeline slot (BnSlotLease), not by the context mutex
     HIP_TRY(hipSetDevice(ctx->device));

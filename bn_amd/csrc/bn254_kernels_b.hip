@@ -200,31 +200,9 @@ extern "C" int bn254_debug_stamps(uint64_t *out, size_t n) { return (int)hipMemc
 #define BN_STAMP_END() ((void)0)
 #endif
 template <bool NAF>
-__device__ __forceinline__ Fq12<F2> miller_B_value(const uint32_t *g1, const uint32_t *g2, uint32_t pair) {
-    const uint32_t *w1 = g1 + 24u * pair, *w2 = g2 + 48u * pair;
-    bool inf = words_all_zero(w1 + 16, 8) || words_all_zero(w2 + 32, 16);        // groups/mod.rs:766
-    G1Aff<Fe> p;
-    G2Aff<F2> q;
-    pair_prologue<Fe>(f2_scalar_load((const F2 *)nullptr, w1), f2_scalar_load((const F2 *)nullptr, w1 + 8), f2_scalar_load((const F2 *)nullptr, w1 + 16),
-                      f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32), p, q);
-    __shared__ uint32_t park[PARK_DWORDS * BLOCK];
-    MillerStateLds st = {park + threadIdx.x};
-    Fq12<F2> f;
-#ifdef BN_MILLER_MERGE_LINES
-    if constexpr (NAF) f = miller_loop_naf_merged(p, q, st);
-    else f = miller_loop_sched<NAF>(p, q, st);
-#else
-    f = miller_loop_sched<NAF>(p, q, st);
-#endif
-    Fq12<F2> one = f12_one<F2>();
-    f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
-    f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);
-    return f;
-}
-template <bool NAF>
 __device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
-    // (deliberately not expressed through miller_B_value: the register allocation of this kernel is sensitive to its exact shape -
-    //  3 spilled VGPRs in this form, 14 through the helper)
+    // (the register allocation of this kernel is sensitive to its exact shape: 3 spilled VGPRs in this form, 14 when the value
+    //  computation is factored into a helper)
     BN_STAMP_BEGIN();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
@@ -348,23 +326,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair), tbl);
     if (live) f12_store(f, out + 96u * pair);
     BN_STAMP_END();
-}
-// EXPERIMENT (BN254_FUSED=1 in the environment): Miller loop and final exponentiation in ONE kernel - no 384-byte round trip, one
-// kernel tail instead of two.
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_pairing_fused_B(const uint32_t *g1, const uint32_t *g2, uint32_t *out, uint32_t n, uint32_t *table) {
-    BN_KERNEL_PROLOGUE();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
-    uint32_t pair = t >> 1;
-    bool live = pair < n;
-    if (!live) pair = n - 1;
-    Fq12<F2> f = miller_B_value<true>(g1, g2, pair);
-#ifdef BN_EXP_TABLE_DWORD
-    ExpTableMem tbl = {table, t, gridDim.x * BLOCK};
-#else
-    ExpTableMem tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
-#endif
-    f = final_exponentiation(f, tbl);
-    if (live) f12_store(f, out + 96u * pair);
 }
 // ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
 constexpr int NCOEFF = 102, COEFF_WORDS = 48;
@@ -535,11 +496,6 @@ int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int n
 size_t bn254_final_exp_table_bytes_B(size_t n) {
     size_t grid = (2 * n + BLOCK - 1) / BLOCK;
     return grid * BLOCK * EXP_TABLE_DWORDS_PER_LANE * sizeof(uint32_t);
-}
-int bn254_launch_pairing_fused_B(const void *p, const void *q, void *out, size_t n, void *table, hipStream_t s) {
-    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_pairing_fused_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)out, (uint32_t)n, (uint32_t *)table);
-    return (int)hipGetLastError();
 }
 int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);

@@ -24,30 +24,41 @@ namespace {
 constexpr int BLOCK = 64;
 typedef Fq2B<Fe> F2;
 
-template <class F>
-__device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km, int normalize) {
+// NORMALIZE is a template parameter, i.e. each flavour is its OWN kernel: with a run-time flag the reference chain and the GLV /
+// windowed chain were register-allocated together (round 2: 74 spilled VGPRs in the G1 kernel).
+template <class F, bool NORMALIZE>
+__device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km) {
     uint32_t kw[8], raw[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) kw[i] = km[i];
     fr_from_mont(kw, raw);
-    if (normalize) {
+    if constexpr (NORMALIZE) {
         if constexpr (std::is_same<F, FqField>::value) return jac_normalize<F>(scalar_mul_glv(p, raw));      // G1: GLV + signed windows
         else return jac_normalize<F>(scalar_mul_windowed<F>(p, raw));
+    } else {
+        return scalar_mul_reference_chain<F>(p, raw);
     }
-    return scalar_mul_reference_chain<F>(p, raw);
 }
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_MUL_WAVES, BN_MUL_WAVES))) bn254_g1_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
+template <bool NORMALIZE>
+__device__ __forceinline__ void g1_mul_body(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
     uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= n) return;
     const uint32_t *w = p + 24u * idx;
     Jac<FqField> pt = {fe_from_u32x8(w), fe_from_u32x8(w + 8), fe_from_u32x8(w + 16)};
-    Jac<FqField> r = run_chain<FqField>(pt, k + 8u * idx, normalize);
+    Jac<FqField> r = run_chain<FqField, NORMALIZE>(pt, k + 8u * idx);
     uint32_t *o = out + 24u * idx;
     fe_to_u32x8(r.x, o); fe_to_u32x8(r.y, o + 8); fe_to_u32x8(r.z, o + 16);
 }
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_MUL_WAVES, BN_MUL_WAVES))) bn254_g1_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
+    g1_mul_body<true>(p, k, out, n);
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_MUL_WAVES, BN_MUL_WAVES))) bn254_g1_mul_chain_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
+    g1_mul_body<false>(p, k, out, n);
+}
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
+template <bool NORMALIZE>
+__device__ __forceinline__ void g2_mul_body(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -55,11 +66,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2
     const uint32_t *w = p + 48u * pair;
     typedef Fq2Field<F2> F;
     Jac<F> pt = {f2_load((const F2 *)nullptr, w), f2_load((const F2 *)nullptr, w + 16), f2_load((const F2 *)nullptr, w + 32)};
-    Jac<F> r = run_chain<F>(pt, k + 8u * pair, normalize);
+    Jac<F> r = run_chain<F, NORMALIZE>(pt, k + 8u * pair);
     if (live) {
         uint32_t *o = out + 48u * pair;
         f2_store(r.x, o); f2_store(r.y, o + 16); f2_store(r.z, o + 32);
     }
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
+    g2_mul_body<true>(p, k, out, n);
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_mul_chain_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
+    g2_mul_body<false>(p, k, out, n);
 }
 // a[i] + b[i]  (or a[i] - b[i] = a[i] + (-b[i]): lib.rs:103-114,146-157, groups/mod.rs:275-347): the reference's add-2007-bl
 // with its zero / equal-point branches, so the Jacobian limbs returned are the reference's own
@@ -109,12 +126,12 @@ int bn254_launch_g2_add_M(const void *a, const void *b, void *out, size_t n, int
 }
 int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s) {
     unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_g1_mul_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, normalize);
+    hipLaunchKernelGGL(normalize ? bn254_g1_mul_M : bn254_g1_mul_chain_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
 int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_g2_mul_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, normalize);
+    hipLaunchKernelGGL(normalize ? bn254_g2_mul_M : bn254_g2_mul_chain_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
 }

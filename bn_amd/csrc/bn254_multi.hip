@@ -43,11 +43,7 @@ struct MapJob {
 };
 
 // worker `w` of `j.nslots` handles chunks w, w + nslots, ... on pipeline slot `slot_index`
-int run_slot(const MapJob &j, int w, int slot_index) {
-    bn254_ctx *c = j.ctx;
-    BnSlot &s = c->slot[slot_index];
-    HIP_TRY(hipSetDevice(c->device));
-    if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+int run_slot_chunks(const MapJob &j, int w, BnSlot &s) {
     for (size_t ci = (size_t)w; ci * j.chunk < j.n; ci += (size_t)j.nslots) {
         const size_t lo = ci * j.chunk, cnt = std::min(j.chunk, j.n - lo);
         int rc;
@@ -64,33 +60,55 @@ int run_slot(const MapJob &j, int w, int slot_index) {
     }
     return BN254_OK;
 }
+int run_slot(const MapJob &j, int w, int slot_index) {
+    bn254_ctx *c = j.ctx;
+    BnSlot &s = c->slot[slot_index];
+    HIP_TRY(hipSetDevice(c->device));
+    if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    const int rc = run_slot_chunks(j, w, s);
+    // On an error return copies that read or write the CALLER's buffers may still be in flight on this stream: drain it before
+    // the C call returns and the slot lease passes to the next caller.
+    if (rc) (void)hipStreamSynchronize(s.stream);
+    return rc;
+}
 
-void plan(size_t n, size_t &chunk, int &nslots) {
-    // as few chunks as possible with none above 2^16, all of (nearly) the same size: a ragged tail of a few pairings would cost a
-    // whole kernel latency (one wave takes as long as a full machine)
-    const size_t nchunks = (n + 65535) / 65536;
-    size_t c = ((n + nchunks - 1) / nchunks + 31) / 32 * 32;
+void plan(const bn254_ctx *c, size_t n, size_t &chunk, int &nslots) {
+    // as few chunks as possible with none above one round of the machine (256 pairings per CU: two waves on every SIMD), all of
+    // (nearly) the same size: a ragged tail of a few pairings would cost a whole kernel latency
+    size_t ch = bn_sub_launch(c, n);
     const char *e = getenv("BN254_PIPELINE_CHUNK");                                // experiments
-    if (e && atol(e) > 0) c = (size_t)atol(e);
-    chunk = c;
+    if (e && atol(e) > 0) ch = (size_t)atol(e);
+    chunk = ch;
     int want = 2;
     const char *s = getenv("BN254_PIPELINE_SLOTS");
     if (s && atoi(s) > 0) want = std::min(BN_MAX_SLOTS, atoi(s));
-    nslots = (int)std::min<size_t>((size_t)want, (n + c - 1) / c);
+    nslots = (int)std::min<size_t>((size_t)want, (n + ch - 1) / ch);
+}
+
+// runs fn(w) for w = 0 .. count-1, workers 1.. on their own host threads.  A std::thread constructor that throws (resource
+// exhaustion) must not unwind past joinable threads (std::terminate): the workers that could not be started run inline instead.
+template <class Fn>
+void run_workers(int count, Fn fn) {
+    std::vector<std::thread> th;
+    th.reserve((size_t)count);
+    int started = 1;
+    for (int w = 1; w < count; ++w) {
+        try { th.emplace_back(fn, w); ++started; } catch (...) { break; }
+    }
+    fn(0);
+    for (int w = started; w < count; ++w) fn(w);
+    for (auto &t : th) t.join();
 }
 
 int run_map(MapJob &j) {
-    plan(j.n, j.chunk, j.nslots);
+    plan(j.ctx, j.n, j.chunk, j.nslots);
     if (j.nslots <= 1) {                                      // one chunk: one slot, on the calling thread; a second caller overlaps
         BnSlotLease lease(j.ctx, false);
         return run_slot(j, 0, lease.first);
     }
     BnSlotLease lease(j.ctx, true);
     std::vector<int> rcs(j.nslots, BN254_OK);
-    std::vector<std::thread> th;
-    for (int w = 1; w < j.nslots; ++w) th.emplace_back([&, w] { rcs[w] = run_slot(j, w, w); });
-    rcs[0] = run_slot(j, 0, 0);
-    for (auto &t : th) t.join();
+    run_workers(j.nslots, [&](int w) { rcs[w] = run_slot(j, w, w); });
     for (int rc : rcs) if (rc) return rc;
     return BN254_OK;
 }
@@ -130,6 +148,7 @@ struct Rccl {
     void *h = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -154,6 +173,7 @@ Rccl &rccl() {
     auto sym = [&](const char *n) { return dlsym(g_rccl.h, n); };
     g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))sym("ncclCommAbort");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
@@ -253,14 +273,10 @@ static int pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, b
     std::lock_guard<std::mutex> lk(m->mu);
     const size_t G = m->ctx.size();
     std::vector<int> rcs(G, BN254_OK);
-    std::vector<std::thread> th;
-    auto shard = [&](size_t g) {
-        const size_t lo = n * g / G, hi = n * (g + 1) / G;
+    run_workers((int)G, [&](int g) {
+        const size_t lo = n * (size_t)g / G, hi = n * ((size_t)g + 1) / G;
         rcs[g] = bn254_pairing_batch(m->ctx[g], p + lo, q + lo, out + lo, hi - lo);
-    };
-    for (size_t g = 1; g < G; ++g) th.emplace_back(shard, g);
-    shard(0);
-    for (auto &t : th) t.join();
+    });
     for (int rc : rcs) if (rc) return rc;
     return BN254_OK;
 }
@@ -287,22 +303,28 @@ static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q,
         HIP_TRY(hipStreamSynchronize(c->stream));
         return BN254_OK;
     };
-    {
-        std::vector<std::thread> th;
-        for (size_t g = 1; g < G; ++g) th.emplace_back([&, g] { rcs[g] = local(g); });
-        rcs[0] = local(0);
-        for (auto &t : th) t.join();
-        for (int rc : rcs) if (rc) return rc;
-    }
+    run_workers((int)G, [&](int g) { rcs[g] = local((size_t)g); });
+    for (int rc : rcs) if (rc) return rc;
     // 2. the ONE exchange step: 384 bytes per rank
     if (m->exchange == BN254_EXCHANGE_RCCL) {
         Rccl &r = rccl();
-        if (r.GroupStart() != ncclSuccess) return BN254_E_COMM;
-        for (size_t g = 0; g < G; ++g) {
+        // A failed collective leaves work enqueued on the earlier ranks' streams and the communicators unusable: abort them (a later
+        // call or ncclCommDestroy on a wedged communicator can hang), fall back to the peer-copy exchange for the following calls,
+        // and report BN254_E_COMM for this one.
+        auto fail = [&]() -> int {
+            for (auto &c : m->comms) if (c) { if (r.CommAbort) r.CommAbort(c); else r.CommDestroy(c); c = nullptr; }
+            m->comms.clear();
+            m->exchange = BN254_EXCHANGE_PEER;
+            for (size_t g = 0; g < G; ++g) { hipSetDevice(m->devices[g]); (void)hipStreamSynchronize(m->ctx[g]->stream); }
+            return BN254_E_COMM;
+        };
+        if (r.GroupStart() != ncclSuccess) return fail();
+        bool ok = true;
+        for (size_t g = 0; g < G && ok; ++g) {
             hipSetDevice(m->devices[g]);
-            if (r.AllGather(m->d_partial[g].p, m->d_gather[g].p, 48, ncclUint64, m->comms[g], m->ctx[g]->stream) != ncclSuccess) { r.GroupEnd(); return BN254_E_COMM; }
+            ok = r.AllGather(m->d_partial[g].p, m->d_gather[g].p, 48, ncclUint64, m->comms[g], m->ctx[g]->stream) == ncclSuccess;
         }
-        if (r.GroupEnd() != ncclSuccess) return BN254_E_COMM;
+        if (r.GroupEnd() != ncclSuccess || !ok) return fail();
         for (size_t g = 1; g < G; ++g) { HIP_TRY(hipSetDevice(m->devices[g])); HIP_TRY(hipStreamSynchronize(m->ctx[g]->stream)); }
     } else {
         HIP_TRY(hipSetDevice(m->devices[0]));

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <map>
 #include <new>
@@ -69,7 +70,8 @@ struct BnSlot {
 
 struct bn254_ctx {
     int device = 0;
-    int mapping = 1;                    // 1: lane-pair mapping (default), 0: one lane per pairing
+    int cus = 256;                      // compute units of the device (sizes one "round" of the lane-pair kernels: bn_round_pairs)
+    std::atomic<int> mapping{1};        // 1: lane-pair mapping (default), 0: one lane per pairing; read by slot-leased callers without ctx->mu
     std::mutex mu;                      // host-buffer entry points hold it for the whole call
     std::mutex scratch_mu;              // guards the scratch bookkeeping below (held only while enqueueing)
     hipStream_t stream = nullptr;       // the context's own stream (host-buffer entry points)
@@ -87,7 +89,7 @@ struct bn254_ctx {
     std::condition_variable slot_cv;
     unsigned slot_busy = 0;             // bit i: slot i is leased
     int slot_waiting_all = 0;           // callers waiting for every slot (new single leases queue behind them)
-    bool profile = false;
+    std::atomic<bool> profile{false};   // read by every launch helper, possibly from several host threads
     std::mutex prof_mu;                 // recs / folded (worker threads of the pipelined path launch concurrently)
     struct Rec { std::string name; hipEvent_t a, b; };
     std::vector<Rec> recs;
@@ -133,6 +135,8 @@ struct BnScratchGuard {
 };
 
 // kernel launch helpers (bn254_hip.hip); `table` = caller-provided final-exponentiation table or NULL for the context's own
+size_t bn_round_pairs(const bn254_ctx *c);                        // pairings in one full-machine launch of the lane-pair kernels
+size_t bn_sub_launch(const bn254_ctx *c, size_t n);                // sub-launch size for a batch of n (equal parts, none above one round)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf);
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table);
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s);
@@ -143,7 +147,6 @@ extern "C" {
 // bn254_kernels_b.hip
 int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s);
 int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hipStream_t s);
-int bn254_launch_pairing_fused_B(const void *p, const void *q, void *out, size_t n, void *table, hipStream_t s);
 size_t bn254_final_exp_table_bytes_B(size_t n);
 int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
 int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
