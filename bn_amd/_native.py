@@ -7,7 +7,7 @@ import subprocess
 
 HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("BN254_LIB_PATH", HERE / "libbn254_hip.so"))     # override: kernel experiments only
-SOURCES = [HERE / "csrc" / f for f in ("bn254_hip.hip", "bn254_kernels_b.hip", "bn254_kernels_mul.hip", "bn254_multi.hip")]
+SOURCES = [HERE / "csrc" / f for f in ("bn254_hip.hip", "bn254_kernels_b.hip", "bn254_kernels_mul.hip", "bn254_kernels_w.hip", "bn254_multi.hip")]
 OBJ_DIR = HERE / "csrc" / "build"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -61,6 +61,7 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_final_exp_batch_dev": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_gt_product_dev": [_VP, _VP, _SZ, _VP, _VP],
     "bn254_miller_product_dev": [_VP, _VP, _VP, _SZ, _VP, _VP],
+    "bn254_gt_product_final_exp_dev": [_VP, _VP, _SZ, _VP, _VP],
     "bn254_g1_mul_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
     "bn254_g2_mul_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
     "bn254_g1_mul_jacobian_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],

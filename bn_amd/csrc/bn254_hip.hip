@@ -264,8 +264,18 @@ int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t
     hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
+// Up to this many final exponentiations per call run ONE PER WAVE (bn254_kernels_w.hip: ~0.45 ms whatever the count, while a
+// lane pair needs 2.1 ms for its serial chain); above it the lane-pair kernel's throughput wins.  BN254_WAVE_FE_MAX overrides.
+size_t bn_wave_fe_max() {
+    const char *e = getenv("BN254_WAVE_FE_MAX");
+    return e ? (size_t)atol(e) : 512;
+}
 // table: the caller's own table buffer (pipelined path: one per chunk in flight) or NULL for the context's (under a BnScratchGuard)
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table) {
+    if (c->mapping.load() == 1 && n <= bn_wave_fe_max()) {
+        BnScope sc(c, s, "final_exp_wave");
+        return bn254_launch_final_exp_W(f, out, n, s);
+    }
     if (c->mapping.load() == 1) {
         BnBuf *t = table ? table : &c->exp_tbl;
         const size_t step = bn_sub_launch(c, n);
@@ -283,8 +293,16 @@ int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStr
     hipLaunchKernelGGL(bn254_final_exp_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
-// reduces n Fq12 values at `in` to one at `out` using ping-pong space `tmp` (>= 2 * ceil(n/4) * 384 B)
+// reduces n Fq12 values at `in` to one at `out`; `tmp` >= bn_product_tmp_bytes(n).  Lane-pair mapping: ONE launch (lane chunks ->
+// wave-cooperative fold -> arrival tree over the waves, bn254_kernels_w.hip); one-lane mapping (test double): a launch per level.
+static unsigned product_chunk(size_t n) { return (unsigned)((n + 65535) / 65536); }      // at most 2^16 lane pairs = two waves per SIMD
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s) {
+    if (c->mapping.load() == 1) {
+        size_t grid, sb, cw;
+        bn254_gt_reduce_sizes_W(n, product_chunk(n), &grid, &sb, &cw);
+        BnScope sc(c, s, "gt_product");
+        return bn254_launch_gt_reduce_W(in, n, product_chunk(n), tmp, (char *)tmp + sb, out, s);
+    }
     const uint32_t chunk = 4;
     const uint32_t *src = (const uint32_t *)in;
     size_t level_cap = (n + chunk - 1) / chunk;
@@ -293,23 +311,34 @@ int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *t
     while (true) {
         size_t m = (n + chunk - 1) / chunk;
         uint32_t *dst = (m == 1) ? (uint32_t *)out : (useA ? bufA : bufB);
-        int rc;
         {
             BnScope sc(c, s, "gt_product");
-            if (c->mapping == 1) {
-                rc = bn254_launch_gt_product_B(src, dst, n, chunk, s);
-            } else {
-                hipLaunchKernelGGL(bn254_gt_product_A, dim3(grid_for(m)), dim3(BLOCK), 0, s, src, dst, (uint32_t)n, chunk);
-                rc = (int)hipGetLastError();
-            }
+            hipLaunchKernelGGL(bn254_gt_product_A, dim3(grid_for(m)), dim3(BLOCK), 0, s, src, dst, (uint32_t)n, chunk);
+            int rc = (int)hipGetLastError();
+            if (rc) return rc;
         }
-        if (rc) return rc;
         if (m == 1) break;
         src = dst; n = m; useA = !useA;
     }
     return BN254_OK;
 }
-size_t bn_product_tmp_bytes(size_t n) { return 2 * ((n + 3) / 4) * 384 + 384; }
+// out = final_exponentiation(in[0] * ... * in[m-1]): the tail of a sharded multi-pairing (the partial products of the ranks, then
+// the ONE final exponentiation).  Up to 64 values: one wave-cooperative launch; more: product tree, then the exponentiation.
+int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *out, hipStream_t s) {
+    if (c->mapping.load() == 1 && m >= 1 && m <= 64) {
+        BnScope sc(c, s, "gt_tail");
+        return bn254_launch_gt_tail_W(in, 1, (unsigned)m, out, 1, s);
+    }
+    int rc = c->ws.reserve(bn_product_tmp_bytes(m)); if (rc) return rc;
+    if ((rc = bn_launch_product(c, in, m, out, c->ws.p, s))) return rc;
+    return bn_launch_final_exp(c, out, out, 1, s, nullptr);
+}
+size_t bn_product_tmp_bytes(size_t n) {
+    size_t grid, sb, cw;
+    bn254_gt_reduce_sizes_W(n ? n : 1, product_chunk(n ? n : 1), &grid, &sb, &cw);
+    const size_t a = 2 * ((n + 3) / 4) * 384 + 384, b = sb + cw * sizeof(uint32_t) + 256;
+    return a > b ? a : b;
+}
 
 // sub-launches of at most `step` units: fn(lo, cnt) enqueues one
 template <class Fn>
@@ -427,7 +456,7 @@ int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, vo
 }
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;
-    if (!d_out || (n && !d_in) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    if (!d_out || (n && !d_in) || n > 0xffffffffu) return BN254_E_BAD_ARG;
     BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
@@ -442,9 +471,18 @@ int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out
     rc = ctx->ws.reserve(bn_product_tmp_bytes(n)); if (rc) return rc;
     return bn_launch_product(ctx, d_in, n, d_out, ctx->ws.p, s);
 }
+int bn254_gt_product_final_exp_dev(bn254_ctx *ctx, const void *d_in, size_t m, void *d_out, void *stream) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (!d_out || !d_in || m == 0 || m > BN_N_MAX) return BN254_E_BAD_ARG;
+    BnDeviceGuard dev_guard;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
+    return bn_launch_product_final_exp(ctx, d_in, m, d_out, s);
+}
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;
-    if (!d_partial || (n && (!d_p || !d_q)) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    if (!d_partial || (n && (!d_p || !d_q)) || n > 0xffffffffu) return BN254_E_BAD_ARG;
     if (n == 0) return bn254_gt_product_dev(ctx, nullptr, 0, d_partial, stream);
     BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -374,22 +374,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     if (live) f12_store(f, f_out + 96u * pair);
 }
 
-// out[t] = product of in[t*chunk .. min(n, (t+1)*chunk))   (product tree of the multi-pairing; chunk is small so that every
-// level keeps many lane pairs busy: 2^15 values -> 1 in 8 levels of 3 multiplications instead of 3 levels of 63)
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_product_B(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t chunk) {
-    BN_KERNEL_PROLOGUE();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
-    uint32_t pair = t >> 1;
-    uint32_t groups = (n + chunk - 1) / chunk;
-    bool live = pair < groups;
-    if (!live) pair = groups - 1;
-    uint32_t lo = pair * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    Fq12<F2> acc = f12_load<F2>(in + 96u * lo);
-#pragma unroll 1
-    for (uint32_t j = lo + 1; j < hi; ++j) acc = f12_mul_o(acc, f12_load<F2>(in + 96u * j));
-    if (live) f12_store(acc, out + 96u * pair);
-}
-
 // out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
     BN_KERNEL_PROLOGUE();
@@ -461,12 +445,6 @@ int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(bn254_miller_prepared_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)coeffs,
                        (uint32_t)(shared ? 0 : NCOEFF * COEFF_WORDS), (uint32_t *)f, (uint32_t)n);
-    return (int)hipGetLastError();
-}
-int bn254_launch_gt_product_B(const void *in, void *out, size_t n, unsigned chunk, hipStream_t s) {
-    size_t groups = (n + chunk - 1) / chunk;
-    unsigned grid = (unsigned)((2 * groups + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_gt_product_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)in, (uint32_t *)out, (uint32_t)n, chunk);
     return (int)hipGetLastError();
 }
 int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s) {

@@ -339,8 +339,7 @@ static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q,
     std::lock_guard<std::mutex> cl(c0->mu);
     HIP_TRY(hipSetDevice(c0->device));
     int rc;
-    if ((rc = bn254_gt_product_dev(c0, m->d_gather[0].p, G, m->d_partial[0].p, c0->stream))) return rc;
-    if ((rc = bn254_final_exp_batch_dev(c0, m->d_partial[0].p, m->d_partial[0].p, 1, c0->stream))) return rc;
+    if ((rc = bn254_gt_product_final_exp_dev(c0, m->d_gather[0].p, G, m->d_partial[0].p, c0->stream))) return rc;      // ONE launch
     HIP_TRY(hipMemcpyAsync(out, m->d_partial[0].p, sizeof(bn_gt), hipMemcpyDeviceToHost, c0->stream));
     HIP_TRY(hipStreamSynchronize(c0->stream));
     return BN254_OK;

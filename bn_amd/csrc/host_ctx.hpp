@@ -139,6 +139,7 @@ size_t bn_round_pairs(const bn254_ctx *c);                        // pairings in
 size_t bn_sub_launch(const bn254_ctx *c, size_t n);                // sub-launch size for a batch of n (equal parts, none above one round)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf);
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table);
+int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *out, hipStream_t s);   // scratch guard held by the caller
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s);
 size_t bn_product_tmp_bytes(size_t n);
 int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize);
@@ -150,11 +151,15 @@ int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hi
 size_t bn254_final_exp_table_bytes_B(size_t n);
 int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
 int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
-int bn254_launch_gt_product_B(const void *in, void *out, size_t n, unsigned chunk, hipStream_t s);
 int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
 size_t bn254_gt_pow_table_bytes_B(size_t n);
 int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, hipStream_t s);
 int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s);
+// bn254_kernels_w.hip: one Fq12 per wave (wave.hpp)
+int bn254_launch_final_exp_W(const void *f, void *out, size_t n, hipStream_t s);
+int bn254_launch_gt_tail_W(const void *in, size_t groups, unsigned m, void *out, int final_exp, hipStream_t s);
+void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, size_t *grid, size_t *scratch_bytes, size_t *counter_words);
+int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, void *scratch, void *counters, void *out, hipStream_t s);
 // bn254_kernels_mul.hip
 int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);
 int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);

@@ -53,6 +53,13 @@ class TorchEngine:
         self.e.gt_product_dev(vals.data_ptr(), vals.shape[0], out.data_ptr(), self._stream())
         return out
 
+    def product_final_exp(self, vals):
+        """final_exponentiation(prod vals): ONE launch for the tail of the sharded multi-pairing"""
+        out = self.empty(GT_WORDS)
+        vals = vals.contiguous()
+        self.e.gt_product_final_exp_dev(vals.data_ptr(), vals.shape[0], out.data_ptr(), self._stream())
+        return out
+
     def final_exp(self, f):
         out = self.empty(GT_WORDS)
         self.e.final_exp_batch_dev(f.data_ptr(), out.data_ptr(), 1, self._stream())
@@ -95,7 +102,9 @@ def pairing_product_sharded(eng, p_local, q_local, group=None):
     """multi-pairing product over all ranks' shards; every rank returns the same Gt (48 words)"""
     partial = eng.miller_product(p_local, q_local)          # local: Miller loops + Fq12 product tree
     parts = all_gather_partials(partial, group)             # RCCL all-gather of 384 B per rank
-    return eng.final_exp(eng.gt_product(parts))             # world-1 multiplications + ONE final exponentiation
+    if hasattr(eng, "product_final_exp"):
+        return eng.product_final_exp(parts)                 # world-1 multiplications + ONE final exponentiation, one launch
+    return eng.final_exp(eng.gt_product(parts))
 
 
 def pairing_batch_sharded(eng, p_local, q_local, out=None):

@@ -207,6 +207,9 @@ class Engine:
     def gt_product_dev(self, d_in, n, d_out, stream=0):
         _native.check(self._lib.bn254_gt_product_dev(self._h, d_in, n, d_out, stream))
 
+    def gt_product_final_exp_dev(self, d_in, m, d_out, stream=0):
+        _native.check(self._lib.bn254_gt_product_final_exp_dev(self._h, d_in, m, d_out, stream))
+
     def miller_product_dev(self, d_p, d_q, n, d_partial, stream=0):
         _native.check(self._lib.bn254_miller_product_dev(self._h, d_p, d_q, n, d_partial, stream))
 

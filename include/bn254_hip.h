@@ -157,6 +157,10 @@ int bn254_miller_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, voi
 int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size_t n, void *stream);
 /* d_out[0] = product of d_in[0..n) in Fq12 (lib.rs:175-179 semantics; order-independent because Fq12 is commutative) */
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream);
+/* d_out[0] = final_exponentiation(d_in[0] * ... * d_in[m-1]), m >= 1: the tail of a sharded multi-pairing - the ranks' partial
+   products after their exchange, then the ONE final exponentiation (fq12.rs:41-88 behind the fold of shootout/main.rs:11-16).
+   Up to 64 values it is a single wave-cooperative launch (one Fq12 spread over a wave, ~0.5 ms instead of 2.9 ms). */
+int bn254_gt_product_final_exp_dev(bn254_ctx *ctx, const void *d_in, size_t m, void *d_out, void *stream);
 /* local part of a sharded multi-pairing: un-exponentiated product of the Miller values of n pairs -> one Fq12 */
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream);
 int bn254_g2_precompute_dev(bn254_ctx *ctx, const void *d_q, void *d_coeffs, size_t n, void *stream);
@@ -182,7 +186,7 @@ int bn254_tile_dev(bn254_ctx *ctx, const void *d_record, size_t record_bytes, si
    accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
 int bn254_profile_enable(bn254_ctx *ctx, int on);
 int bn254_profile_reset(bn254_ctx *ctx);
-/* kernel: "miller", "final_exp", "gt_product", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
+/* kernel: "miller", "final_exp", "final_exp_wave", "gt_product", "gt_tail", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
    Synchronises and consumes the recorded events (totals accumulate until bn254_profile_reset). */
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 /* issue-rate ceiling of v_mad_u64_u32 (the 32x32+64 multiply-accumulate every field product is built from) at

@@ -36,6 +36,9 @@ BN_FN FeP fe_sqr(const FeP &a) { return fe_mul(a, a); }
 BN_FN FeP fe_mul2(const FeP &a, const FeP &u, const FeP &c, const FeP &v) {
     return {{fe_mul2(a.v[0], u.v[0], c.v[0], v.v[0]), fe_mul2(a.v[1], u.v[1], c.v[1], v.v[1])}};
 }
+struct Fe;
+BN_FN Fe fe_cneg(bool flag, const Fe &z);         // wave.hpp
+BN_FN FeP fe_cneg(bool flag, const FeP &a) { return {{fe_cneg(flag, a.v[0]), fe_cneg(flag, a.v[1])}}; }
 BN_FN FeP fe_inverse(const FeP &a) { return {{fe_inverse(a.v[0]), fe_inverse(a.v[1])}}; }
 BN_FN FeP fe_select(bool take_b, const FeP &a, const FeP &b) { return {{fe_select(take_b, a.v[0], b.v[0]), fe_select(take_b, a.v[1], b.v[1])}}; }
 // I/O of a pair: the even lane reads/writes w0, the odd lane w1

@@ -15,7 +15,7 @@ def build(bounds=True):
     out = HERE / name
     srcs = [HERE / "hostsim.cpp"] + sorted(CSRC.glob("*.hpp"))
     if (not out.exists()) or out.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
-        cmd = ["g++", "-std=c++17", "-O1" if bounds else "-O2", "-fPIC", "-shared", "-fvisibility=hidden",
+        cmd = ["g++", "-std=c++17", "-O1" if bounds else "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-pthread",
                "-o", str(out), str(HERE / "hostsim.cpp")]
         if bounds:
             cmd.insert(1, "-DBN_BOUNDS")

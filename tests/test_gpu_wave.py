@@ -1,0 +1,142 @@
+"""GPU parity tests of the WAVE-COOPERATIVE kernels (bn_amd/csrc/wave.hpp, bn254_kernels_w.hip): one Fq12 per wave for the
+latency-bound tails of the path - the single final exponentiation of a multi-pairing, the one-launch product tree with its
+arrival tree across workgroups, the product-then-exponentiate tail of the sharded product.  Everything goes through the C ABI
+and is compared with the CPU oracle bit for bit (run with -m gpu on an MI355X)."""
+import os
+
+import numpy as np
+import pytest
+
+import bn_model as M
+from bn_oracle import FQ
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def te():
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    return D.TorchEngine(bn_amd.Engine(0), torch.device("cuda", 0))
+
+
+def _rand_fq12(oracle, rng, n):
+    return np.stack([np.concatenate([oracle.fp_from_int(FQ, int.from_bytes(rng.bytes(40), "little") % M.Q) for _ in range(12)]) for _ in range(n)])
+
+
+def _dev(te, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(te.device)
+
+
+def _host(t):
+    import torch
+    torch.cuda.synchronize()
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _final_exp_batch(te, vals):
+    out = te.empty(vals.shape[0], 48)
+    te.e.final_exp_batch_dev(vals.data_ptr(), out.data_ptr(), vals.shape[0], te._stream())
+    return out
+
+
+def _fold(oracle, vals):
+    acc = oracle.fq12_one()
+    for v in vals:
+        acc = oracle.fq12_mul(acc, v)
+    return acc
+
+
+class _env:
+    def __init__(self, **kv): self.kv = kv
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update({k: str(v) for k, v in self.kv.items()})
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+def test_wave_final_exponentiation_matches_oracle(oracle, kats, te):
+    """fq12.rs:41-88 with one Fq12 per wave: arbitrary Fq12 inputs (the easy part maps anything non-zero into the cyclotomic
+    subgroup), the reference's own Miller-loop known answer (groups/mod.rs:522-547 -> :773-796), one and several per launch"""
+    rng = np.random.default_rng(301)
+    vals = _rand_fq12(oracle, rng, 9)
+    want = np.stack([oracle.fq12_final_exponentiation(v) for v in vals])
+    for n in (1, 2, 9):
+        assert np.array_equal(_host(_final_exp_batch(te, _dev(te, vals[:n]))), want[:n]), n
+    one = oracle.fq12_one()
+    assert np.array_equal(_host(_final_exp_batch(te, _dev(te, one.reshape(1, 48))))[0], one)
+    # in place, as pairing_batch uses it
+    d = _dev(te, vals)
+    te.e.final_exp_batch_dev(d.data_ptr(), d.data_ptr(), 9, te._stream())
+    assert np.array_equal(_host(d), want)
+
+
+def test_wave_and_lane_pair_final_exponentiation_agree(te):
+    """the same 600 Miller values through both kernels (the switch-over is a host-side threshold, BN254_WAVE_FE_MAX)"""
+    import torch
+    from bn_amd import distributed as D
+    n = 600
+    P, Q = D.synthetic_points(te, 5000, 5000 + n)
+    f = te.empty(n, 48)
+    te.e.miller_batch_dev(P.data_ptr(), Q.data_ptr(), f.data_ptr(), n, te._stream())
+    with _env(BN254_WAVE_FE_MAX=0):
+        a = _final_exp_batch(te, f); torch.cuda.synchronize()
+    with _env(BN254_WAVE_FE_MAX=4096):
+        b = _final_exp_batch(te, f); torch.cuda.synchronize()
+    te.e.profile(True); te.e.profile_reset()
+    with _env(BN254_WAVE_FE_MAX=4096):
+        _final_exp_batch(te, f[:1].contiguous()); torch.cuda.synchronize()
+    assert te.e.kernel_stats("final_exp_wave")[1] == 1 and te.e.kernel_stats("final_exp")[1] == 0
+    te.e.profile(False)
+    assert torch.equal(a, b)
+
+
+def test_one_launch_product_tree_matches_fold(oracle, te):
+    """bn254_gt_product_dev = fold of shootout/main.rs:11-16 over Fq12 values: lane chunks, the wave-cooperative fold of a wave's 32
+    partial products, and the arrival tree across workgroups - sizes around every boundary (one pair, one wave, several waves,
+    ragged tails, chunks of two and four values per lane pair)"""
+    import torch
+    from bn_amd import distributed as D
+    rng = np.random.default_rng(302)
+    small = _rand_fq12(oracle, rng, 70)
+    for n in (1, 2, 3, 31, 32, 33, 64, 65, 70):
+        assert np.array_equal(_host(te.gt_product(_dev(te, small[:n]))), _fold(oracle, small[:n])), n
+    n = 140000                                                    # chunk 3: 46667 groups, 1459 waves, an 11-level arrival tree
+    P, Q = D.synthetic_points(te, 0, n)
+    vals = te.pairing_batch(P, Q)
+    host = _host(vals)
+    for m in (1000, 4097, 65536, 70001, n):
+        got = _host(te.gt_product(vals[:m].contiguous()))
+        assert np.array_equal(got, _fold(oracle, host[:m])), m
+    # the arrival tree is a race by design (first arriver leaves, second continues): the value must not depend on who wins
+    ref = te.gt_product(vals)
+    for _ in range(20):
+        assert torch.equal(te.gt_product(vals), ref)
+
+
+def test_product_final_exp_tail(oracle, te):
+    """bn254_gt_product_final_exp_dev: what rank 0 runs after the all-gather of the sharded multi-pairing (one launch up to 64 values)"""
+    rng = np.random.default_rng(303)
+    vals = _rand_fq12(oracle, rng, 66)
+    for m in (1, 2, 8, 64, 66):
+        want = oracle.fq12_final_exponentiation(_fold(oracle, vals[:m]))
+        assert np.array_equal(_host(te.product_final_exp(_dev(te, vals[:m]))), want), m
+
+
+def test_single_pairing_latency_path(oracle, te):
+    """n = 1 through every entry point: the by-value `pairing(p, q)` of lib.rs:181-183"""
+    import bn_amd
+    rng = np.random.default_rng(304)
+    k = [int.from_bytes(rng.bytes(40), "little") % M.R_ORD for _ in range(2)]
+    from bn_oracle import FR
+    P = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, k[0])); Q = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_int(FR, k[1]))
+    want = oracle.pairing(P, Q)
+    e = bn_amd.Engine(0)
+    assert np.array_equal(e.pairing_batch(P, Q)[0], want)
+    assert np.array_equal(e.pairing_product(P.reshape(1, 12), Q.reshape(1, 24)), want)
+    e.close()

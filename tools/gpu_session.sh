@@ -8,6 +8,8 @@ export TMPDIR=/tmp
 for s in $steps; do
   case $s in
     tests) timeout 1500 python -m pytest tests -m gpu -x -q > $out/${tag}_tests.log 2>&1; echo "tests rc=$?" | tee -a $out/${tag}_summary.txt; tail -3 $out/${tag}_tests.log | tee -a $out/${tag}_summary.txt ;;
+    wavetests) timeout 900 python -m pytest tests/test_gpu_wave.py -x -q > $out/${tag}_wavetests.log 2>&1; echo "wavetests rc=$?" | tee -a $out/${tag}_summary.txt; tail -15 $out/${tag}_wavetests.log | tee -a $out/${tag}_summary.txt ;;
+    latency) timeout 600 python tools/wave_latency.py > $out/${tag}_latency.json 2> $out/${tag}_latency.err; echo "latency rc=$?" | tee -a $out/${tag}_summary.txt; cat $out/${tag}_latency.json | tee -a $out/${tag}_summary.txt; tail -5 $out/${tag}_latency.err ;;
     bench) timeout 600 python bench.py --steps 20 --warmup 3 > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?" | tee -a $out/${tag}_summary.txt; cat $out/${tag}_bench.json | tee -a $out/${tag}_summary.txt ;;
     side) for w in g1mul g2mul gtpow product prepared; do timeout 300 python bench.py --workload $w --steps 5 --warmup 1 >> $out/${tag}_side.json 2>> $out/${tag}_side.err; done; cat $out/${tag}_side.json | tee -a $out/${tag}_summary.txt ;;
     hostapi) for cfg in "2 0" "1 0" "2 32768" "4 16384"; do set -- $cfg; echo "slots=$1 chunk=$2" >> $out/${tag}_hostapi.txt; BN254_PIPELINE_SLOTS=$1 BN254_PIPELINE_CHUNK=$2 timeout 300 python tools/host_api_rate.py >> $out/${tag}_hostapi.txt 2>&1; done; timeout 300 python tools/host_api_rate.py 1048576 >> $out/${tag}_hostapi.txt 2>&1; cat $out/${tag}_hostapi.txt | tee -a $out/${tag}_summary.txt ;;
