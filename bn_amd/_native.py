@@ -54,6 +54,7 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_synthetic_scalars_dev": [_VP, C.c_uint64, C.c_uint64, _SZ, C.c_int, _VP, _VP],
     "bn254_tile_dev": [_VP, _VP, _SZ, _SZ, _VP, _VP],
     "bn254_ubench_mac32": [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "bn254_wave_ubench": [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
     "bn254_gt_mul_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
     "bn254_gt_pow_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
     "bn254_pairing_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],

@@ -264,11 +264,11 @@ int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t
     hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
-// Up to this many final exponentiations per call run ONE PER WAVE (bn254_kernels_w.hip: ~0.45 ms whatever the count, while a
-// lane pair needs 2.1 ms for its serial chain); above it the lane-pair kernel's throughput wins.  BN254_WAVE_FE_MAX overrides.
+// Up to this many final exponentiations per call run ONE PER WAVE (bn254_kernels_w.hip: 0.6 ms up to 1024 - one wave per SIMD -
+// while a lane pair needs 2.05 ms for its serial chain); beyond ~2700 the lane-pair kernel's throughput wins (profiles/r03a_*).  BN254_WAVE_FE_MAX overrides.
 size_t bn_wave_fe_max() {
     const char *e = getenv("BN254_WAVE_FE_MAX");
-    return e ? (size_t)atol(e) : 512;
+    return e ? (size_t)atol(e) : 1024;
 }
 // table: the caller's own table buffer (pipelined path: one per chunk in flight) or NULL for the context's (under a BnScratchGuard)
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table) {
@@ -753,6 +753,27 @@ int bn254_profile_reset(bn254_ctx *ctx) {
     ctx->recs.clear();
     ctx->folded.clear();
     return BN254_OK;
+}
+// per-program time of the wave-cooperative machine on ONE wave (bn254_wave_ubench_W): ms for `iters` runs of program `which`
+int bn254_wave_ubench(bn254_ctx *ctx, int which, int iters, double *ms_out) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (which < 0 || which > 4 || iters < 1 || !ms_out) return BN254_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BnDeviceGuard dev_guard;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->stage[0].reserve(4096))) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    rc = bn254_launch_wave_ubench_W(which, 1, ctx->stage[0].p, ctx->stream);           // warm-up (code and tables into the caches)
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    if (!rc) rc = bn254_launch_wave_ubench_W(which, iters, ctx->stage[0].p, ctx->stream);
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_out = ms;
+    return rc;
 }
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;

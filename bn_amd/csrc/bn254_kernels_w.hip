@@ -89,6 +89,20 @@ __global__ void __launch_bounds__(64) bn254_gt_tail_W(const uint32_t *in, uint32
     w_store_f12(w, OFF_RES, out + 96u * blockIdx.x);
 }
 
+// measurement: `iters` runs of one program on one wave (which: 0 cyclotomic squaring = 2 phases, 1 product = 3 phases, 2 slot copy =
+// 1 COMB phase, 3 Frobenius map = 1 PROD phase with conjugation, 4 the whole final exponentiation)
+__global__ void __launch_bounds__(64) bn254_wave_ubench_W(int which, int iters, uint32_t *out) {
+    __shared__ WaveLds lds;
+    WaveDev w = wave_init(lds);
+    w.sync();
+    if (threadIdx.x < 12) w.st(OFF_RES + 8u * (threadIdx.x >> 1), w.ld((uint32_t)KBASE_OFF[1] + 8u * (threadIdx.x >> 1) + 8u));
+    w.sync();
+    const uint32_t *prog = which == 0 ? PROG_CYC : which == 1 ? PROG_MUL : which == 2 ? PROG_PUT0 : which == 3 ? PROG_FROB1 : PROG_FE;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) w_run(w, prog);
+    w_store_f12(w, OFF_RES, out);
+}
+
 // ---- the multi-pairing product tree in ONE launch (lane chunks -> wave -> grid, last arriver continues) ------------
 // in[0..n) Fq12 values (384-byte images) -> out[0] = their product (fq12.rs:295-307 folded, shootout/main.rs:11-16; the order is
 // free: Fq12 is commutative and every value is exact).
@@ -193,7 +207,8 @@ extern "C" {
 // scratch bytes and counter words the product tree needs for `n` values in groups of `chunk`
 void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, size_t *grid, size_t *scratch_bytes, size_t *counter_words) {
     const size_t groups = (n + chunk - 1) / chunk, waves = (groups + 31) / 32;
-    *grid = waves; *scratch_bytes = 2 * waves * NODE_DWORDS * sizeof(uint32_t); *counter_words = waves + 1;
+    // tree levels have ceil(c/2) nodes each: sum over levels of the values published <= 2 waves + log2(waves), tickets <= waves + log2(waves)
+    *grid = waves; *scratch_bytes = (2 * waves + 64) * NODE_DWORDS * sizeof(uint32_t); *counter_words = waves + 64;
 }
 int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, void *scratch, void *counters, void *out, hipStream_t s) {
     size_t grid, sb, cw;
@@ -201,6 +216,10 @@ int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, void *scr
     hipError_t e = hipMemsetAsync(counters, 0, cw * sizeof(uint32_t), s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bn254_gt_reduce_W, dim3((unsigned)grid), dim3(64), 0, s, (const uint32_t *)in, (uint32_t)n, chunk, (uint32_t *)scratch, (uint32_t *)counters, (uint32_t *)out);
+    return (int)hipGetLastError();
+}
+int bn254_launch_wave_ubench_W(int which, int iters, void *out, hipStream_t s) {
+    hipLaunchKernelGGL(bn254_wave_ubench_W, dim3(1), dim3(64), 0, s, which, iters, (uint32_t *)out);
     return (int)hipGetLastError();
 }
 int bn254_launch_final_exp_W(const void *f, void *out, size_t n, hipStream_t s) {

@@ -156,6 +156,7 @@ size_t bn254_gt_pow_table_bytes_B(size_t n);
 int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, hipStream_t s);
 int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s);
 // bn254_kernels_w.hip: one Fq12 per wave (wave.hpp)
+int bn254_launch_wave_ubench_W(int which, int iters, void *out, hipStream_t s);
 int bn254_launch_final_exp_W(const void *f, void *out, size_t n, hipStream_t s);
 int bn254_launch_gt_tail_W(const void *in, size_t groups, unsigned m, void *out, int final_exp, hipStream_t s);
 void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, size_t *grid, size_t *scratch_bytes, size_t *counter_words);

@@ -246,6 +246,12 @@ class Engine:
         _native.check(self._lib.bn254_ubench_mac32(self._h, int(waves_per_simd), int(iters), C.byref(g), C.byref(ms)))
         return g.value, ms.value
 
+    def wave_ubench(self, which, iters=200):
+        """microseconds per run of one program of the wave-cooperative machine on a single wave"""
+        ms = C.c_double()
+        _native.check(self._lib.bn254_wave_ubench(self._h, int(which), int(iters), C.byref(ms)))
+        return ms.value * 1e3 / iters
+
     def profile(self, on=True):
         _native.check(self._lib.bn254_profile_enable(self._h, 1 if on else 0))
 

@@ -193,6 +193,9 @@ int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uin
    `waves_per_simd` resident waves: G lane-MACs per second over the whole chip and the kernel's duration.  bench.py prints it
    as the same-run `roofline.peak`. */
 int bn254_ubench_mac32(bn254_ctx *ctx, int waves_per_simd, int iters, double *gmac_per_s, double *ms);
+/* the wave-cooperative machine on one wave: milliseconds for `iters` runs of program `which` (0 cyclotomic squaring, 1 Fq12
+   product, 2 slot copy, 3 Frobenius map, 4 whole final exponentiation) - the per-phase costs quoted in DESIGN.md */
+int bn254_wave_ubench(bn254_ctx *ctx, int which, int iters, double *ms);
 
 #ifdef __cplusplus
 }
