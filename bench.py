@@ -8,13 +8,17 @@ A "step" is one pass of `pairing_batch` over one batch of synthetic (r*G1, s*G2)
   N = 1   BASELINE.json configs[1]: 2^16 independent pairings on one MI355X;
   N > 1   BASELINE.json configs[2]: 2^20 independent pairings sharded over the N GPUs (2^20/N each, contiguous index ranges, no
           data-path collective) - total work fixed, so "scaling": "strong".
-Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     the dominant kernel's algorithmic 32x32->64 MACs per launch / its HIP-event-measured duration, against the
+Rank 0 prints ONE JSON line.  The K steps are timed with the library's event profiling OFF; the per-kernel durations behind
+`roofline` come from a separate short profiled pass right after.  Extra objects:
+  roofline     the dominant kernel's algorithmic 32x32->64 MACs per step / its HIP-event-measured duration, against the
                v_mad_u64_u32 issue peak of the chip MEASURED IN THIS RUN (bn254_ubench_mac32 in the untimed prologue; this path is
                integer-VALU bound, not HBM or MFMA: SURVEY.md 8d); `traffic` is the rocprofv3 HBM byte count per launch taken
                from profiles/ (a separate --pmc run, not this run - `traffic_source` says which)
   host_api     PCIe-inclusive rate of the host-buffer entry point bn254_pairing_batch on pageable numpy buffers (never `value`)
   cpu_baseline the reference-faithful CPU port (oracle/) timed on this box's host cores on a bounded sample
+  side         (N = 1, default workload) the other BASELINE configs that fit one GPU, each measured in a few steps after the
+               headline: configs[4] 2^20 G1 scalar multiplications, configs[3] the 2^18-pair multi-pairing and its 2^15 per-GPU
+               shard, and the latency of ONE pairing - never part of `value`
 Side workloads (--workload g1mul | g2mul | gtpow | prepared | product) print the same kind of line for their own metric.
 """
 import argparse
@@ -37,10 +41,15 @@ PRODUCT_TOTAL = 1 << 18       # configs[3]
 MAC32_PER_FQMUL = 136
 MAC32_PER_PAIRING = 2.583e6
 KERNEL_SHARE = {"miller": 9919 / 18686, "final_exp": 8767 / 18686}
-MAC32_PER_G1MUL = 3817 * MAC32_PER_FQMUL      # 255 x dbl-2009-l (2M+5S) + 127 x add-2007-bl (11M+5S), groups/mod.rs:228-311
-MAC32_PER_G2MUL = 9541 * MAC32_PER_FQMUL      # the same chain over Fq2 (M = 3, S = 2 Fq products)
-MAC32_PER_GTPOW = 16128 * MAC32_PER_FQMUL     # 256 Fq12 squarings (36) + 128 Fq12 products (54), fields/mod.rs:35-46
 ALGO_BYTES_PER_PAIRING = 672
+# Side kernels: Fq-product equivalents per unit of (a) the REFERENCE's chain (groups/mod.rs:228-311 double-and-add: 255 doublings +
+# 127 additions on average; fields/mod.rs:35-46: 256 Fq12 squarings + 128 products) and (b) the chain the kernel actually EXECUTES
+# (GLV + Booth windows for G1, windows for G2 and Gt::pow), counted by the host simulation of the device code (fe_mul + 1.5 x
+# fe_mul2 per unit; tests/test_hostsim.py::test_executed_chain_lengths keeps profiles/executed_chain_lengths.json honest).
+# `roofline.frac` of a side kernel is over (b) - what the hardware is asked to do - and `frac_vs_reference_chain` over (a); (a) can
+# exceed the peak when the kernel's chain is shorter than the reference's, (b) cannot.
+FQMUL_REF = {"g1_mul": 3817, "g2_mul": 9541, "gt_pow": 16128}
+FQMUL_OWN = json.loads((ROOT / "profiles" / "executed_chain_lengths.json").read_text())["fq_products_per_unit"]
 
 
 def _barrier(dist, dev):
@@ -64,26 +73,54 @@ def _max_over_ranks(dist, dev, elapsed):
     return float(t.item())
 
 
+def timed_steps(dist, dev, fn, steps, warmup):
+    """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks"""
+    for _ in range(warmup):
+        fn()
+    _barrier(dist, dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    _barrier(dist, dev)
+    return _max_over_ranks(dist, dev, time.perf_counter() - t0)
+
+
+def kernel_times(eng, dev, fn, names, steps):
+    """a SEPARATE profiled pass (event pairs around every launch): {name: (total_ms, launches)} over `steps` steps"""
+    import torch
+    eng.e.profile(True); eng.e.profile_reset()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    eng.e.profile(False)
+    st = {k: eng.e.kernel_stats(k) for k in names}
+    return {k: v for k, v in st.items() if v[1]}
+
+
+_PEAK = {}
+
+
 def measured_peak(eng):
-    """same-run ceiling: G lane-MAC32/s of a pure v_mad_u64_u32 stream at 8 waves/SIMD (the chip's issue peak) and at the 2
+    """same-run ceiling: T lane-MAC32/s of a pure v_mad_u64_u32 stream at 8 waves/SIMD (the chip's issue peak) and at the 2
     waves/SIMD the pairing kernels run at (256 VGPRs each)"""
-    best8 = max(eng.e.ubench_mac32(8, 1 << 14)[0] for _ in range(3))
-    best2 = max(eng.e.ubench_mac32(2, 1 << 14)[0] for _ in range(3))
-    return best8 / 1e3, best2 / 1e3            # T MAC32/s
+    if "v" not in _PEAK:
+        best8 = max(eng.e.ubench_mac32(8, 1 << 14)[0] for _ in range(3))
+        best2 = max(eng.e.ubench_mac32(2, 1 << 14)[0] for _ in range(3))
+        _PEAK["v"] = (best8 / 1e3, best2 / 1e3)
+    return _PEAK["v"]
 
 
-def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=None):
-    """roofline object for the dominant kernel among `stats` = {name: (total_ms, launches)}"""
+def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=None, steps=1, ref_mac32_per_unit=None):
+    """roofline object for the dominant kernel among `stats` = {name: (total_ms, launches)}.  Each kernel processed `unit_count` units
+    per step (a step may be several sub-launches of one machine round: bn_sub_launch in csrc/bn254_hip.hip) over `steps` recorded
+    steps: achieved = units x steps x algorithmic MAC32 per unit / total kernel time."""
     peak8, peak2 = measured_peak(eng)
     dom = max(stats, key=lambda k: stats[k][0])
     per = {}
     for k, (ms, cnt) in stats.items():
-        if not cnt:
-            continue
-        avg = ms * 1e-3 / cnt
-        share = shares[k] if shares else 1.0
-        ach = unit_count * mac32_per_unit * share / avg / 1e12
-        per[k] = {"avg_launch_ms": avg * 1e3, "launches": cnt, "achieved": ach, "frac": ach / peak8}
+        share = shares.get(k, 1.0) if shares else 1.0
+        ach = unit_count * steps * mac32_per_unit * share / (ms * 1e-3) / 1e12
+        per[k] = {"avg_launch_ms": ms / cnt, "launches": cnt, "ms_per_step": ms / steps, "achieved": ach, "frac": ach / peak8}
     traffic, src = None, None
     tf = ROOT / "profiles" / "pmc_traffic.json"
     if traffic_key and tf.exists():
@@ -91,11 +128,17 @@ def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=No
         traffic = ent.get("hbm_bytes_per_launch")
         src = (ent.get("source", "profiles/pmc_traffic.json") + " (separate rocprofv3 --pmc run at 2^16 pairings per launch, NOT this run)") if traffic else None
     d = per[dom]
-    return {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": d["achieved"], "peak": peak8,
-            "unit": "TMAC32/s", "frac": d["frac"],
-            "peak_source": "bn254_ubench_mac32 in this run: pure v_mad_u64_u32 stream, 8 waves/SIMD",
-            "peak_at_kernel_occupancy": peak2, "kernel_occupancy_waves_per_simd": 2, "frac_of_occupancy_peak": d["achieved"] / peak2,
-            "traffic": traffic, "traffic_source": src, "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"], "kernels": per}
+    out = {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": d["achieved"], "peak": peak8,
+           "unit": "TMAC32/s", "frac": d["frac"],
+           "achieved_is": "Fq products of the chain x 136 MAC32 (an 8 x 32-bit-limb Montgomery product) / measured kernel time",
+           "peak_source": "bn254_ubench_mac32 in this run: pure v_mad_u64_u32 stream, 8 waves/SIMD",
+           "peak_at_kernel_occupancy": peak2, "kernel_occupancy_waves_per_simd": 2, "frac_of_occupancy_peak": d["achieved"] / peak2,
+           "traffic": traffic, "traffic_source": src, "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"], "kernels": per}
+    if ref_mac32_per_unit:
+        out["frac_vs_reference_chain"] = d["frac"] * ref_mac32_per_unit / mac32_per_unit
+        out["frac_is"] = ("over the Fq products of the chain this kernel EXECUTES (profiles/executed_chain_lengths.json); frac_vs_reference_chain "
+                          "counts the reference's longer double-and-add / square-and-multiply chain instead and may exceed 1")
+    return out
 
 
 def cpu_baseline(batch_p, batch_q):
@@ -108,13 +151,13 @@ def cpu_baseline(batch_p, batch_q):
     t0 = time.perf_counter(); o.pairing_batch(batch_p[:8], batch_q[:8], nthreads=1); t1 = (time.perf_counter() - t0) / 8
     n = int(min(len(batch_p), max(cores, min(4096, 20.0 / t1))))   # ~20 s of single-thread work
     t0 = time.perf_counter(); o.pairing_batch(batch_p[:n], batch_q[:n], nthreads=cores); dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "pairings/s", "cores": cores, "kind": "port", "one_thread_ms_per_pairing": t1 * 1e3,
             "sample": f"{n} pairings of the same synthetic batch on {cores} threads ({dt:.2f} s wall); 1 thread: {t1 * 1e3:.2f} ms/pairing"}
 
 
 def host_api_rate(gpu_index, Pn, Qn, reps=5):
     """what a binding of the reference's `pairing` gets: pageable host buffers in and out through bn254_pairing_batch (chunked,
-    copies of one chunk overlapped with the kernels of the other)"""
+    copies of one chunk overlapped with the kernels of the other); and the latency of ONE by-value pairing(p, q) (lib.rs:181-183)"""
     import bn_amd
     import numpy as np
     e = bn_amd.Engine(gpu_index)
@@ -125,9 +168,14 @@ def host_api_rate(gpu_index, Pn, Qn, reps=5):
     for _ in range(reps):
         e.pairing_batch(Pn, Qn, out)
     dt = (time.perf_counter() - t0) / reps
+    e.pairing_batch(Pn[:1], Qn[:1], out[:1])
+    t0 = time.perf_counter()
+    for _ in range(20):
+        e.pairing_batch(Pn[:1], Qn[:1], out[:1])
+    one = (time.perf_counter() - t0) / 20
     e.close()
-    return {"value": n / dt, "unit": "pairings/s", "ms_per_call": dt * 1e3,
-            "what": f"bn254_pairing_batch, {n} pairings per call, pageable numpy buffers: H2D {n * 288 / 1e6:.1f} MB + kernels + D2H {n * 384 / 1e6:.1f} MB"}
+    return {"value": n / dt, "unit": "pairings/s", "ms_per_call": dt * 1e3, "single_pairing_ms": one * 1e3,
+            "what": f"bn254_pairing_batch, {n} pairings per call, pageable numpy buffers: H2D {n * 288 / 1e6:.1f} MB + kernels + D2H {n * 384 / 1e6:.1f} MB; single_pairing_ms: the same call with n = 1"}
 
 
 def _line(metric, unit, value, world, args, elapsed, scaling, workload, extra=None, cfg=None):
@@ -138,30 +186,29 @@ def _line(metric, unit, value, world, args, elapsed, scaling, workload, extra=No
     return d
 
 
-def bench_mul(args, eng, dev, world, rank, which):
-    """side metrics: BASELINE.json configs[4] - 2^20 normalized G1 scalar multiplications of DISTINCT random points by distinct
-    random Fr on one GPU (benches/api.rs:107-111) - and the same for G2 (2^18)"""
-    import torch.distributed as dist
+# ------------------------------------------------------------------------------------------------------------ side workloads
+def run_mul(eng, dev, dist, which, n, lo, steps, warmup):
+    """n normalized scalar multiplications of DISTINCT random points by distinct random Fr (benches/api.rs:107-111)"""
     from bn_amd import distributed as D
-    n = (1 << 20) if which == 1 else (1 << 18)
-    lo = rank * n
     P, Q = D.synthetic_points(eng, lo, lo + n)                              # distinct points r_i*G, Jacobian z != 1
     pts = P if which == 1 else Q
     k = D.synthetic_scalars_device(eng, (1 << 24) + lo, (1 << 24) + lo + n, 1)    # distinct scalars, another index range
     fn = eng.g1_mul if which == 1 else eng.g2_mul
     name = "g1_mul" if which == 1 else "g2_mul"
-    for _ in range(args.warmup):
-        fn(pts, k)
-    eng.e.profile(True); eng.e.profile_reset()
-    _barrier(dist, dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fn(pts, k)
-    _barrier(dist, dev)
-    elapsed = _max_over_ranks(dist, dev, time.perf_counter() - t0)
-    eng.e.profile(False)
+    step = lambda: fn(pts, k)
+    elapsed = timed_steps(dist, dev, step, steps, warmup)
+    ks = min(steps, 5)
+    st = kernel_times(eng, dev, step, (name,), ks)
+    rf = roofline(eng, st, n, FQMUL_OWN[name] * MAC32_PER_FQMUL, steps=ks, ref_mac32_per_unit=FQMUL_REF[name] * MAC32_PER_FQMUL)
+    return elapsed, rf
+
+
+def bench_mul(args, eng, dev, world, rank, which):
+    """side metrics: BASELINE.json configs[4] - 2^20 normalized G1 scalar multiplications on one GPU - and the same for G2 (2^18)"""
+    import torch.distributed as dist
+    n = (1 << 20) if which == 1 else (1 << 18)
+    elapsed, rf = run_mul(eng, dev, dist, which, n, rank * n, args.steps, args.warmup)
     if rank == 0:
-        rf = roofline(eng, {name: eng.e.kernel_stats(name)}, n, MAC32_PER_G1MUL if which == 1 else MAC32_PER_G2MUL)
         print(json.dumps(_line(f"BN254 G{which} scalar multiplications/sec (normalized output, bit-exact vs ref)", "scalar muls/s",
                                world * n * args.steps / elapsed, world, args, elapsed, "weak",
                                f"{n} G{which} scalar muls of distinct random points by distinct random Fr per GPU per step"
@@ -177,70 +224,85 @@ def bench_gtpow(args, eng, dev, world, rank):
     P, Q = D.synthetic_points(eng, lo, lo + n)
     g = eng.pairing_batch(P, Q)
     k = D.synthetic_scalars_device(eng, (1 << 24) + lo, (1 << 24) + lo + n, 0)
-    for _ in range(args.warmup):
-        eng.gt_pow(g, k)
-    eng.e.profile(True); eng.e.profile_reset()
-    _barrier(dist, dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.gt_pow(g, k)
-    _barrier(dist, dev)
-    elapsed = _max_over_ranks(dist, dev, time.perf_counter() - t0)
-    eng.e.profile(False)
+    step = lambda: eng.gt_pow(g, k)
+    elapsed = timed_steps(dist, dev, step, args.steps, args.warmup)
     if rank == 0:
-        rf = roofline(eng, {"gt_pow": eng.e.kernel_stats("gt_pow")}, n, MAC32_PER_GTPOW)
+        ks = min(args.steps, 5)
+        st = kernel_times(eng, dev, step, ("gt_pow",), ks)
+        rf = roofline(eng, st, n, FQMUL_OWN["gt_pow"] * MAC32_PER_FQMUL, steps=ks, ref_mac32_per_unit=FQMUL_REF["gt_pow"] * MAC32_PER_FQMUL)
         print(json.dumps(_line("BN254 Gt::pow/sec (bit-exact vs ref)", "pows/s", world * n * args.steps / elapsed, world, args, elapsed,
                                "weak", f"{n} Gt values ^ distinct random Fr per GPU per step", {"roofline": rf})), flush=True)
+
+
+PRODUCT_KERNELS = ("miller", "gt_product", "gt_tail", "final_exp_wave", "final_exp")
+
+
+def run_product(eng, dev, dist, P, Q, steps, warmup):
+    from bn_amd import distributed as D
+    step = lambda: D.pairing_product_sharded(eng, P, Q)
+    elapsed = timed_steps(dist, dev, step, steps, warmup)
+    ks = min(steps, 3)
+    st = kernel_times(eng, dev, step, PRODUCT_KERNELS, ks)
+    return elapsed, {k: v[0] / ks for k, v in st.items()}
 
 
 def bench_product(args, eng, dev, world, rank):
     """side metric: BASELINE.json configs[3] - multi-pairing product of 2^18 pairs -> ONE Gt, sharded 2^18/N per GPU; the only
     workload with an exchange step: one RCCL all-gather of 384 B per rank, then world-1 Fq12 products and a single final
-    exponentiation"""
+    exponentiation (one wave-cooperative launch)"""
     import torch.distributed as dist
     from bn_amd import distributed as D
     lo, hi = D.shard_range(PRODUCT_TOTAL, rank, world)
     P, Q = D.synthetic_points(eng, lo, hi)
-    for _ in range(args.warmup):
-        D.pairing_product_sharded(eng, P, Q)
-    _barrier(dist, dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        D.pairing_product_sharded(eng, P, Q)
-    _barrier(dist, dev)
-    elapsed = _max_over_ranks(dist, dev, time.perf_counter() - t0)
+    elapsed, kms = run_product(eng, dev, dist, P, Q, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps(_line("BN254 pairs/sec folded into one multi-pairing product (bit-exact vs ref)", "pairs/s",
                                PRODUCT_TOTAL * args.steps / elapsed, world, args, elapsed, "strong",
-                               f"product of 2^18 pairs -> 1 Gt, {hi - lo} pairs per GPU (BASELINE.json configs[3]); all_gather of 384 B per rank")), flush=True)
+                               f"product of 2^18 pairs -> 1 Gt, {hi - lo} pairs per GPU (BASELINE.json configs[3]); all_gather of 384 B per rank",
+                               {"kernel_ms_per_step": kms}, {"process_group": (dist.get_backend() if dist.is_initialized() else None)})), flush=True)
 
 
 def bench_prepared(args, eng, dev, world, rank):
     """side metric: prepared-G2 mode - 2^16 pairings of random P against ONE precomputed Q per GPU per step"""
-    import torch
+    import torch.distributed as dist
     from bn_amd import distributed as D
     n = args.batch or BATCH
     P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
     coeffs = eng.empty(102, 24)
     eng.e.g2_precompute_dev(Q.data_ptr(), coeffs.data_ptr(), 1, eng._stream())
     out = eng.empty(n, 48)
+
     def step():
         eng.e.miller_prepared_dev(P.data_ptr(), coeffs.data_ptr(), True, out.data_ptr(), n, eng._stream())
         eng.e.final_exp_batch_dev(out.data_ptr(), out.data_ptr(), n, eng._stream())
-    for _ in range(args.warmup):
-        step()
-    eng.e.profile(True); eng.e.profile_reset()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(dist, dev, step, args.steps, args.warmup)
     if rank == 0:
-        st = {k: eng.e.kernel_stats(k) for k in ("miller_prepared", "final_exp")}
+        st = kernel_times(eng, dev, step, ("miller_prepared", "final_exp"), min(args.steps, 5))
         print(json.dumps(_line("BN254 pairings/sec against one prepared G2 point (bit-exact vs ref)", "pairings/s", world * n * args.steps / elapsed,
                                world, args, elapsed, "weak", f"{n} random P against one precomputed Q (102 x 192 B coefficients shared by all lanes)",
                                {"kernel_ms": {k: v[0] / max(v[1], 1) for k, v in st.items()}})), flush=True)
+
+
+def side_object(eng, dev, dist, P16, Q16):
+    """the BASELINE configs besides the headline that fit one GPU, a few steps each (never part of `value`)"""
+    from bn_amd import distributed as D
+    side = {}
+    n = 1 << 20
+    elapsed, rf = run_mul(eng, dev, dist, 1, n, 0, 3, 1)
+    side["g1mul_2_20"] = {"config": "BASELINE.json configs[4]: 2^20 G1 scalar muls by random Fr, 1 MI355X", "value": n * 3 / elapsed, "unit": "scalar muls/s",
+                          "ms_per_step": elapsed / 3 * 1e3, "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "frac_vs_reference_chain", "avg_launch_ms")}}
+    P, Q = D.synthetic_points(eng, 0, PRODUCT_TOTAL)
+    for tag, m, what in (("product_2_18", PRODUCT_TOTAL, "BASELINE.json configs[3] on ONE GPU: multi-pairing product of 2^18 pairs -> 1 Gt"),
+                         ("product_2_15", PRODUCT_TOTAL // 8, "the per-GPU shard of configs[3] at 8 GPUs: 2^15 pairs -> 1 Gt (Miller loops, one-launch product tree, one final exponentiation)")):
+        elapsed, kms = run_product(eng, dev, dist, P[:m], Q[:m], 3, 1)
+        side[tag] = {"config": what, "value": m * 3 / elapsed, "unit": "pairs/s", "ms_per_step": elapsed / 3 * 1e3, "kernel_ms_per_step": kms}
+    out1 = eng.empty(1, 48)
+    step = lambda: eng.pairing_batch(P16[:1], Q16[:1], out1)
+    elapsed = timed_steps(dist, dev, step, 20, 3)
+    side["single_pairing"] = {"config": "BASELINE.json configs[0] on the GPU: ONE pairing, device-resident (the reference's by-value pairing(p, q))",
+                              "latency_ms": elapsed / 20 * 1e3,
+                              "kernel_ms": {k: v[0] / 5 for k, v in kernel_times(eng, dev, step, ("miller", "final_exp_wave", "final_exp"), 5).items()}}
+    return side
 
 
 def relaunch_under_torchrun(n):
@@ -262,6 +324,7 @@ def main():
     ap.add_argument("--mapping", type=int, default=None, help="0: one lane per pairing, 1: lane pair per pairing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the `side` object (configs[3], configs[4], single-pairing latency) of the default line")
     ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product"], default="pairing",
                     help="pairing: the headline metric (default); the others are side metrics with their own line")
     args = ap.parse_args()
@@ -283,14 +346,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: bn_amd has no CPU path")
-    # Test hooks for a ONE-GPU box (never set by the driver): all ranks share cuda:0 and rendezvous over gloo, which exercises
-    # the N>1 control flow (shards, barriers, MAX over ranks, rank-0 line) without RCCL's one-GPU-per-rank requirement.
+    # Test hooks for a ONE-GPU box (never set by the driver): BN254_BENCH_SHARE_GPU=1 puts all ranks on cuda:0 and
+    # BN254_BENCH_BACKEND=gloo rendezvous over gloo, which exercises the N>1 control flow (shards, barriers, MAX over ranks, rank-0
+    # line) without RCCL's one-GPU-per-rank requirement; BN254_BENCH_FORCE_DIST=1 initialises the RCCL process group even at
+    # world 1, so that init_process_group("nccl"), barrier(device_ids), all_reduce(MAX) on a device tensor and
+    # all_gather_into_tensor through RCCL execute on a one-GPU box exactly as they will on eight.
     share_gpu = os.environ.get("BN254_BENCH_SHARE_GPU") == "1"
     backend = os.environ.get("BN254_BENCH_BACKEND", "nccl")
+    force_dist = os.environ.get("BN254_BENCH_FORCE_DIST") == "1"
     gpu_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
-    if world > 1:
+    if world > 1 or force_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -319,26 +393,17 @@ def main():
             workload = f"2^20 independent pairings per step sharded over {world} MI355X, {n} per GPU, contiguous ranges (BASELINE.json configs[2])"
         P, Q = D.synthetic_points(eng, lo, lo + n)              # untimed: inputs resident in HBM before the clock starts
         out = eng.empty(n, 48)
-
-        for _ in range(args.warmup):
-            D.pairing_batch_sharded(eng, P, Q, out)
-        eng.e.profile(True); eng.e.profile_reset()
-        _barrier(dist, dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            D.pairing_batch_sharded(eng, P, Q, out)
-        _barrier(dist, dev)
-        elapsed = time.perf_counter() - t0
-        eng.e.profile(False)
-        elapsed = _max_over_ranks(dist, dev, elapsed)
+        step = lambda: D.pairing_batch_sharded(eng, P, Q, out)
+        elapsed = timed_steps(dist, dev, step, args.steps, args.warmup)          # profiling OFF inside the timed region
 
         if rank == 0:
-            stats = {k: eng.e.kernel_stats(k) for k in ("miller", "final_exp", "pairing_fused")}
-            stats = {k: v for k, v in stats.items() if v[1]}            # "pairing_fused": the BN254_FUSED=1 experiment (one kernel)
-            rf = roofline(eng, stats, n, MAC32_PER_PAIRING, dict(KERNEL_SHARE, pairing_fused=1.0), traffic_key=True)
+            ksteps = min(args.steps, 10)
+            stats = kernel_times(eng, dev, step, ("miller", "final_exp", "final_exp_wave"), ksteps)
+            rf = roofline(eng, stats, n, MAC32_PER_PAIRING, dict(KERNEL_SHARE, final_exp_wave=KERNEL_SHARE["final_exp"]), traffic_key=True, steps=ksteps)
             rf["algorithmic_hbm_bytes_per_launch"] = n * ALGO_BYTES_PER_PAIRING
-            if n != BATCH:
-                rf["traffic"] = rf["traffic_source"] = None          # the PMC figures in profiles/ were taken at 2^16 per launch
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            if n != BATCH or cus != 256:
+                rf["traffic"] = rf["traffic_source"] = None          # the PMC figures in profiles/ were taken at 2^16 per launch on 256 CUs
             if rf["traffic"] is not None:
                 rf["hbm_GBps_of_8000"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
             line = _line("BN254 optimal-ate pairings/sec (bit-exact vs ref)", "pairings/s", total * args.steps / elapsed, world, args, elapsed,
@@ -346,18 +411,21 @@ def main():
                          {"pairings_per_gpu": n, "inputs": "r*G1 / s*G2 (Jacobian, z != 1) resident in HBM", "parallelism": f"dp{world} (sharded, no collective)",
                           "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
                           "mapping": 1 if args.mapping is None else args.mapping,
-                          # 2^16 pairings are exactly two waves on each of 1024 SIMDs: a box that exposes fewer than 256 CUs runs the
-                          # remainder in a second round (one box of round 2 ran every 2048-wave kernel 33-100 % slower)
-                          "cus": torch.cuda.get_device_properties(dev).multi_processor_count})
-            if world == 1:
+                          # the lane-pair kernels are launched in rounds of 256 pairings per CU (two waves on every SIMD): the library
+                          # sizes its sub-launches from the CU count of the device it finds (bn_round_pairs in csrc/bn254_hip.hip)
+                          "cus": cus, "pairings_per_launch": n if n <= 256 * cus else f"equal parts of at most {256 * cus}",
+                          "process_group": (dist.get_backend() if dist.is_initialized() else None)})
+            if world == 1 and args.batch is None:
                 Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
+                if not args.no_side:
+                    line["side"] = side_object(eng, dev, dist, P, Q)
                 if not args.no_host_api:
                     line["host_api"] = host_api_rate(gpu_index, Pn, Qn)
                 if not args.no_cpu_baseline:
                     line["cpu_baseline"] = cpu_baseline(Pn[:4096], Qn[:4096])
             print(json.dumps(line), flush=True)
     finally:
-        if world > 1 and dist.is_initialized():
+        if dist.is_initialized():
             dist.destroy_process_group()
 
 

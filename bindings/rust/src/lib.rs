@@ -28,9 +28,10 @@ extern "C" {
     fn bn254_pairing_product_multi(m: *mut c_void, p: *const G1, q: *const G2, n: usize, out: *mut Gt) -> c_int;
 }
 
-// Thread safety: every host-buffer entry point of the C ABI serialises the callers of one context internally (including the
-// process-wide default context behind a NULL ctx), so these safe `pub fn`s may be called from any number of threads, like the
-// crate's own `pairing` (its types are `Send + Sync`, src/lib.rs:55-61).
+// Thread safety: every host-buffer entry point of the C ABI may be called from any number of threads on one context (including the
+// process-wide default context behind a NULL ctx), like the crate's own `pairing` (its types are `Send + Sync`,
+// src/lib.rs:55-61): the batch entry points lease one of two pipeline slots per call (two callers overlap on the GPU, more queue),
+// the others lock the context for the call.
 
 /// Error code of the HIP engine: negative `BN254_E_*`, positive `hipError_t`.  There is no CPU fallback.
 #[derive(Debug, Clone, Copy, PartialEq, Eq)]

@@ -85,8 +85,8 @@ def all_gather_partials(partial, group=None):
     """the ONE exchange step of the multi-pairing: (48,) int64 per rank -> (world, 48)"""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return partial.reshape(1, GT_WORDS)
+    if not (dist.is_available() and dist.is_initialized()):          # no process group: a single process, nothing to exchange
+        return partial.reshape(1, GT_WORDS)                          # (an initialised group of ONE rank still goes through the collective)
     world = dist.get_world_size(group)
     src = partial.contiguous().reshape(GT_WORDS)
     if dist.get_backend(group) != "nccl" and src.is_cuda:          # gloo (tests, one-GPU smoke runs): exchange through the host

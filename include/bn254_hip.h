@@ -32,6 +32,11 @@
  * aborts across this boundary.  Inputs are trusted to be valid subgroup points exactly as the Rust type system guarantees
  * for G1/G2 values; behaviour on other limb patterns is unspecified (but memory safe).
  *
+ * Sizes: n is limited by device memory only.  Batches are cut internally into sub-launches of at most one machine round, and the
+ * context-owned tables (final exponentiation: 4 KB, Gt::pow: 6.9 KB per pairing) are sized for ONE round - 264 MB / 450 MB on an
+ * MI355X whatever n is.  Up to 1024 final exponentiations per call (the tail of every multi-pairing: exactly one) run one per WAVE
+ * instead of one per lane pair: 0.6 ms instead of 2.1 ms.
+ *
  * Ownership: the caller owns every buffer passed in; the library owns device memory and streams inside a context and keeps
  * no pointer after a call returns.  A context is bound to one GPU.  There is NO CPU fallback: without a usable MI355X the
  * calls fail with BN254_E_NO_DEVICE.
@@ -39,9 +44,10 @@
  * Threading (the reference's `pairing` is a pure function and its types are Send + Sync, lib.rs:55-61):
  *   - every HOST-BUFFER entry point is safe to call from any number of threads on the same context, including ctx == NULL
  *     (a process-wide default context per HIP device).  bn254_pairing_batch and bn254_g{1,2}_mul_batch arbitrate per pipeline
- *     slot: two callers with batches of up to 2^16 run concurrently on two streams (the number of streams the GPU overlaps
- *     without loss), further callers and multi-chunk batches queue; every other entry point serialises its callers on the
- *     context.  Use one context per thread (or bn254_multi_*) for more overlap;
+ *     slot: two callers with batches of up to one machine round (256 pairings per CU: 2^16 on an MI355X) run concurrently on two
+ *     streams (the number of streams the GPU overlaps without loss), further callers and multi-chunk batches queue; every other
+ *     entry point serialises its callers on the context.  Use one context per thread (or bn254_multi_*) for more overlap;
+ *     bn254_ctx_set_mapping is atomic, but set it before concurrent use: a call in flight keeps the mapping it started with;
  *   - the *_dev entry points are asynchronous on the caller's stream.  Context-owned scratch (the final-exponentiation table,
  *     the product workspace) is ordered across streams with events, so calls on different streams of one context are safe
  *     and serialise on that scratch; the caller still owns the ordering of its OWN buffers between streams.
@@ -143,7 +149,11 @@ int bn254_g2_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g2 *out, int32_t
 /* the crate's own byte stream (what bincode/rustc_serialize produce for a sequence of points, groups/mod.rs:143-205): a point at
    infinity is the lone byte 0, a finite point is 4 + coordinates, so records have variable length.  encode: `written` bytes are
    produced (BN254_E_BAD_ARG if `cap` is too small).  decode: up to `max_points` points are parsed from `len` bytes; `count` points
-   and `consumed` bytes are reported (a truncated trailing record is left unconsumed); status[i] as for the batch decoders. */
+   and `consumed` bytes are reported (a truncated trailing record is left unconsumed); status[i] as for the batch decoders.
+   DIFFERENCE from the crate: its Decodable returns Err at the first bad record and the caller's stream stops there
+   (groups/mod.rs:165-175); this decoder records the status (a bad tag consumes its one byte, a record that fails a check consumes
+   its full length), decodes the record to G::zero() and CONTINUES with the next one - a caller that wants the crate's behaviour
+   stops at the first non-zero status[i]. */
 int bn254_g1_encode_stream(bn254_ctx *ctx, const bn_g1 *p, size_t n, uint8_t *out, size_t cap, size_t *written);
 int bn254_g2_encode_stream(bn254_ctx *ctx, const bn_g2 *p, size_t n, uint8_t *out, size_t cap, size_t *written);
 int bn254_g1_decode_stream(bn254_ctx *ctx, const uint8_t *in, size_t len, bn_g1 *out, int32_t *status, size_t max_points, size_t *count, size_t *consumed);

@@ -742,3 +742,116 @@ def test_wire_stream_format_on_gpu(oracle, eng):
         assert np.array_equal(out2[1:], out[:out2.shape[0] - 1])
         out3, st3, used3 = decs(got, max_points=5)
         assert out3.shape[0] == 5 and np.array_equal(out3, out[:5])
+
+
+@pytest.mark.parametrize("workload", ["pairing", "product"])
+def test_bench_through_rccl_process_group_at_world_1(workload):
+    """First contact with RCCL through torch.distributed, on the one GPU there is: bench.py with BN254_BENCH_FORCE_DIST=1 runs
+    init_process_group("nccl", device_id), barrier(device_ids), all_reduce(MAX) on a DEVICE tensor and - for the product - the
+    all_gather_into_tensor of the 384-byte partial through RCCL (bn_amd.distributed no longer short-circuits a one-rank group),
+    i.e. every torch.distributed call of the 8-GPU SCALE run except a transfer between two different GPUs"""
+    import json, os, pathlib, subprocess, sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = dict(os.environ, BN254_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BN254_BENCH_BACKEND", "BN254_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--workload", workload,
+                          "--no-side", "--no-host-api", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["process_group"] == "nccl" and d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_rccl_all_gather_of_partials_at_world_1(oracle):
+    """bn_amd.distributed.pairing_product_sharded with a REAL one-rank RCCL group: the partial travels through
+    all_gather_into_tensor on device memory, then the one-launch tail; equal to the oracle's fold"""
+    import os, socket
+    import torch
+    import torch.distributed as dist
+    import bn_amd
+    from bn_amd import distributed as D
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=dev)
+    try:
+        te = D.TorchEngine(bn_amd.Engine(0), dev)
+        P, Q = D.synthetic_points(te, 40, 40 + 77)
+        part = te.miller_product(P, Q)
+        parts = D.all_gather_partials(part)
+        assert parts.shape == (1, 48) and parts.is_cuda and torch.equal(parts[0], part)
+        got = D.pairing_product_sharded(te, P, Q)
+        dist.barrier(device_ids=[0])
+        torch.cuda.synchronize()
+        Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), oracle.pairing_product(Pn, Qn))
+    finally:
+        dist.destroy_process_group()
+        for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE"):
+            os.environ.pop(k, None)
+
+
+def test_multi_device_c_abi_at_config_sizes(oracle):
+    """the C entry points a Rust/C++ host calls, at BASELINE sizes with EIGHT ranks (device list [0]*8: eight contexts, eight host
+    threads, eight shards on the one GPU): bn254_pairing_product_multi on configs[3]'s 2^18 pairs equals the single-context product,
+    bn254_pairing_batch_multi on 2^17 pairs equals the single-context batch and a 2048-index sample equals the oracle"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    te = D.TorchEngine(bn_amd.Engine(0), dev)
+    n = 1 << 18
+    P, Q = D.synthetic_points(te, 0, n)
+    want_prod = D.pairing_product_sharded(te, P, Q)
+    nb = 1 << 17
+    want_batch = te.pairing_batch(P[:nb].contiguous(), Q[:nb].contiguous())
+    torch.cuda.synchronize()
+    Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
+    m = bn_amd.MultiEngine([0] * 8)
+    assert m.exchange == "peer"
+    assert np.array_equal(m.pairing_product(Pn, Qn), want_prod.cpu().numpy().view(np.uint64))
+    got = m.pairing_batch(Pn[:nb], Qn[:nb])
+    assert np.array_equal(got, want_batch.cpu().numpy().view(np.uint64))
+    idx = np.sort(np.random.default_rng(17).choice(nb, 2048, replace=False))
+    assert np.array_equal(got[idx], oracle.pairing_batch(Pn[idx], Qn[idx]))
+    m.close()
+
+
+def test_scratch_is_bounded_by_one_round(oracle):
+    """bn254_pairing_batch_dev on 2^22 pairings: the context's tables are sized for ONE machine round (256 pairings per CU), not for
+    the batch - round 2 allocated 4 KB per pairing (17 GB here).  Device memory taken by the call stays below 1 GB and the result
+    equals the shard-wise one; Gt::pow likewise reuses one bounded window table"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    te = D.TorchEngine(bn_amd.Engine(0), dev)
+    n = 1 << 22
+    base = 1 << 18
+    P0, Q0 = D.synthetic_points(te, 0, base)
+    P = P0.repeat(n // base, 1); Q = Q0.repeat(n // base, 1)            # 2^22 inputs from 2^18 distinct pairs (the point is the size)
+    out = te.empty(n, 48)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    te.pairing_batch(P, Q, out)
+    torch.cuda.synchronize()
+    used = free0 - torch.cuda.mem_get_info(dev)[0]
+    assert used < (1 << 30), f"context scratch grew by {used / 2**20:.0f} MiB"
+    ref = te.pairing_batch(P0, Q0)
+    for rep in (0, 7, 15):
+        assert torch.equal(out[rep * base:(rep + 1) * base], ref)
+    torch.cuda.synchronize()
+    idx = np.sort(np.random.default_rng(19).choice(base, 512, replace=False))
+    Pn = P0.cpu().numpy().view(np.uint64)[idx]; Qn = Q0.cpu().numpy().view(np.uint64)[idx]
+    assert np.array_equal(ref.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn, Qn))
+    k = D.synthetic_scalars_device(te, 1 << 24, (1 << 24) + base, 0)
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    pw = te.gt_pow(ref, k)
+    torch.cuda.synchronize()
+    assert free1 - torch.cuda.mem_get_info(dev)[0] < (1 << 30)
+    small = te.gt_pow(ref[:300].contiguous(), k[:300].contiguous())
+    assert torch.equal(pw[:300], small)

@@ -325,3 +325,27 @@ def test_group_addition_branches(oracle, hs):
         for x, y in ((a, b), (a, a), (a, z), (z, b), (z, z), (b, a)):
             assert np.array_equal(hs.call(fn, x, y, 0, out_words=2 * w), add(x, y))
             assert np.array_equal(hs.call(fn, x, y, 1, out_words=2 * w), add(x, neg(y)))
+
+
+def executed_chain_lengths(oracle, hs):
+    """Fq-product equivalents (fe_mul + 1.5 x fe_mul2, both lanes of a lane pair) of the chains the side kernels execute, counted by
+    the host simulation of the device code on one unit (the control flow is data independent)"""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    k1, k2 = (oracle.fp_from_int(FR, int.from_bytes(rng.bytes(40), "little") % M.R_ORD) for _ in range(2))
+    P = oracle.g1_mul(oracle.g1_one(), k1); Q = oracle.g2_mul(oracle.g2_one(), k1)
+    g = oracle.pairing(P, Q)
+    def count(fn, *args, out_words):
+        hs.lib.hs_counts_reset()
+        hs.call(fn, *args, out_words=out_words)
+        a = (C.c_ulong * 8)(); hs.lib.hs_counts_get(a)
+        return int(a[0] + 1.5 * a[1])
+    return {"g1_mul": count("hs_g1_mul_glv", P, k2, out_words=24), "g2_mul": count("hsb_g2_mul", Q, k2, 2, out_words=48),
+            "gt_pow": count("hsb_gt_pow", g, k2, out_words=96)}
+
+
+def test_executed_chain_lengths(oracle, hs):
+    """bench.py prices the side kernels' `roofline.frac` over the chain they EXECUTE: the committed figures are the simulation's"""
+    import json, pathlib
+    want = json.loads((pathlib.Path(__file__).resolve().parents[1] / "profiles" / "executed_chain_lengths.json").read_text())["fq_products_per_unit"]
+    assert executed_chain_lengths(oracle, hs) == want
