@@ -68,6 +68,7 @@
 #define BN_B_FAIR_SHIFT 21
 #endif
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 __device__ __forceinline__ void bn_fair_priority(int step) {
     const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_ID.wave_id: 0 / 1 for the two resident waves
     if ((step ^ slot) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
@@ -245,38 +246,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // stored as 7 groups of 4 dwords (one pad dword): group-major, then the lane - every access of a wave is ONE global_load/store_dwordx4
 // over 1 KB of contiguous memory (a dword-per-instruction layout costs 27 memory instructions per half; at two waves per SIMD every
 // memory instruction costs the SIMD ~40 cycles, measured on the spills of the Miller kernel).
-#ifdef BN_EXP_TABLE_DWORD            // experiment switch: the round-1 layout, one dword per instruction
-struct ExpTableMem {
-    uint32_t *table;         // wave-uniform base (SGPRs)
-    uint32_t lane;           // this lane's column
-    uint32_t stride;         // lanes in the launch
-    __device__ __forceinline__ uint32_t *row(int slot, int half) const { return table + (size_t)(uint32_t)((slot * 2 + half) * 27) * stride; }
-    __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
-        uint32_t *p = row(slot, half);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            (p + (size_t)i * stride)[lane] = v.c0.v.l[i];
-            (p + (size_t)(9 + i) * stride)[lane] = v.c1.v.l[i];
-            (p + (size_t)(18 + i) * stride)[lane] = v.c2.v.l[i];
-        }
-    }
-    __device__ __forceinline__ Fq6<F2> ld6(int slot, int half) const {
-        const uint32_t *p = row(slot, half);
-        Fq6<F2> v;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            v.c0.v.l[i] = (p + (size_t)i * stride)[lane];
-            v.c1.v.l[i] = (p + (size_t)(9 + i) * stride)[lane];
-            v.c2.v.l[i] = (p + (size_t)(18 + i) * stride)[lane];
-        }
-        return v;
-    }
-    __device__ __forceinline__ void put(int i, const Fq12<F2> &v) const { st6(i, 0, v.c0); st6(i, 1, v.c1); }
-    __device__ __forceinline__ Fq6<F2> c0(int i) const { return ld6(i, 0); }
-    __device__ __forceinline__ Fq6<F2> c1(int i) const { return ld6(i, 1); }
-};
-constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 54;
-#else
 struct ExpTableMem {
     uint4 *table;            // wave-uniform base (SGPRs)
     uint32_t lane;           // this lane's column
@@ -309,7 +278,6 @@ struct ExpTableMem {
     __device__ __forceinline__ Fq6<F2> c1(int i) const { return ld6(i, 1); }
 };
 constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 2 * 7 * 4;
-#endif
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n, uint32_t *table) {
     BN_KERNEL_PROLOGUE();
@@ -318,11 +286,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
-#ifdef BN_EXP_TABLE_DWORD
-    ExpTableMem tbl = {table, t, gridDim.x * BLOCK};
-#else
     ExpTableMem tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
-#endif
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair), tbl);
     if (live) f12_store(f, out + 96u * pair);
     BN_STAMP_END();
@@ -388,28 +352,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // taken out of Montgomery form).  The power is a unique field element, so any addition chain returns the reference's bytes:
 // fixed 4-bit windows, MSB first - 256 squarings + 64 table products + a 14-operation table instead of 256 x (square, multiply,
 // select).  General Fq12 squarings (not cyclotomic ones): correct for ANY non-zero Fq12, like the reference's generic pow.
-// The table a^0 .. a^15 lives in global memory, [lane][entry][54 dwords]: every lane reads the entry of ITS OWN digit as one
-// contiguous 216-byte run (the digits differ per lane, so a slot-major layout would scatter every dword load over 64 rows).
-struct PowTableMem {
-    uint32_t *base;          // this lane's 16 x 54 dwords
-    __device__ __forceinline__ void st6(int e, int half, const Fq6<F2> &v) const {
-        uint32_t *p = base + (e * 2 + half) * 27;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { p[i] = v.c0.v.l[i]; p[9 + i] = v.c1.v.l[i]; p[18 + i] = v.c2.v.l[i]; }
-    }
-    __device__ __forceinline__ Fq6<F2> ld6(int e, int half) const {
-        const uint32_t *p = base + (e * 2 + half) * 27;
-        Fq6<F2> v;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { v.c0.v.l[i] = p[i]; v.c1.v.l[i] = p[9 + i]; v.c2.v.l[i] = p[18 + i]; }
-        return v;
-    }
-    __device__ __forceinline__ void put(int e, const Fq12<F2> &v) const { st6(e, 0, v.c0); st6(e, 1, v.c1); }
-    __device__ __forceinline__ Fq6<F2> c0(int e) const { return ld6(e, 0); }
-    __device__ __forceinline__ Fq6<F2> c1(int e) const { return ld6(e, 1); }
-};
-constexpr size_t POW_TABLE_DWORDS_PER_LANE = 16 * 54;
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table) {
+// The window table lives in global memory in the layout of the exponentiation machine's table (ExpTableMem: entry-major, 16 bytes
+// per lane and access): the table is BUILT with wave-uniform entry numbers (perfectly coalesced dwordx4 stores) and READ with each
+// lane pair's own digit - at most 9 (16) different 1 KB rows per instruction instead of 64 different cache lines with the round-2
+// [lane][entry] layout.  Inputs in the cyclotomic subgroup (checked on the device: every value the reference's API can produce)
+// take the signed-window Granger-Scott chain (pairing.hpp gt_pow_cyclotomic), anything else the general one.
+constexpr size_t POW_TABLE_DWORDS_PER_LANE = 16 * 2 * 7 * 4;
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table, int force_general) {
     BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
@@ -419,8 +368,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 #pragma unroll
     for (int i = 0; i < 8; ++i) kw[i] = k[8u * pair + i];
     fr_from_mont(kw, raw);
-    PowTableMem tbl = {table + (size_t)t * POW_TABLE_DWORDS_PER_LANE};
-    Fq12<F2> res = gt_pow_windowed(f12_load<F2>(a + 96u * pair), raw, tbl);          // pairing.hpp
+    ExpTableMem tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
+    const Fq12<F2> base = f12_load<F2>(a + 96u * pair);
+    Fq12<F2> res;
+    if (!force_general && __all(gt_is_cyclotomic(base))) res = gt_pow_cyclotomic(base, raw, tbl);          // wave-uniform choice
+    else res = gt_pow_windowed(base, raw, tbl);
     if (live) f12_store(res, out + 96u * pair);
 }
 // out[i] = a[i]^-1   (Gt::inverse, lib.rs:172 -> fq12.rs:284-292; one Fq inversion per element, constant-time divsteps)
@@ -458,7 +410,8 @@ size_t bn254_gt_pow_table_bytes_B(size_t n) {
 }
 int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, (uint32_t *)table);
+    static const int force_general = getenv("BN254_GT_POW_GENERAL") ? atoi(getenv("BN254_GT_POW_GENERAL")) : 0;      // A/B experiments
+    hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, (uint32_t *)table, force_general);
     return (int)hipGetLastError();
 }
 int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s) {

@@ -34,7 +34,7 @@ __device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km)
     fr_from_mont(kw, raw);
     if constexpr (NORMALIZE) {
         if constexpr (std::is_same<F, FqField>::value) return jac_normalize<F>(scalar_mul_glv(p, raw));      // G1: GLV + signed windows
-        else return jac_normalize<F>(scalar_mul_windowed<F>(p, raw));
+        else return jac_normalize<F>(scalar_mul_booth_affine<F>(p, raw));
     } else {
         return scalar_mul_reference_chain<F>(p, raw);
     }

@@ -96,6 +96,58 @@ BN_COARSE Jac<F> jac_add_flags(const Jac<F> &p, const Jac<F> &q, bool pz, bool q
     r.x = F::select(pz, r.x, q.x); r.y = F::select(pz, r.y, q.y); r.z = F::select(pz, r.z, q.z);     // :276-278
     return r;
 }
+// Mixed addition p + (q.x, q.y, 1): the same add-2007-bl with Z2 = 1 (8 products + 3 squarings instead of 11 + 5), same special
+// cases.  Used with window tables that were brought to a COMMON z and are therefore affine points of an isomorphic curve (below).
+template <class F> struct Aff { typename F::T x, y; };
+template <class F>
+BN_COARSE Jac<F> jac_madd_flags(const Jac<F> &p, const Aff<F> &q, bool pz, bool qz) {
+    using T = typename F::T;
+    T z1s = F::sqr(p.z);
+    T u2 = F::mul(q.x, z1s), s2 = F::mul(q.y, F::mul(p.z, z1s));
+    T h = F::template lc3<1, -1, 0>(u2, p.x, p.x), sd = F::template lc3<1, -1, 0>(s2, p.y, p.y);
+    bool same = F::is_zero_std(h) && F::is_zero_std(sd) && !pz && !qz;
+    Jac<F> r;
+    { T zh = F::mul(p.z, h); r.z = F::sum(zh, zh); }
+    T i = F::sqr(F::sum(h, h));
+    T j = F::mul(h, i);
+    T v = F::mul(p.x, i);
+    T rr = F::sum(sd, sd);
+    r.x = F::template lc3<1, -1, -2>(F::sqr(rr), j, v);
+    r.y = F::template lc3<1, -2, 0>(F::mul(rr, F::template lc3<1, -1, 0>(v, r.x, v)), F::mul(p.y, j), j);
+    if (same) {
+        const Jac<F> pc = p;
+        Jac<F> d = jac_double_cold(pc);
+        r.x = F::select(same, r.x, d.x); r.y = F::select(same, r.y, d.y); r.z = F::select(same, r.z, d.z);
+    }
+    r.x = F::select(pz, r.x, q.x); r.y = F::select(pz, r.y, q.y); r.z = F::select(pz, r.z, F::one());     // infinity + q = q ...
+    r.x = F::select(qz, r.x, p.x); r.y = F::select(qz, r.y, p.y); r.z = F::select(qz, r.z, p.z);           // ... and p + infinity = p, also when p is infinite
+    return r;
+}
+// Window table -> COMMON z without an inversion.  Entry i = (X_i : Y_i : Z_i) is rescaled by s_i = prod_{j != i} Z_j to
+// (X_i s_i^2 : Y_i s_i^3 : Zc), Zc = prod Z_j.  On the isomorphic curve y^2 = x^3 + b Zc^6 - reached by (x, y) -> (x Zc^2, y Zc^3), and
+// the group law of a curve with a = 0 never looks at b - the rescaled (X, Y) are AFFINE points: the whole chain runs there with
+// mixed additions and the result (X : Y : Z) is the point (X : Y : Z Zc) of the original curve.  Cost: 3N - 4 + 4N products for N
+// entries (52 for N = 8) against 5 saved per addition (66 additions: 330), and a table entry is 2 instead of 3 field elements.
+// (The "effective affine" technique of libsecp256k1's ecmult, with the plain prefix/suffix product instead of its z-ratio chain.)
+// tab[1..N] in, aff[1..N] out; returns Zc.  An infinite input point gives Zc = 0 and the chain's result z = 0: infinity again.
+template <class F, int N>
+BN_FN typename F::T table_to_common_z(const Jac<F> *tab, Aff<F> *aff) {
+    using T = typename F::T;
+    T pre[N + 1];                                             // pre[i] = Z_1 ... Z_i
+    pre[1] = tab[1].z;
+#pragma unroll 1
+    for (int i = 2; i <= N; ++i) pre[i] = F::mul(pre[i - 1], tab[i].z);
+    T suf = F::one();                                         // Z_{i+1} ... Z_N
+#pragma unroll 1
+    for (int i = N; i >= 1; --i) {
+        T s = i > 1 ? F::mul(pre[i - 1], suf) : suf;
+        T s2 = F::sqr(s);
+        aff[i].x = F::mul(tab[i].x, s2);
+        aff[i].y = F::mul(tab[i].y, F::mul(s2, s));
+        if (i > 1) suf = F::mul(suf, tab[i].z);
+    }
+    return pre[N];
+}
 template <class F>
 BN_FN Jac<F> jac_add(const Jac<F> &p, const Jac<F> &q) { return jac_add_flags(p, q, F::is_zero(p.z), F::is_zero(q.z)); }
 
@@ -177,6 +229,43 @@ BN_FN Jac<F> scalar_mul_windowed(const Jac<F> &p, const uint32_t *k_raw) {
         res = jac_add_flags(res, tab[digit], res_inf, q_inf);
         res_inf = res_inf && q_inf;
     }
+    return res;
+}
+// 4-bit SIGNED (Booth) windows over the affine table 1P .. 8P on the isomorphic curve (table_to_common_z): 252 doublings + 64 mixed
+// additions + a table of 4 doublings, 3 additions and 52 products - against scalar_mul_windowed's 64 full additions and 14-operation
+// table of 16 Jacobian entries.  A table entry is 2 field elements and there are 8 of them: a third of the private memory.
+template <class F>
+BN_FN Jac<F> scalar_mul_booth_affine(const Jac<F> &p, const uint32_t *k_raw) {
+    const bool p_inf = F::is_zero(p.z);
+    Jac<F> tab[9];
+    tab[1] = p;
+    tab[2] = jac_double(tab[1]);
+    tab[4] = jac_double(tab[2]);
+    tab[8] = jac_double(tab[4]);
+    tab[3] = jac_add_flags(tab[2], p, p_inf, p_inf);
+    tab[6] = jac_double(tab[3]);
+    tab[5] = jac_add_flags(tab[4], p, p_inf, p_inf);
+    tab[7] = jac_add_flags(tab[6], p, p_inf, p_inf);
+    Aff<F> aff[9];
+    const typename F::T zc = table_to_common_z<F, 8>(tab, aff);
+    aff[0] = {F::zero(), F::one()};
+    Jac<F> res = {F::zero(), F::one(), F::zero()};
+    bool res_inf = true;
+#pragma unroll 1
+    for (int w = 63; w >= 0; --w) {
+        if (w != 63) {
+#pragma unroll 1
+            for (int d = 0; d < 4; ++d) res = jac_double(res);
+        }
+        const int d = booth_digit_256(k_raw, w);               // k < r < 2^254: the top window needs no carry
+        const int ad = d < 0 ? -d : d;
+        Aff<F> q = aff[ad];
+        q.y = F::select(d < 0, q.y, F::template lc3<-1, 0, 0>(q.y, q.y, q.y));
+        const bool q_inf = p_inf || ad == 0;
+        res = jac_madd_flags(res, q, res_inf, q_inf);
+        res_inf = res_inf && q_inf;                             // k < r: a partial sum j P with 0 < j < r is never infinity
+    }
+    res.z = F::mul(res.z, zc);
     return res;
 }
 // ---- G1 only: GLV.  phi(x, y) = (beta x, y) is multiplication by lambda on the order-r subgroup of E(Fq) (beta^3 = 1, lambda^3 = 1),
@@ -267,6 +356,9 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) 
     tab[5] = jac_add_flags(tab[4], p, p_inf, p_inf);
     tab[7] = jac_add_flags(tab[6], p, p_inf, p_inf);
     tab[0] = {F::zero(), F::one(), F::zero()};
+    Aff<F> aff[9];                                            // the table on the isomorphic curve where it is affine (table_to_common_z)
+    const Fe zc = table_to_common_z<F, 8>(tab, aff);
+    aff[0] = {F::zero(), F::one()};
     const Fe beta = fe_const(k::GLV_BETA);
     Jac<F> res = {F::zero(), F::one(), F::zero()};
     bool res_inf = true;
@@ -281,16 +373,17 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) 
             const int d = booth_digit(half ? g.m2 : g.m1, w);
             const int ad = d < 0 ? -d : d;
             const bool negate = (d < 0) != (half ? g.neg2 : g.neg1);
-            Jac<F> q = tab[ad];
-            if (half) q.x = fe_mul(q.x, beta);                    // phi(j P)
+            Aff<F> q = aff[ad];
+            if (half) q.x = fe_mul(q.x, beta);                    // phi(j P): the endomorphism commutes with the isomorphism
             q.y = F::select(negate, q.y, F::template lc3<-1, 0, 0>(q.y, q.y, q.y));
             const bool q_inf = p_inf || ad == 0;
-            res = jac_add_flags(res, q, res_inf, q_inf);
-            // the sum of two finite points may be infinity (opposite points: z = Z1 Z2 H = 0), and partial sums of the two
-            // interleaved scalars can cancel for crafted inputs - so the flag is read off z (a product: normalized, < 2q)
+            res = jac_madd_flags(res, q, res_inf, q_inf);
+            // the sum of two finite points may be infinity (opposite points: z = 2 Z1 H = 0), and partial sums of the two
+            // interleaved scalars can cancel for crafted inputs - so the flag is read off z (a carry-propagated sum of two products)
             res_inf = F::is_zero_std(res.z);
         }
     }
+    res.z = fe_mul(res.z, zc);                                    // back from the isomorphic curve
     return res;
 }
 

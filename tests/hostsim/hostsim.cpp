@@ -92,7 +92,7 @@ static void hs_mul_generic(const uint32_t *pt, const uint32_t *k, uint32_t *o, i
     Jac<F> p = {ld(pt), ld(pt + W), ld(pt + 2 * W)};
     uint32_t raw[8];
     fr_from_mont(k, raw);
-    Jac<F> r = normalize == 2 ? scalar_mul_windowed<F>(p, raw) : scalar_mul_reference_chain<F>(p, raw);
+    Jac<F> r = normalize == 3 ? scalar_mul_booth_affine<F>(p, raw) : normalize == 2 ? scalar_mul_windowed<F>(p, raw) : scalar_mul_reference_chain<F>(p, raw);
     if (normalize) r = jac_normalize<F>(r);
     st(r.x, o); st(r.y, o + W); st(r.z, o + 2 * W);
 }
@@ -259,4 +259,21 @@ EXPORT void hsw_run(int which, const uint32_t *a, const uint32_t *b, uint32_t *o
         w_run(w, prog);
         w_store_f12(w, OFF_RES, o);
     });
+}
+
+// Gt::pow on the cyclotomic subgroup (bn254_gt_pow_B's fast path) and the membership test that selects it
+EXPORT void hsb_gt_pow_cyclotomic(const uint32_t *a, const uint32_t *k, uint32_t *o) {
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    PowTableVars<F2B> tbl;
+    f12_store(gt_pow_cyclotomic(f12_load<F2B>(a), raw, tbl), o);
+}
+EXPORT int hsb_gt_is_cyclotomic(const uint32_t *a) { return gt_is_cyclotomic(f12_load<F2B>(a)) ? 1 : 0; }
+// what bn254_gt_pow_B executes for one element: membership test, then the chain it selects
+EXPORT void hsb_gt_pow_auto(const uint32_t *a, const uint32_t *k, uint32_t *o) {
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    PowTableVars<F2B> tbl;
+    const Fq12<F2B> base = f12_load<F2B>(a);
+    f12_store(gt_is_cyclotomic(base) ? gt_pow_cyclotomic(base, raw, tbl) : gt_pow_windowed(base, raw, tbl), o);
 }

@@ -855,3 +855,18 @@ def test_scratch_is_bounded_by_one_round(oracle):
     assert free1 - torch.cuda.mem_get_info(dev)[0] < (1 << 30)
     small = te.gt_pow(ref[:300].contiguous(), k[:300].contiguous())
     assert torch.equal(pw[:300], small)
+
+
+def test_gt_pow_mixed_subgroup_membership(oracle, eng):
+    """Gt::pow chooses its chain per WAVE on the device (cyclotomic signed windows when every element of the wave is a pairing
+    value, the general chain otherwise): a batch of 200 pairing values with two arbitrary Fq12 elements in the middle of different
+    waves equals the oracle everywhere"""
+    rng = np.random.default_rng(206)
+    n = 200
+    P, Q = _points(oracle, rng, n)
+    g = eng.pairing_batch(P, Q)
+    g[17] = oracle.miller_only(P[17], Q[17]); g[150] = oracle.miller_only(P[150], Q[150])          # off the cyclotomic subgroup
+    s = _fr(oracle, _scalars(rng, n))
+    pw = eng.gt_pow_batch(g, s)
+    for i in list(range(0, n, 7)) + [16, 17, 18, 149, 150, 151]:
+        assert np.array_equal(pw[i], oracle.gt_pow(g[i], s[i])), i

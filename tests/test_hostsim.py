@@ -188,6 +188,7 @@ def test_scalar_mul_reference_chain(oracle, hs):
             assert np.array_equal(hs.call(fn, base, k, 0, out_words=2 * w), want)
             assert np.array_equal(hs.call(fn, base, k, 1, out_words=2 * w), canon_infinity(on(want)))
             assert np.array_equal(hs.call(fn, base, k, 2, out_words=2 * w), canon_infinity(on(want)))   # windowed algorithm, normalized
+            assert np.array_equal(hs.call(fn, base, k, 3, out_words=2 * w), canon_infinity(on(want)))   # Booth windows, affine table on the isomorphic curve
 
 
 def test_prepared_mode_and_product_chain(oracle, hs, kats):
@@ -340,8 +341,8 @@ def executed_chain_lengths(oracle, hs):
         hs.call(fn, *args, out_words=out_words)
         a = (C.c_ulong * 8)(); hs.lib.hs_counts_get(a)
         return int(a[0] + 1.5 * a[1])
-    return {"g1_mul": count("hs_g1_mul_glv", P, k2, out_words=24), "g2_mul": count("hsb_g2_mul", Q, k2, 2, out_words=48),
-            "gt_pow": count("hsb_gt_pow", g, k2, out_words=96)}
+    return {"g1_mul": count("hs_g1_mul_glv", P, k2, out_words=24), "g2_mul": count("hsb_g2_mul", Q, k2, 3, out_words=48),
+            "gt_pow": count("hsb_gt_pow_auto", g, k2, out_words=96)}             # a pairing value: membership test + cyclotomic chain
 
 
 def test_executed_chain_lengths(oracle, hs):
@@ -349,3 +350,22 @@ def test_executed_chain_lengths(oracle, hs):
     import json, pathlib
     want = json.loads((pathlib.Path(__file__).resolve().parents[1] / "profiles" / "executed_chain_lengths.json").read_text())["fq_products_per_unit"]
     assert executed_chain_lengths(oracle, hs) == want
+
+
+def test_gt_pow_cyclotomic_chain(oracle, hs):
+    """bn254_gt_pow_B's fast path: the device's membership test separates pairing values (and one) from arbitrary Fq12 elements, and
+    the signed-window Granger-Scott chain equals fields/mod.rs:35-46 on pairing values for edge and random scalars; the automatic
+    choice equals the oracle for both kinds of input"""
+    rng = np.random.default_rng(61)
+    k = _fr(oracle, rng)
+    g = oracle.pairing(oracle.g1_mul(oracle.g1_one(), k), oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng)))
+    rnd = _rf(oracle, rng, 12)
+    U32 = hostsim_lib._U32P
+    assert hs.lib.hsb_gt_is_cyclotomic(g.ctypes.data_as(U32)) == 1 and hs.lib.hsb_gt_is_cyclotomic(oracle.fq12_one().ctypes.data_as(U32)) == 1
+    assert hs.lib.hsb_gt_is_cyclotomic(rnd.ctypes.data_as(U32)) == 0
+    for kv in [0, 1, 2, 7, 8, 9, 15, 16, 0x88888888, M.R_ORD - 1, M.R_ORD - 2, (1 << 253) + 5] + [int.from_bytes(rng.bytes(40), "little") % M.R_ORD for _ in range(4)]:
+        ke = oracle.fp_from_int(FR, kv)
+        assert np.array_equal(hs.call("hsb_gt_pow_cyclotomic", g, ke, out_words=96), oracle.gt_pow(g, ke)), kv
+    ke = _fr(oracle, rng)
+    assert np.array_equal(hs.call("hsb_gt_pow_auto", g, ke, out_words=96), oracle.gt_pow(g, ke))
+    assert np.array_equal(hs.call("hsb_gt_pow_auto", rnd, ke, out_words=96), oracle.gt_pow(rnd, ke))
