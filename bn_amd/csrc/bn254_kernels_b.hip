@@ -250,22 +250,24 @@ struct ExpTableMem {
     uint4 *table;            // wave-uniform base (SGPRs)
     uint32_t lane;           // this lane's column
     uint32_t stride;         // lanes in the launch
-    __device__ __forceinline__ uint4 *row(int slot, int half) const { return table + (size_t)(uint32_t)((slot * 2 + half) * 7) * stride; }
+    // 32-bit element index (the table is far below 2^32 x 16 bytes): with a per-lane slot (Gt::pow's digit) the address is ONE VGPR
+    // offset on the scalar base instead of a 64-bit pointer per access
+    __device__ __forceinline__ uint32_t row(int slot, int half) const { return (uint32_t)((slot * 2 + half) * 7) * stride + lane; }
     __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
-        uint4 *p = row(slot, half);
+        const uint32_t r = row(slot, half);
         uint32_t w[28];
 #pragma unroll
         for (int i = 0; i < 9; ++i) { w[i] = v.c0.v.l[i]; w[9 + i] = v.c1.v.l[i]; w[18 + i] = v.c2.v.l[i]; }
         w[27] = 0;
 #pragma unroll
-        for (int g = 0; g < 7; ++g) (p + (size_t)g * stride)[lane] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+        for (int g = 0; g < 7; ++g) table[r + (uint32_t)g * stride] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
     }
     __device__ __forceinline__ Fq6<F2> ld6(int slot, int half) const {
-        const uint4 *p = row(slot, half);
+        const uint32_t r = row(slot, half);
         uint32_t w[28];
 #pragma unroll
         for (int g = 0; g < 7; ++g) {
-            const uint4 x = (p + (size_t)g * stride)[lane];
+            const uint4 x = table[r + (uint32_t)g * stride];
             w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w;
         }
         Fq6<F2> v;
@@ -358,6 +360,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // [lane][entry] layout.  Inputs in the cyclotomic subgroup (checked on the device: every value the reference's API can produce)
 // take the signed-window Granger-Scott chain (pairing.hpp gt_pow_cyclotomic), anything else the general one.
 constexpr size_t POW_TABLE_DWORDS_PER_LANE = 16 * 2 * 7 * 4;
+// the general chain as a real function: it is the rare path, and inlined next to the cyclotomic chain the two were register-allocated
+// together (97 spilled VGPRs)
+__device__ __noinline__ void gt_pow_general_cold(const Fq12<F2> *base, const uint32_t *raw, const ExpTableMem *tbl, Fq12<F2> *res) {
+    ExpTableMem t = *tbl;
+    *res = gt_pow_windowed(*base, raw, t);
+}
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table, int force_general) {
     BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
@@ -372,7 +380,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     const Fq12<F2> base = f12_load<F2>(a + 96u * pair);
     Fq12<F2> res;
     if (!force_general && __all(gt_is_cyclotomic(base))) res = gt_pow_cyclotomic(base, raw, tbl);          // wave-uniform choice
-    else res = gt_pow_windowed(base, raw, tbl);
+    else gt_pow_general_cold(&base, raw, &tbl, &res);
     if (live) f12_store(res, out + 96u * pair);
 }
 // out[i] = a[i]^-1   (Gt::inverse, lib.rs:172 -> fq12.rs:284-292; one Fq inversion per element, constant-time divsteps)

@@ -431,7 +431,20 @@ BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any l
 // :257-263).  One 64-bit accumulator per column, 81 + 81 v_mad_u64_u32, no carry instructions.
 // Column bound: 9*(la*lb) * 2^58 + 9 * 2^58 + carry < 2^64  <=>  la*lb <= 6.
 // Value: result < (A*B/169.3 + 1) q, so A*B <= 169 gives < 2q.
+// On the GPU the three multiplier leaves below run the same arithmetic with every column's multiply-add chain as ONE inline-asm
+// statement (fe_asm.hpp, tools/gen_asm_leaf.py): the compiler otherwise splits each column sum into two chains and joins them with
+// a 64-bit add (16 v_lshl_add_u64 per product); +3.6 % pairings/s (profiles/r03_ab_asm_leaf.txt).  The host simulation - and
+// -DBN_NO_ASM_LEAF - use the C++ bodies, which also carry the bound checks.
+#if !defined(BN_HOSTSIM) && !defined(BN_NO_ASM_LEAF)
+#define BN_ASM_LEAF 1
+}  // namespace bn254
+#include "fe_asm.hpp"
+namespace bn254 {
+#endif
 BN_FN Fe fe_mul_body(const Fe &a, const Fe &b) {
+#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+    return fe_mul_asm(a, b);
+#endif
     BN_COUNT(mul);
     BN_REQUIRE(!a.sg && !b.sg, "fe_mul on a signed lazy value");
     BN_REQUIRE(a.lb * b.lb <= 6, "fe_mul column overflow");
@@ -467,6 +480,9 @@ BN_LEAF2(fe_mul, fe_mul_body)
 // a*a / R: the 36 cross products a_i a_j (i < j) are taken once against the doubled limbs 2 a_j, so the product part is 45
 // instead of 81 mads (+ the same 81 of the reduction).  Same column sums as fe_mul(a, a), hence the same bounds.
 BN_FN Fe fe_sqr_body(const Fe &a) {
+#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+    return fe_sqr_asm(a);
+#endif
     BN_COUNT(mul);
     BN_REQUIRE(!a.sg, "fe_sqr on a signed lazy value");
     BN_REQUIRE(a.lb * a.lb <= 6, "fe_sqr column overflow");
@@ -507,6 +523,9 @@ BN_LEAF1M(fe_sqr, fe_sqr_body)
 
 // (a*u + c*v) / R with ONE reduction: 162 + 81 mads.   Column bound: la*lu + lc*lv <= 6; value: A*U + C*V <= 169.
 BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
+#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+    return fe_mul2_asm(a, u, c, v);
+#endif
     BN_COUNT(mul2);
     BN_REQUIRE(!a.sg && !u.sg && !c.sg && !v.sg, "fe_mul2 on a signed lazy value");
     BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 6, "fe_mul2 column overflow");

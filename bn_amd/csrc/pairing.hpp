@@ -420,17 +420,12 @@ BN_FN int booth_digit_256(const uint32_t *k, int i) {          // radix-16 Booth
     }
     return (int)((x >> 1) & 7u) + (int)(x & 1u) - (int)((x >> 4) << 3);
 }
-template <class F2, class Tbl>
-struct Fq12SlotSigned {                 // table entry `i`, conjugated when `neg` (a per-lane-pair flag: the digits differ)
-    const Tbl &t;
-    int i;
-    bool neg;
-    BN_FN Fq6<F2> c0() const { return t.c0(i); }
-    BN_FN Fq6<F2> c1() const {
-        Fq6<F2> v = t.c1(i), n = f6_neg(v);
-        return {f2_select(neg, v.c0, n.c0), f2_select(neg, v.c1, n.c1), f2_select(neg, v.c2, n.c2)};
-    }
-};
+// conj(f) for the lane pairs with `neg` set (the digits differ per pair)
+template <class F2>
+BN_FN Fq6<F2> f6_cond_neg(bool neg, const Fq6<F2> &v) {
+    const Fq6<F2> n = f6_neg(v);
+    return {f2_select(neg, v.c0, n.c0), f2_select(neg, v.c1, n.c1), f2_select(neg, v.c2, n.c2)};
+}
 template <class F2, class Tbl>
 BN_FN Fq12<F2> gt_pow_cyclotomic(const Fq12<F2> &base, const uint32_t *k_raw, Tbl &tbl) {
     tbl.put(0, f12_one<F2>());
@@ -451,7 +446,11 @@ BN_FN Fq12<F2> gt_pow_cyclotomic(const Fq12<F2> &base, const uint32_t *k_raw, Tb
             for (int d = 0; d < 4; ++d) res = f12_cyclotomic_sqr(res);
         }
         const int digit = booth_digit_256(k_raw, w);                            // per lane pair: both lanes hold the same scalar
-        res = f12_mul_src(res, Fq12SlotSigned<F2, Tbl>{tbl, digit < 0 ? -digit : digit, digit < 0}, false);
+        // res * conj(t) = conj(conj(res) * t): the sign is applied to the running value (in registers anyway), so the table operand
+        // takes the same path as in the exponentiation machine (conjugating the operand on load cost 97 spilled VGPRs)
+        res.c1 = f6_cond_neg(digit < 0, res.c1);
+        res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, digit < 0 ? -digit : digit}, false);
+        res.c1 = f6_cond_neg(digit < 0, res.c1);
     }
     return res;
 }

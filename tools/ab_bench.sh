@@ -6,7 +6,7 @@ repo=$(pwd); out=$repo/gpurun_out; mkdir -p $out
 for r in $(seq $rounds); do
   for so in build_variants/lib_*.so; do
     echo -n "$(basename $so) " >> $out/${tag}_ab.txt
-    BN254_LIB_PATH=$repo/$so timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-host-api 2>&1 | python tools/brief_line.py >> $out/${tag}_ab.txt
+    BN254_LIB_PATH=$repo/$so timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-host-api --no-side 2>&1 | python tools/brief_line.py >> $out/${tag}_ab.txt
   done
 done
 sort $out/${tag}_ab.txt

@@ -9,6 +9,6 @@ mkdir -p build_variants
 name=$1; shift
 B=bn_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c bn_amd/csrc/bn254_kernels_b.hip -o build_variants/kb_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/bn254_hip.o build_variants/kb_$name.o $B/bn254_kernels_mul.o $B/bn254_multi.o -ldl -lpthread -o build_variants/lib_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/bn254_hip.o build_variants/kb_$name.o $B/bn254_kernels_mul.o $B/bn254_kernels_w.o $B/bn254_multi.o -ldl -lpthread -o build_variants/lib_$name.so
 rm -f build_variants/kb_$name.o
 echo built build_variants/lib_$name.so
