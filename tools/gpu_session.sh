@@ -13,7 +13,7 @@ for s in $steps; do
     bench) timeout 600 python bench.py --steps 20 --warmup 3 > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?" | tee -a $out/${tag}_summary.txt; cat $out/${tag}_bench.json | tee -a $out/${tag}_summary.txt ;;
     side) for w in g1mul g2mul gtpow product prepared; do timeout 300 python bench.py --workload $w --steps 5 --warmup 1 >> $out/${tag}_side.json 2>> $out/${tag}_side.err; done; cat $out/${tag}_side.json | tee -a $out/${tag}_summary.txt ;;
     hostapi) for cfg in "2 0" "1 0" "2 32768" "4 16384"; do set -- $cfg; echo "slots=$1 chunk=$2" >> $out/${tag}_hostapi.txt; BN254_PIPELINE_SLOTS=$1 BN254_PIPELINE_CHUNK=$2 timeout 300 python tools/host_api_rate.py >> $out/${tag}_hostapi.txt 2>&1; done; timeout 300 python tools/host_api_rate.py 1048576 >> $out/${tag}_hostapi.txt 2>&1; cat $out/${tag}_hostapi.txt | tee -a $out/${tag}_summary.txt ;;
-    prof) cd /tmp; B="python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-api"
+    prof) cd /tmp; B="python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-api --no-side"
           timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python $repo/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-api > $out/${tag}_stats.log 2>&1
           timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -- $B > $out/${tag}_fetch.log 2>&1
           timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -- $B > $out/${tag}_write.log 2>&1
