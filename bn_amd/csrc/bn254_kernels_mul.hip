@@ -2,7 +2,8 @@
 //   bn254_g1_mul_M   one lane per point (G1 is over Fq: a Jacobian point is 27 VGPRs)
 //   bn254_g2_mul_M   one point per lane PAIR (Fq2B: even lane = c0, odd lane = c1 of every coordinate, DPP exchange)
 // normalize = 0 runs the reference's own double-and-add chain (raw Jacobian limbs identical to the crate's, used to make
-// benchmark inputs with z != 1); normalize = 1 runs fixed 4-bit windows and returns the normalized point.
+// benchmark inputs with z != 1); normalize = 1 returns the normalized point by the short chains of curve.hpp: GLV (G1) / GLS (G2)
+// decomposition, signed 4-bit windows, a window table brought to a common z so that every addition is a mixed one.
 //
 // This translation unit inlines the point operations and the multiplier leaves: the running point stays in registers for the
 // whole chain (in the call-based build of bn254_hip.hip every doubling went through private memory: 6 / 27 GB of HBM traffic
@@ -34,7 +35,7 @@ __device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km)
     fr_from_mont(kw, raw);
     if constexpr (NORMALIZE) {
         if constexpr (std::is_same<F, FqField>::value) return jac_normalize<F>(scalar_mul_glv(p, raw));      // G1: GLV + signed windows
-        else return jac_normalize<F>(scalar_mul_booth_affine<F>(p, raw));
+        else return jac_normalize<F>(scalar_mul_gls<F2>(p, raw));                                             // G2: GLS, four signed-window streams
     } else {
         return scalar_mul_reference_chain<F>(p, raw);
     }

@@ -130,14 +130,17 @@ BN_COARSE Jac<F> jac_madd_flags(const Jac<F> &p, const Aff<F> &q, bool pz, bool 
 // entries (52 for N = 8) against 5 saved per addition (66 additions: 330), and a table entry is 2 instead of 3 field elements.
 // (The "effective affine" technique of libsecp256k1's ecmult, with the plain prefix/suffix product instead of its z-ratio chain.)
 // tab[1..N] in, aff[1..N] out; returns Zc.  An infinite input point gives Zc = 0 and the chain's result z = 0: infinity again.
-template <class F, int N>
+// CONJ_EXTRA (G2 only): every entry is rescaled by conj(Zc) as well, so that the common z becomes Zc conj(Zc) = norm(Zc), an element
+// of Fq - the isomorphism (x, y) -> (x s^2, y s^3) commutes with the Frobenius-twist endomorphism psi exactly when s is in Fq.
+template <class F, int N, bool CONJ_EXTRA = false>
 BN_FN typename F::T table_to_common_z(const Jac<F> *tab, Aff<F> *aff) {
     using T = typename F::T;
     T pre[N + 1];                                             // pre[i] = Z_1 ... Z_i
     pre[1] = tab[1].z;
 #pragma unroll 1
     for (int i = 2; i <= N; ++i) pre[i] = F::mul(pre[i - 1], tab[i].z);
-    T suf = F::one();                                         // Z_{i+1} ... Z_N
+    T suf = F::one();                                         // (conj(Zc)) Z_{i+1} ... Z_N
+    if constexpr (CONJ_EXTRA) suf = f2_conj(pre[N]);
 #pragma unroll 1
     for (int i = N; i >= 1; --i) {
         T s = i > 1 ? F::mul(pre[i - 1], suf) : suf;
@@ -326,8 +329,9 @@ BN_FN GlvSplit glv_decompose(const uint32_t *k_raw) {
     }
     return g;
 }
-// radix-16 Booth digit i of a non-negative magnitude (5 words): -8 b[4i+3] + 4 b[4i+2] + 2 b[4i+1] + b[4i] + b[4i-1], in [-8, 8];
+// radix-16 Booth digit i of a non-negative magnitude (NW words): -8 b[4i+3] + 4 b[4i+2] + 2 b[4i+1] + b[4i] + b[4i-1], in [-8, 8];
 // sum digit_i 16^i = magnitude when the window above the top one is empty (no carries to propagate: MSB-first evaluation)
+template <int NW = 5>
 BN_FN int booth_digit(const uint32_t *mag, int i) {
     const int pos = 4 * i - 1;
     uint32_t x;
@@ -335,7 +339,7 @@ BN_FN int booth_digit(const uint32_t *mag, int i) {
         x = (mag[0] << 1) & 31u;
     } else {
         const int w = pos >> 5, sh = pos & 31;
-        uint64_t two = (uint64_t)mag[w] | (w + 1 < 5 ? ((uint64_t)mag[w + 1] << 32) : 0);
+        uint64_t two = (uint64_t)mag[w] | (w + 1 < NW ? ((uint64_t)mag[w + 1] << 32) : 0);
         x = (uint32_t)(two >> sh) & 31u;
     }
     return (int)((x >> 1) & 7u) + (int)(x & 1u) - (int)((x >> 4) << 3);
@@ -384,6 +388,101 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) 
         }
     }
     res.z = fe_mul(res.z, zc);                                    // back from the isomorphic curve
+    return res;
+}
+
+// ---- G2 only: GLS.  psi = twist o Frobenius o untwist - the reference's own mul_by_q (groups/mod.rs:550-555), (x, y) -> (conj(x) gx,
+// conj(y) gy) - is multiplication by lambda = q mod r = 6u^2 on the order-r subgroup of the twist, and lambda^4 - lambda^2 + 1 = 0:
+// k Q = k0 Q + k1 psi(Q) + k2 psi^2(Q) + k3 psi^3(Q) with |k_i| < 2^67 (Galbraith-Scott; Babai rounding against four short lattice
+// vectors in per-lane integer arithmetic, a word-for-word model is asserted over 20 000 scalars in tools/gen_device_constants.py).
+// 68 doublings instead of 252; the four Booth digit streams share one accumulator; psi^j is applied to the affine table entry on
+// the fly (psi^2 = (w x, -y): one Fq product per coordinate; psi, psi^3: two products by constants).  Same group element as
+// groups/mod.rs:250-270, different Jacobian coordinates - callers normalize.
+struct GlsSplit {
+    uint32_t m[4][3];            // |k_i| (96-bit little-endian words; < 2^67)
+    bool neg[4];
+};
+BN_FN GlsSplit gls_decompose(const uint32_t *k_raw) {
+    uint32_t c[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t pr[12];
+        words_mul<8, 8, 12>(k_raw, k::GLS_G[j], pr);              // c_j = floor(k G_j / 2^288) mod 2^96
+        c[j][0] = pr[9]; c[j][1] = pr[10]; c[j][2] = pr[11];
+    }
+    GlsSplit g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v[3] = {i == 0 ? k_raw[0] : 0u, i == 0 ? k_raw[1] : 0u, i == 0 ? k_raw[2] : 0u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t t[3];
+            words_mul<3, 3, 3>(c[j], k::GLS_B[j][i], t);
+            int64_t cy = 0;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {                         // v -= sign_j * t  (mod 2^96)
+                int64_t x = (int64_t)v[w] + (k::GLS_GNEG[j] ? (int64_t)t[w] : -(int64_t)t[w]) + cy;
+                v[w] = (uint32_t)x; cy = x >> 32;
+            }
+        }
+        g.neg[i] = (v[2] >> 31) != 0;
+        uint32_t carry = g.neg[i] ? 1u : 0u;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            uint64_t x = (uint64_t)(g.neg[i] ? ~v[w] : v[w]) + carry;
+            g.m[i][w] = (uint32_t)x; carry = (uint32_t)(x >> 32);
+        }
+    }
+    return g;
+}
+constexpr int GLS_WINDOWS = 18;          // 4 * 18 = 72 bits >= 67 + the Booth sign bit
+
+template <class F2>
+BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_t *k_raw) {
+    using F = Fq2Field<F2>;
+    const GlsSplit g = gls_decompose(k_raw);
+    const bool p_inf = F::is_zero(p.z);
+    Jac<F> tab[9];
+    tab[1] = p;
+    tab[2] = jac_double(tab[1]);
+    tab[4] = jac_double(tab[2]);
+    tab[8] = jac_double(tab[4]);
+    tab[3] = jac_add_flags(tab[2], p, p_inf, p_inf);
+    tab[6] = jac_double(tab[3]);
+    tab[5] = jac_add_flags(tab[4], p, p_inf, p_inf);
+    tab[7] = jac_add_flags(tab[6], p, p_inf, p_inf);
+    Aff<F> aff[9];
+    const F2 zc = table_to_common_z<F, 8, true>(tab, aff);       // entries affine for the common z = norm(zc), an element of Fq
+    const F2 zn = f2_mul(zc, f2_conj(zc));
+    aff[0] = {F::zero(), F::one()};
+    Jac<F> res = {F::zero(), F::one(), F::zero()};
+    bool res_inf = true;
+#pragma unroll 1
+    for (int w = GLS_WINDOWS - 1; w >= 0; --w) {
+        if (w != GLS_WINDOWS - 1) {
+#pragma unroll 1
+            for (int d = 0; d < 4; ++d) res = jac_double(res);
+        }
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int d = booth_digit<3>(g.m[j], w);
+            const int ad = d < 0 ? -d : d;
+            const bool negate = ((d < 0) != g.neg[j]) != (j >= 2);            // psi^2, psi^3 carry a minus sign on y
+            Aff<F> q = aff[ad];
+            if (j == 1) {
+                q.x = f2_mul_const(f2_conj_lazy(q.x), k::TWIST_MUL_BY_Q_X); q.y = f2_mul_const(f2_conj_lazy(q.y), k::TWIST_MUL_BY_Q_Y);
+            } else if (j == 2) {
+                q.x = f2_scale(q.x, f2_scalar_const((const F2 *)nullptr, k::GLS_W));
+            } else if (j == 3) {
+                q.x = f2_mul_const(f2_conj_lazy(q.x), k::GLS_WGX); q.y = f2_mul_const(f2_conj_lazy(q.y), k::TWIST_MUL_BY_Q_Y);
+            }
+            q.y = F::select(negate, q.y, F::template lc3<-1, 0, 0>(q.y, q.y, q.y));
+            const bool q_inf = p_inf || ad == 0;
+            res = jac_madd_flags(res, q, res_inf, q_inf);
+            res_inf = F::is_zero_std(res.z);                       // partial sums of the four interleaved parts can cancel
+        }
+    }
+    res.z = F::mul(res.z, zn);                                     // back from the isomorphic curve
     return res;
 }
 

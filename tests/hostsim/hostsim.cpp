@@ -277,3 +277,22 @@ EXPORT void hsb_gt_pow_auto(const uint32_t *a, const uint32_t *k, uint32_t *o) {
     const Fq12<F2B> base = f12_load<F2B>(a);
     f12_store(gt_is_cyclotomic(base) ? gt_pow_cyclotomic(base, raw, tbl) : gt_pow_windowed(base, raw, tbl), o);
 }
+
+// G2 * Fr through the GLS chain (what bn254_g2_mul_batch runs), normalized; and the 4-dimensional decomposition itself
+template <class F2X>
+static void hs_g2_gls_generic(const uint32_t *pt, const uint32_t *k, uint32_t *o) {
+    typedef Fq2Field<F2X> F;
+    Jac<F> p = {f2_load((F2X *)0, pt), f2_load((F2X *)0, pt + 16), f2_load((F2X *)0, pt + 32)};
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    Jac<F> r = jac_normalize<F>(scalar_mul_gls<F2X>(p, raw));
+    f2_store(r.x, o); f2_store(r.y, o + 16); f2_store(r.z, o + 32);
+}
+EXPORT void hs_g2_mul_gls(const uint32_t *pt, const uint32_t *k, uint32_t *o) { hs_g2_gls_generic<F2>(pt, k, o); }
+EXPORT void hsb_g2_mul_gls(const uint32_t *pt, const uint32_t *k, uint32_t *o) { hs_g2_gls_generic<F2B>(pt, k, o); }
+EXPORT void hs_gls_decompose(const uint32_t *k, uint32_t *o) {         // o: 4 x (3 words magnitude, 1 word sign)
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    GlsSplit g = gls_decompose(raw);
+    for (int i = 0; i < 4; ++i) { o[4 * i] = g.m[i][0]; o[4 * i + 1] = g.m[i][1]; o[4 * i + 2] = g.m[i][2]; o[4 * i + 3] = g.neg[i]; }
+}

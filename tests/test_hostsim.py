@@ -341,7 +341,7 @@ def executed_chain_lengths(oracle, hs):
         hs.call(fn, *args, out_words=out_words)
         a = (C.c_ulong * 8)(); hs.lib.hs_counts_get(a)
         return int(a[0] + 1.5 * a[1])
-    return {"g1_mul": count("hs_g1_mul_glv", P, k2, out_words=24), "g2_mul": count("hsb_g2_mul", Q, k2, 3, out_words=48),
+    return {"g1_mul": count("hs_g1_mul_glv", P, k2, out_words=24), "g2_mul": count("hsb_g2_mul_gls", Q, k2, out_words=48),
             "gt_pow": count("hsb_gt_pow_auto", g, k2, out_words=96)}             # a pairing value: membership test + cyclotomic chain
 
 
@@ -369,3 +369,25 @@ def test_gt_pow_cyclotomic_chain(oracle, hs):
     ke = _fr(oracle, rng)
     assert np.array_equal(hs.call("hsb_gt_pow_auto", g, ke, out_words=96), oracle.gt_pow(g, ke))
     assert np.array_equal(hs.call("hsb_gt_pow_auto", rnd, ke, out_words=96), oracle.gt_pow(rnd, ke))
+
+
+def test_g2_gls_scalar_mul(oracle, hs):
+    """bn254_g2_mul_batch's chain: the 4-dimensional GLS decomposition k = k0 + k1 L + k2 L^2 + k3 L^3 (L = q mod r, the eigenvalue of
+    the reference's mul_by_q on G2) as the device computes it, and the whole scalar multiplication in both Fq2 mappings, normalized,
+    against groups/mod.rs:250-270 - edge scalars (0, 1, r-1, the eigenvalue and its powers), a point with z = 1 and infinity"""
+    rng = np.random.default_rng(62)
+    lam = M.Q % M.R_ORD
+    assert (pow(lam, 4, M.R_ORD) - pow(lam, 2, M.R_ORD) + 1) % M.R_ORD == 0
+    b2 = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_int(FR, 999))
+    ks = [0, 1, 2, 3, 15, 16, 17, M.R_ORD - 1, M.R_ORD - 2, lam, lam + 1, M.R_ORD - lam, lam * lam % M.R_ORD, pow(lam, 3, M.R_ORD), 1 << 200, (1 << 253) + 7]
+    ks += [int.from_bytes(rng.bytes(40), "little") % M.R_ORD for _ in range(8)]
+    for kv in ks:
+        k = oracle.fp_from_int(FR, kv)
+        d = hs.call("hs_gls_decompose", k, out_words=16).view(np.uint32)
+        parts = [(int(d[4 * i]) | int(d[4 * i + 1]) << 32 | int(d[4 * i + 2]) << 64, int(d[4 * i + 3])) for i in range(4)]
+        assert sum((-m if s else m) * pow(lam, i, M.R_ORD) for i, (m, s) in enumerate(parts)) % M.R_ORD == kv
+        assert all(m < (1 << 67) for m, _ in parts)
+        for base in (b2, oracle.g2_one(), oracle.g2_zero()):
+            want = canon_infinity(oracle.g2_normalize(oracle.g2_mul(base, k)))
+            assert np.array_equal(hs.call("hs_g2_mul_gls", base, k, out_words=48), want), kv
+            assert np.array_equal(hs.call("hsb_g2_mul_gls", base, k, out_words=48), want), kv
