@@ -247,8 +247,19 @@ size_t bn_sub_launch(const bn254_ctx *c, size_t n) {
     return parts <= 1 ? n : ((n + parts - 1) / parts + 31) / 32 * 32;
 }
 
+// Up to this many pairings (or Miller loops whose value only meets a final exponentiation) per call run ONE PER WAVE - the whole
+// pairing as a program of the wave machine, ~1.2 ms - instead of one per lane pair (2.3 + 0.6 ms whatever the count).  The role
+// tables and the register file take 52 KB of LDS per pairing: three per CU.  BN254_WAVE_PAIRING_MAX overrides.
+size_t bn_wave_pairing_max() {
+    const char *e = getenv("BN254_WAVE_PAIRING_MAX");
+    return e ? (size_t)atol(e) : 512;
+}
 // naf: the value is only consumed by a final exponentiation, so the shorter NAF schedule may be used (pairing.hpp)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf) {
+    if (c->mapping.load() == 1 && naf && n <= bn_wave_pairing_max()) {
+        BnScope sc(c, s, "miller_wave");
+        return bn254_launch_pairing_W(p, q, f, n, 0, s);
+    }
     if (c->mapping.load() == 1) {
         const size_t step = bn_sub_launch(c, n);
         for (size_t lo = 0; lo < n; lo += step) {
@@ -351,6 +362,17 @@ static int bn_for_parts(size_t n, size_t step, Fn fn) {
 }
 constexpr size_t BN_LAUNCH_MAX = (size_t)1 << 22;       // units per launch where no table is involved (32-bit word offsets inside a kernel)
 
+// out[i] = pairing(p[i], q[i]).  Small batches: Miller loop + final exponentiation per WAVE, one launch; otherwise the lane-pair
+// kernels, the Miller values written to `out` and exponentiated in place (same 384-byte slots).
+int bn_launch_pairing(bn254_ctx *c, const void *p, const void *q, void *out, size_t n, hipStream_t s, BnBuf *table) {
+    if (c->mapping.load() == 1 && n <= bn_wave_pairing_max()) {
+        BnScope sc(c, s, "pairing_wave");
+        return bn254_launch_pairing_W(p, q, out, n, 1, s);
+    }
+    int rc = bn_launch_miller(c, p, q, out, n, s, true); if (rc) return rc;
+    return bn_launch_final_exp(c, out, out, n, s, table);
+}
+
 int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize) {
     const size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
     const bool mapping_b = ctx->mapping.load() == 1;
@@ -450,9 +472,7 @@ int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size
 int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, void *d_out, size_t n, void *stream) {
     BN_DEV_PROLOGUE(!d_p || !d_q || !d_out, BN_N_MAX);
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
-    // the Miller values are written to d_out and exponentiated in place (same 384-byte slots)
-    rc = bn_launch_miller(ctx, d_p, d_q, d_out, n, s, true); if (rc) return rc;
-    return bn_launch_final_exp(ctx, d_out, d_out, n, s, nullptr);
+    return bn_launch_pairing(ctx, d_p, d_q, d_out, n, s, nullptr);
 }
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;

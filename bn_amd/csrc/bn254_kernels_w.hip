@@ -4,8 +4,8 @@
 // lane-pair kernels of bn254_kernels_b.hip take 2.1 ms per final exponentiation whatever the batch size.
 //
 // One workgroup = one wave = one Fq12.  LDS: the register file of the machine (5 pages x 9 limbs x 64 slots = 11.5 KB) and a copy
-// of the role tables (24 phases x 32 pairs x 24 B = 18 KB) - every role fetch of the ~570 phases of a final exponentiation is an
-// LDS read, not a global one.  A wave has a SIMD to itself (occupancy is not the point here: the chain is serial), so the leaves
+// of the role tables (52 phases x 32 pairs x 24 B = 40 KB) - every role fetch of the ~1130 phases of a pairing is an LDS read, not
+// a global one.  A wave has a SIMD to itself (occupancy is not the point here: the chain is serial), so the leaves
 // may use the whole register file.
 #define BN_COARSE __device__ __forceinline__
 #define BN_LEAF_MUL __device__ __forceinline__
@@ -18,7 +18,7 @@ using namespace bn254;
 using namespace bn254::wv;
 
 namespace {
-constexpr int ROLE_DWORDS = NPHASES * 32 * (int)(sizeof(Role) / 4);
+constexpr int ROLE_DWORDS_PER_PHASE = 32 * (int)(sizeof(Role) / 4);
 
 struct WaveDev {
     using T = Fe;
@@ -39,15 +39,20 @@ struct WaveDev {
     __device__ __forceinline__ void sync() const { __syncthreads(); }        // single-wave workgroup: a wave-level barrier
 };
 
-struct WaveLds {
+// NP = number of role tables resident: NPHASES_FE for the programs without a Miller loop (20 KB: a workgroup takes 32 KB of LDS, four
+// fit a CU - 1024 exponentiations in flight on the chip), NPHASES for the whole pairing (52 KB: three per CU)
+template <int NP>
+struct WaveLdsT {
     uint32_t regs[NPAGES * PAGE_DW];
-    uint32_t roles[ROLE_DWORDS];
+    uint32_t roles[NP * ROLE_DWORDS_PER_PHASE];
 };
+typedef WaveLdsT<NPHASES_FE> WaveLds;
 
-// role tables -> LDS, register file zeroed, Frobenius multipliers into their registers
-__device__ __forceinline__ WaveDev wave_init(WaveLds &l) {
+// role tables -> LDS, register file zeroed, Frobenius multipliers (and the Miller program's constants) into their registers
+template <int NP>
+__device__ __forceinline__ WaveDev wave_init(WaveLdsT<NP> &l) {
     const uint32_t *src = (const uint32_t *)&ROLES[0][0];
-    for (int i = threadIdx.x; i < ROLE_DWORDS; i += 64) l.roles[i] = src[i];
+    for (int i = threadIdx.x; i < NP * ROLE_DWORDS_PER_PHASE; i += 64) l.roles[i] = src[i];
     for (int i = threadIdx.x; i < NPAGES * PAGE_DW; i += 64) l.regs[i] = 0;
     __syncthreads();
     WaveDev w = {(char *)l.regs + 4u * (threadIdx.x & 1u), (const Role *)l.roles};
@@ -57,6 +62,12 @@ __device__ __forceinline__ WaveDev wave_init(WaveLds &l) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) c.l[i] = KCONST[j][threadIdx.x & 1u][i];
         w.st((uint32_t)KBASE_OFF[1] + 8u * j, c);
+    }
+    if (j >= 18 && j < 18 + NMCONST) {                      // constants of the Miller program
+        Fe c;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c.l[i] = MCONST[j - 18][threadIdx.x & 1u][i];
+        w.st(MCONST_OFF[j - 18], c);
     }
     return w;
 }
@@ -68,6 +79,25 @@ __global__ void __launch_bounds__(64) bn254_final_exp_W(const uint32_t *f_in, ui
     w_load_f12(w, f_in + 96u * blockIdx.x, OFF_RES);
     w.sync();
     w_run(w, PROG_FE);
+    w_store_f12(w, OFF_RES, out + 96u * blockIdx.x);
+}
+
+// out[b] = pairing(p[b], q[b])  (lib.rs:181-183 -> groups/mod.rs:764-771), or only its Miller value (final_exp = 0): the whole pairing
+// as ONE program of the wave machine - prologue (both affine conversions behind one inversion phase), the fused NAF Miller loop on
+// the isomorphic curve (six phases per doubling step, seven per addition step), the final exponentiation.  ~1.2 ms for one pairing
+// where the lane-pair kernels need 2.3 + 0.6 ms; one workgroup per pairing, for batches that cannot fill the chip anyway.
+__global__ void __launch_bounds__(64) bn254_pairing_W(const uint32_t *g1, const uint32_t *g2, uint32_t *out, int final_exp) {
+    __shared__ WaveLdsT<NPHASES> lds;
+    WaveDev w = wave_init(lds);
+    const uint32_t *w1 = g1 + 24u * blockIdx.x, *w2 = g2 + 48u * blockIdx.x;
+    uint32_t zp = 0, zq = 0;
+    for (int i = 0; i < 8; ++i) zp |= w1[16 + i];
+    for (int i = 0; i < 16; ++i) zq |= w2[32 + i];
+    const bool inf = zp == 0 || zq == 0;                                       // groups/mod.rs:766
+    w_load_points(w, w1, w2);
+    w.sync();
+    w_run(w, final_exp ? PROG_PAIRING : PROG_MILLER);
+    if (inf) { w_set_one(w); w.sync(); }
     w_store_f12(w, OFF_RES, out + 96u * blockIdx.x);
 }
 
@@ -224,6 +254,10 @@ int bn254_launch_wave_ubench_W(int which, int iters, void *out, hipStream_t s) {
 }
 int bn254_launch_final_exp_W(const void *f, void *out, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(bn254_final_exp_W, dim3((unsigned)n), dim3(64), 0, s, (const uint32_t *)f, (uint32_t *)out);
+    return (int)hipGetLastError();
+}
+int bn254_launch_pairing_W(const void *p, const void *q, void *out, size_t n, int final_exp, hipStream_t s) {
+    hipLaunchKernelGGL(bn254_pairing_W, dim3((unsigned)n), dim3(64), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)out, final_exp);
     return (int)hipGetLastError();
 }
 int bn254_launch_gt_tail_W(const void *in, size_t groups, unsigned m, void *out, int final_exp, hipStream_t s) {

@@ -123,10 +123,8 @@ int bn_pairing_batch_pipelined(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, b
     j.in[1] = (const char *)q; j.in_stride[1] = sizeof(bn_g2);
     j.out = (char *)out; j.out_stride = sizeof(bn_gt);
     j.launch = [ctx](BnSlot &s, size_t cnt) {
-        // Miller values land in the output slots and are exponentiated in place; the table is the slot's own
-        int rc = bn_launch_miller(ctx, s.d_in[0].p, s.d_in[1].p, s.d_out.p, cnt, s.stream, true);
-        if (rc) return rc;
-        return bn_launch_final_exp(ctx, s.d_out.p, s.d_out.p, cnt, s.stream, &s.tbl);
+        // (large chunks: Miller values land in the output slots and are exponentiated in place; the table is the slot's own)
+        return bn_launch_pairing(ctx, s.d_in[0].p, s.d_in[1].p, s.d_out.p, cnt, s.stream, &s.tbl);
     };
     return run_map(j);
 }

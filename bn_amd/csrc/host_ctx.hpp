@@ -138,6 +138,7 @@ struct BnScratchGuard {
 size_t bn_round_pairs(const bn254_ctx *c);                        // pairings in one full-machine launch of the lane-pair kernels
 size_t bn_sub_launch(const bn254_ctx *c, size_t n);                // sub-launch size for a batch of n (equal parts, none above one round)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf);
+int bn_launch_pairing(bn254_ctx *c, const void *p, const void *q, void *out, size_t n, hipStream_t s, BnBuf *table);
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table);
 int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *out, hipStream_t s);   // scratch guard held by the caller
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s);
@@ -158,6 +159,7 @@ int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s)
 // bn254_kernels_w.hip: one Fq12 per wave (wave.hpp)
 int bn254_launch_wave_ubench_W(int which, int iters, void *out, hipStream_t s);
 int bn254_launch_final_exp_W(const void *f, void *out, size_t n, hipStream_t s);
+int bn254_launch_pairing_W(const void *p, const void *q, void *out, size_t n, int final_exp, hipStream_t s);
 int bn254_launch_gt_tail_W(const void *in, size_t groups, unsigned m, void *out, int final_exp, hipStream_t s);
 void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, size_t *grid, size_t *scratch_bytes, size_t *counter_words);
 int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, void *scratch, void *counters, void *out, hipStream_t s);

@@ -77,6 +77,17 @@ BN_FN void w_comb(W &w, const Role &r, uint32_t base) {
     if (r.flags & 1) w.st(w_addr(r.dst, base), res);
 }
 
+// the wider combination of the Miller program: x = R[x0] + R[x1] - R[x2] - R[x3], y = R[y0] + R[y1] + R[y2] - R[y3] - R[y4]; xi x + y
+template <class W>
+BN_FN void w_comb2(W &w, const Role &r, uint32_t base) {
+    using T = typename W::T;
+    T x = fe_ssub(fe_ssub(fe_add(w.ld(w_addr(r.src[0], base)), w.ld(w_addr(r.src[1], base))), w.ld(w_addr(r.src[2], base))), w.ld(w_addr(r.src[3], base)));
+    T y = fe_add(fe_add(w.ld(w_addr(r.src[4], base)), w.ld(w_addr(r.src[5], base))), w.ld(w_addr(r.src[6], base)));
+    y = fe_ssub(fe_ssub(y, w.ld(w_addr(r.src[7], base))), w.ld(w_addr(r.src[8], base)));
+    T res = fe_lc4_par<9, 1, 1, 0>(x, lane_partner(x), y, y);
+    if (r.flags & 1) w.st(w_addr(r.dst, base), res);
+}
+
 template <class W>
 BN_FN void w_inv(W &w, const Role &r, uint32_t base) {
     using T = typename W::T;
@@ -98,6 +109,7 @@ BN_FN void w_run(W &w, const uint32_t *prog) {
         else if (op == OP_COMB_C) w_comb<true>(w, r, base);
         else if (op == OP_PROD_MUL) w_prod<4, 4, false, false>(w, r, base);
         else if (op == OP_COMB_M) w_comb<false>(w, r, base);
+        else if (op == OP_COMB_M2) w_comb2(w, r, base);
         else if (op == OP_PROD_MULC) w_prod<1, 1, false, true>(w, r, base);
         else w_inv(w, r, base);
         w.sync();
@@ -110,6 +122,27 @@ BN_FN void w_load_f12(W &w, const uint32_t *img, uint32_t reg0_off) {
     using T = typename W::T;
     const int j = w.pair();
     if (j < 6) w.st(reg0_off + 8u * (uint32_t)j, lane_load_pair((const T *)nullptr, img + 16 * j, img + 16 * j + 8));
+}
+// inputs of the Miller program: P = (x, y, z) in Fq as the Fq2 values (x, 0), (y, 0), (z, 0) on pairs 0..2; Q on pairs 3..5;
+// the same pairs then test z == 0 (groups/mod.rs:766: a point at infinity in either argument makes the pairing one)
+template <class W>
+BN_FN void w_load_points(W &w, const uint32_t *g1, const uint32_t *g2) {
+    using T = typename W::T;
+    const int j = w.pair();
+    if (j < 3) {
+        T v = lane_load_pair((const T *)nullptr, g1 + 8 * j, g1 + 8 * j);        // both lanes load the coordinate ...
+        w.st((uint32_t)OFF_IN_P + 8u * (uint32_t)j, lane_pick(v, lane_bcast((const T *)nullptr, fe_zero())));     // ... the odd one keeps 0
+    } else if (j < 6) {
+        w.st((uint32_t)OFF_IN_Q + 8u * (uint32_t)(j - 3), lane_load_pair((const T *)nullptr, g2 + 16 * (j - 3), g2 + 16 * (j - 3) + 8));
+    }
+}
+// RES <- one (the pairing of a point at infinity)
+template <class W>
+BN_FN void w_set_one(W &w) {
+    using T = typename W::T;
+    const int j = w.pair();
+    if (j == 0) w.st((uint32_t)OFF_RES, lane_pick(lane_bcast((const T *)nullptr, fe_one()), lane_bcast((const T *)nullptr, fe_zero())));     // (1, 0)
+    else if (j < 6) w.st((uint32_t)OFF_RES + 8u * (uint32_t)j, lane_bcast((const T *)nullptr, fe_zero()));
 }
 template <class W>
 BN_FN void w_store_f12(W &w, uint32_t reg0_off, uint32_t *img) {

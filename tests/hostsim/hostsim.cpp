@@ -296,3 +296,17 @@ EXPORT void hs_gls_decompose(const uint32_t *k, uint32_t *o) {         // o: 4 x
     GlsSplit g = gls_decompose(raw);
     for (int i = 0; i < 4; ++i) { o[4 * i] = g.m[i][0]; o[4 * i + 1] = g.m[i][1]; o[4 * i + 2] = g.m[i][2]; o[4 * i + 3] = g.neg[i]; }
 }
+
+// the Miller loop and the whole pairing on the wave machine: Jacobian G1 / G2 images in, Fq12 image out (infinity -> one)
+EXPORT void hsw_pairing(int fe, const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
+    using namespace bn254::wv;
+    static WaveSimShared sh;
+    wavesim_init(sh);
+    const bool inf = words_all_zero(g1 + 16, 8) || words_all_zero(g2 + 32, 16);
+    wavesim_run(sh, [&](WaveSim &w) {
+        w_load_points(w, g1, g2); w.sync();
+        w_run(w, fe ? PROG_PAIRING : PROG_MILLER);
+        if (inf) { w_set_one(w); w.sync(); }
+        w_store_f12(w, OFF_RES, o);
+    });
+}

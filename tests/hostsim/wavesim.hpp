@@ -52,6 +52,11 @@ inline void wavesim_init(WaveSimShared &sh) {
         for (int k = 0; k < 2; ++k) { for (int i = 0; i < 9; ++i) c.v[k].l[i] = KCONST[j][k][i]; BN_SETB(c.v[k], 1, 1); }
         w.st((uint32_t)KBASE_OFF[1] + 8u * (uint32_t)j, c);
     }
+    for (int j = 0; j < NMCONST; ++j) {
+        FeP c;
+        for (int k = 0; k < 2; ++k) { for (int i = 0; i < 9; ++i) c.v[k].l[i] = MCONST[j][k][i]; BN_SETB(c.v[k], 1, 1); }
+        w.st(MCONST_OFF[j], c);
+    }
 }
 
 // runs body(w) on 32 threads (one per lane pair)

@@ -128,6 +128,40 @@ def test_product_final_exp_tail(oracle, te):
         assert np.array_equal(_host(te.product_final_exp(_dev(te, vals[:m]))), want), m
 
 
+def test_wave_pairing_matches_oracle_and_lane_pair_kernels(oracle, te):
+    """small batches run the WHOLE pairing per wave (bn254_pairing_W: prologue, Miller loop and final exponentiation as one program):
+    against the oracle with the edge cases of groups/mod.rs:764-771 (infinity either side, z = 1), the reference's known answer,
+    and the same 300 pairs through the lane-pair kernels (BN254_WAVE_PAIRING_MAX=0) - both sides of the host's threshold"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    from bn_oracle import FR
+    rng = np.random.default_rng(305)
+    n = 40
+    ks = [oracle.fp_from_int(FR, int.from_bytes(rng.bytes(40), "little") % M.R_ORD) for _ in range(2 * n)]
+    P = oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (n, 1)), np.stack(ks[:n]))
+    Q = oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (n, 1)), np.stack(ks[n:]))
+    P[1] = oracle.g1_zero(); Q[2] = oracle.g2_zero(); P[3] = oracle.g1_zero(); Q[3] = oracle.g2_zero()
+    P[4] = oracle.g1_one(); Q[4] = oracle.g2_one()
+    P[5] = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, M.R_ORD - 1))
+    e = bn_amd.Engine(0)
+    e.profile(True); e.profile_reset()
+    got = e.pairing_batch(P, Q)
+    assert e.kernel_stats("pairing_wave")[1] == 1 and e.kernel_stats("miller")[1] == 0
+    e.profile(False)
+    assert np.array_equal(got, oracle.pairing_batch(P, Q))
+    assert np.array_equal(e.pairing_product(P, Q), oracle.pairing_product(P, Q))          # Miller per wave -> product tree -> one exponentiation
+    e.close()
+    m = 300
+    Pd, Qd = D.synthetic_points(te, 9000, 9000 + m)
+    a = te.pairing_batch(Pd, Qd); torch.cuda.synchronize()
+    with _env(BN254_WAVE_PAIRING_MAX=0, BN254_WAVE_FE_MAX=0):
+        b = te.pairing_batch(Pd, Qd); torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    Pn = Pd[:8].cpu().numpy().view(np.uint64); Qn = Qd[:8].cpu().numpy().view(np.uint64)
+    assert np.array_equal(a[:8].cpu().numpy().view(np.uint64), oracle.pairing_batch(Pn, Qn))
+
+
 def test_single_pairing_latency_path(oracle, te):
     """n = 1 through every entry point: the by-value `pairing(p, q)` of lib.rs:181-183"""
     import bn_amd

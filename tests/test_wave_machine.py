@@ -59,6 +59,14 @@ def test_tables_against_the_big_integer_model(gen):
     assert run("CYC", _flat(c)) == _flat(M.f12_cyclotomic_squared(c))
     assert run("HARD", _flat(c)) == _flat(M.final_exp_last_chunk(c))
     assert run("FE", a) == _flat(M.final_exponentiation(_unflat(a)))
+    # the Miller program: FE(machine Miller loop) == pairing of the oracle's model (groups/mod.rs:764-771), Jacobian inputs
+    k1, k2 = rnd.randrange(1, M.R_ORD), rnd.randrange(1, M.R_ORD)
+    P = M.g_mul(M.FQ_OPS, M.G1_ONE, k1); Qj = M.g_mul(M.FQ2_OPS, M.G2_ONE, k2)
+    regs = gen.fresh_regs()
+    regs[gen.IN_PX], regs[gen.IN_PY], regs[gen.IN_PZ] = (P[0], 0), (P[1], 0), (P[2], 0)
+    regs[gen.IN_QX], regs[gen.IN_QY], regs[gen.IN_QZ] = Qj
+    gen.run(B, progs["PAIRING"], regs)
+    assert [regs[r] for r in gen.RES] == _flat(M.pairing(P, Qj))
     # the committed header is what the generator produces now
     import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()) as out:
@@ -92,3 +100,26 @@ def test_wave_machine_in_host_simulation(oracle, hs, kats):
     assert np.array_equal(hs.call("hsw_run", 0, s, s, out_words=96), oracle.fq12_sqr(s))
     t = oracle.fq12_from_ints(kats["test_cyclotomic_exp"]["orig"])
     assert np.array_equal(hs.call("hsw_run", 8, t, z, out_words=96), oracle.fq12_final_exponentiation(t))
+
+
+def test_wave_pairing_in_host_simulation(oracle, hs, kats):
+    """the whole pairing as ONE program of the wave machine (prologue, fused NAF Miller loop on the isomorphic curve, final
+    exponentiation) on a simulated wave with bounds enforced: random Jacobian inputs, z = 1 inputs, infinity in either argument,
+    and the reference's own known answer (groups/mod.rs:773-796, test_reduced_pairing)"""
+    from bn_oracle import FR
+    rng = np.random.default_rng(43)
+    fr = lambda: oracle.fp_from_int(FR, int.from_bytes(rng.bytes(40), "little") % M.R_ORD)
+    for _ in range(2):
+        P = oracle.g1_mul(oracle.g1_one(), fr()); Q = oracle.g2_mul(oracle.g2_one(), fr())
+        want = oracle.pairing(P, Q)
+        assert np.array_equal(hs.call("hsw_pairing", 1, P, Q, out_words=96), want)
+        m = hs.call("hsw_pairing", 0, P, Q, out_words=96)                       # Miller value: comparable after the exponentiation only
+        assert np.array_equal(oracle.fq12_final_exponentiation(m), want)
+    P, Q = oracle.g1_one(), oracle.g2_one()
+    assert np.array_equal(hs.call("hsw_pairing", 1, P, Q, out_words=96), oracle.pairing(P, Q))
+    one = oracle.fq12_one()
+    assert np.array_equal(hs.call("hsw_pairing", 1, oracle.g1_zero(), Q, out_words=96), one)
+    assert np.array_equal(hs.call("hsw_pairing", 1, P, oracle.g2_zero(), out_words=96), one)
+    k1 = oracle.fp_from_decimal(FR, kats["test_reduced_pairing"]["k1"]); k2 = oracle.fp_from_decimal(FR, kats["test_reduced_pairing"]["k2"])
+    gt = hs.call("hsw_pairing", 1, oracle.g1_mul(oracle.g1_one(), k1), oracle.g2_mul(oracle.g2_one(), k2), out_words=96)
+    assert oracle.fq12_to_ints(gt) == [int(x) for x in kats["test_reduced_pairing"]["expected"]]

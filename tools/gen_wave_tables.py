@@ -96,6 +96,60 @@ def final_exponentiation(f):                                   # fq12.rs:41-88, 
     o = f12_frob(l, 1); p = f12_mul(o, n); q = f12_frob(k, 2); r = f12_mul(q, p); t = f12_mul(f12_conj(s), l); u = f12_frob(t, 3)
     return f12_mul(u, r)
 
+# ---- the reference's Miller loop (groups/mod.rs:486-519, 557-635), binary schedule, on affine P in E(Fq), Q in E'(Fq2): the yardstick
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781, 11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930, 4082367875863433681332203403145435568316851327593401208105741076214120093531))
+def ec_mul(k, P, mul, sub, inv, three_x2):
+    """affine double-and-add on y^2 = x^3 + b (a = 0) over a field given by its operations"""
+    def add(A, Bp):
+        if A is None: return Bp
+        if Bp is None: return A
+        if A[0] == Bp[0]:
+            if A[1] != Bp[1]: return None
+            l = mul(three_x2(A[0]), inv(_dbl(A[1])))
+        else:
+            l = mul(sub(Bp[1], A[1]), inv(sub(Bp[0], A[0])))
+        x3 = sub(sub(mul(l, l), A[0]), Bp[0])
+        return (x3, sub(mul(l, sub(A[0], x3)), A[1]))
+    acc = None
+    while k:
+        if k & 1: acc = add(acc, P)
+        P = add(P, P); k >>= 1
+    return acc
+def _dbl(y): return f2_add(y, y) if isinstance(y, tuple) else 2 * y % Q
+def g1_mul(k): return ec_mul(k, (1, 2), lambda a, b: a * b % Q, lambda a, b: (a - b) % Q, lambda a: pow(a, Q - 2, Q), lambda x: 3 * x * x % Q)
+def g2_mul(k): return ec_mul(k, G2_GEN, f2_mul, f2_sub, f2_inv, lambda x: f2_scale(f2_mul(x, x), 3))
+def ref_miller(P, Qa):
+    xp, yp = P
+    bt = f2_scale(f2_inv(XI), 3)                               # b' = 3 / xi
+    half = pow(2, Q - 2, Q)
+    def line(f, l0, lvw, lvv):
+        return f12_mul(f, [l0, F2_ZERO, f2_scale(lvv, xp), F2_ZERO, f2_scale(lvw, yp), F2_ZERO])
+    def dbl(r):
+        x, y, z = r
+        a = f2_scale(f2_mul(x, y), half); b = f2_mul(y, y); c = f2_mul(z, z); e = f2_mul(bt, f2_scale(c, 3)); f = f2_scale(e, 3)
+        g = f2_scale(f2_add(b, f), half); yz = f2_add(y, z); h = f2_sub(f2_mul(yz, yz), f2_add(b, c)); i = f2_sub(e, b); j = f2_mul(x, x)
+        r2 = (f2_mul(a, f2_sub(b, f)), f2_sub(f2_mul(g, g), f2_scale(f2_mul(e, e), 3)), f2_mul(b, h))
+        return r2, (f2_mul(XI, i), f2_neg(h), f2_scale(j, 3))
+    def add(r, q):
+        x, y, z = r
+        d = f2_sub(x, f2_mul(z, q[0])); e = f2_sub(y, f2_mul(z, q[1])); f = f2_mul(d, d); g = f2_mul(e, e); h = f2_mul(d, f); i = f2_mul(x, f)
+        j = f2_sub(f2_add(f2_mul(z, g), h), f2_add(i, i))
+        r2 = (f2_mul(d, j), f2_sub(f2_mul(e, f2_sub(i, j)), f2_mul(h, y)), f2_mul(z, h))
+        return r2, (f2_mul(XI, f2_sub(f2_mul(e, q[0]), f2_mul(d, q[1]))), d, f2_neg(e))
+    mulq = lambda q: (f2_mul(f2_conj(q[0]), gamma(1, 3, 1)), f2_mul(f2_conj(q[1]), gamma(1, 2, 1)))
+    r = (Qa[0], Qa[1], F2_ONE); f = f12_one()
+    n = 6 * U + 2
+    for bit in bin(n)[3:]:
+        f = f12_mul(f, f)
+        r, (l0, lvw, lvv) = dbl(r); f = line(f, l0, lvw, lvv)
+        if bit == "1":
+            r, (l0, lvw, lvv) = add(r, Qa); f = line(f, l0, lvw, lvv)
+    q1 = mulq(Qa); q2 = mulq(q1); q2 = (q2[0], f2_neg(q2[1]))
+    r, (l0, lvw, lvv) = add(r, q1); f = line(f, l0, lvw, lvv)
+    r, (l0, lvw, lvv) = add(r, q2); f = line(f, l0, lvw, lvv)
+    return f
+
 # ------------------------------------------------------------------------------------------------ register file
 PAGE_DW = 576                    # one LDS page: 9 limbs x 64 slots; a register (Fq2) = two adjacent slots (even lane c0, odd lane c1)
 REL = 0x8000                     # index flag: relative to the base register of the program entry
@@ -110,7 +164,7 @@ def slot(s): return 64 + 32 * (s // 3) + 9 * (s % 3)       # table slot s: 6 reg
 def off(reg): return 4 * ((reg >> 5) * PAGE_DW + ((reg & 31) << 1))       # BYTE offset of the register's even slot, limb 0
 def rel(k): return ('rel', k)    # k-th register after the entry's base
 
-OPS = {"PROD_MUL": 0, "PROD_MULC": 1, "PROD_SQR": 2, "COMB_M": 3, "COMB_C": 4, "INV": 5, "END": 15}
+OPS = {"PROD_MUL": 0, "PROD_MULC": 1, "PROD_SQR": 2, "COMB_M": 3, "COMB_C": 4, "INV": 5, "COMB_M2": 6, "END": 15}
 
 class Phase:
     def __init__(self, kind, name):
@@ -133,6 +187,11 @@ def role_words(kind, ro):
         a = [enc(x) for x in ro["a"]] + [z] * (4 - len(ro["a"]))
         b = [enc(x) for x in ro.get("b", [])] + [z] * (4 - len(ro.get("b", [])))
         return a + b + [z, z] + [enc(ro["dst"]), 1 | (2 if ro.get("conj") else 0)]
+    if kind == "COMB_M2":
+        xp, xm, yp, ym = ro.get("xp", []), ro.get("xm", []), ro.get("yp", []), ro.get("ym", [])
+        assert len(xp) <= 2 and len(xm) <= 2 and len(yp) <= 3 and len(ym) <= 2
+        pad = lambda l, n: [enc(x) for x in l] + [z] * (n - len(l))
+        return pad(xp, 2) + pad(xm, 2) + pad(yp, 3) + pad(ym, 2) + [z] + [enc(ro["dst"]), 1]
     xs = [enc(ro.get("xp", ZERO))] + [enc(x) for x in ro.get("xm", [])] + [z] * (2 - len(ro.get("xm", [])))
     ys = [enc(x) for x in ro.get("yp", [])] + [z] * (2 - len(ro.get("yp", []))) + [enc(x) for x in ro.get("ym", [])] + [z] * (2 - len(ro.get("ym", [])))
     return xs + ys + [enc(ro.get("z", ZERO)), z, z] + [enc(ro["dst"]), 1 | (2 if ro.get("zneg") else 0)]
@@ -201,6 +260,147 @@ def frob_phase(P):
 def frob_constants(P):
     one = F2_ONE
     return [one, FROB6_C1[P], FROB6_C2[P], FROB12_C1[P], f2_mul(FROB6_C1[P], FROB12_C1[P]), f2_mul(FROB6_C2[P], FROB12_C1[P])]
+
+# ------------------------------------------------------------------------------------------------ the Miller loop as a program
+# Registers of the Miller loop live in pages 2-4 (the exponentiation's table slots, which only the final exponentiation uses).
+_m = iter(range(64, 160))
+def _take(n=1):
+    r = [next(_m) for _ in range(n)]
+    return r if n > 1 else r[0]
+TR = _take(9)                      # products of the running point in the first phase of a doubling step
+TA = _take(10)                     # products / temporaries of an addition step
+MH, ML0, MLVW, MLVV = _take(4)     # h and the line (ell_0, ell_vw * yP, ell_vv * xP)
+RX, RY, RZ, ZB, NZB = _take(5)     # R (homogeneous projective), and +-(27 - 3i) z
+QX, QY, NQY, PX, NPX, PY, NPY = _take(7)
+MD, ME, MJ, MT = _take(4)
+C_ONE, C_T2, C_NT2, C_T3, C_NT3, C_B3, C_NB3, C_TWX, C_TWY, C_NTWY = _take(10)      # constants, written by the kernel's prologue
+IN_PX, IN_PY, IN_PZ, IN_QX, IN_QY, IN_QZ = _take(6)                                 # inputs: P as (x, 0) ..., Q
+IZP, IZQ, IZP2, IZQ2, IZP3, IZQ3, PXA, PYA, QXA, QYA = _take(10)
+T27 = list(range(8, 26))           # the 18 products of f * f (the T area of the product)
+
+def iso_constants():
+    """t with t^6 = 82/3: the curve constant 3 b' t^6 of the isomorphic twist is 27 - 3i (gen_device_constants.py ISO_T2 / ISO_T3)"""
+    consts = (pathlib.Path(__file__).resolve().parents[1] / "bn_amd" / "csrc" / "bn254_constants.hpp").read_text()
+    import re
+    def limbs(name):
+        v = [int(x, 16) for x in re.search(name + r"\[9\] = \{([^}]*)\}", consts).group(1).replace("u", "").split(",")]
+        m = sum(l << (29 * i) for i, l in enumerate(v))
+        return m * pow(1 << 261, -1, Q) % Q
+    t2, t3 = limbs("ISO_T2"), limbs("ISO_T3")
+    assert pow(t2, 3, Q) == 82 * pow(3, -1, Q) % Q and t3 * t3 % Q == pow(t2, 3, Q)
+    return t2, t3
+def miller_constants():
+    t2, t3 = iso_constants()
+    gx, gy = gamma(1, 3, 1), gamma(1, 2, 1)
+    return {C_ONE: F2_ONE, C_T2: (t2, 0), C_NT2: (Q - t2, 0), C_T3: (t3, 0), C_NT3: (Q - t3, 0), C_B3: (27, Q - 3), C_NB3: (Q - 27, 3),
+            C_TWX: gx, C_TWY: gy, C_NTWY: f2_neg(gy)}
+
+def ate_naf():
+    n, naf = 6 * U + 2, []
+    while n:
+        z = (2 - (n % 4)) if (n & 1) else 0
+        n -= z; naf.append(z); n //= 2
+    return naf
+
+def miller_program(B):
+    """the fused NAF Miller loop of pairing.hpp miller_loop_sched<true> (groups/mod.rs:486-519 + 557-635 on the isomorphic curve),
+    division-free: the doubling step keeps 4R instead of R (homogeneous coordinates), which scales later lines by elements of Fq
+    that the final exponentiation removes.  Six phases per doubling step, seven per addition step."""
+    E = lambda ph: B.entry(ph)
+    prog = []
+    # ---- prologue: affine P and Q (one INV phase for both z), onto the isomorphic curve, R = Q, f = 1
+    ph = Phase("INV", "m.inv"); ph.add(a=[IN_PZ], dst=IZP); ph.add(a=[IN_QZ], dst=IZQ); prog.append(E(ph))
+    ph = Phase("PROD_MUL", "m.p1"); ph.add(a=[IZP], b=[IZP], dst=IZP2); ph.add(a=[IZQ], b=[IZQ], dst=IZQ2); prog.append(E(ph))
+    ph = Phase("PROD_MUL", "m.p2")
+    ph.add(a=[IZP2], b=[IZP], dst=IZP3); ph.add(a=[IZQ2], b=[IZQ], dst=IZQ3); ph.add(a=[IN_PX], b=[IZP2], dst=PXA); ph.add(a=[IN_QX], b=[IZQ2], dst=QXA)
+    prog.append(E(ph))
+    ph = Phase("PROD_MUL", "m.p3")
+    ph.add(a=[IN_PY], b=[IZP3], dst=PYA); ph.add(a=[IN_QY], b=[IZQ3], dst=QYA)
+    ph.add(a=[PXA], b=[C_T2], dst=PX); ph.add(a=[PXA], b=[C_NT2], dst=NPX); ph.add(a=[QXA], b=[C_T2], dst=QX); ph.add(a=[QXA], b=[C_T2], dst=RX)
+    prog.append(E(ph))
+    ph = Phase("PROD_MUL", "m.p4")
+    ph.add(a=[PYA], b=[C_T3], dst=PY); ph.add(a=[PYA], b=[C_NT3], dst=NPY); ph.add(a=[QYA], b=[C_T3], dst=QY); ph.add(a=[QYA], b=[C_NT3], dst=NQY)
+    ph.add(a=[QYA], b=[C_T3], dst=RY); ph.add(a=[C_ONE], b=[C_ONE], dst=RZ); ph.add(a=[C_ONE], b=[C_B3], dst=ZB); ph.add(a=[C_ONE], b=[C_NB3], dst=NZB)
+    ph.add(a=[C_ONE], b=[C_ONE], dst=RES[0])
+    for k in range(1, 6): ph.add(a=[ZERO], b=[ZERO], dst=RES[k])
+    prog.append(E(ph))
+    # ---- the sparse product f * (l0 + lvv v^2 + lvw v w) (fq12.rs:107-176 as a schoolbook product: 18 products, every output 3 terms)
+    a = RES
+    def sparse_products(ph):
+        for k in range(6):
+            ph.add(a=[a[k]], b=[ML0], dst=T27[3 * k]); ph.add(a=[a[k]], b=[MLVV], dst=T27[3 * k + 1]); ph.add(a=[a[k]], b=[MLVW], dst=T27[3 * k + 2])
+    def sparse_combine(ph):
+        t = lambda k, w: T27[3 * k + {"l0": 0, "lvv": 1, "lvw": 2}[w]]
+        ph.add(xp=[t(1, "lvv"), t(4, "lvw")], yp=[t(0, "l0")], dst=a[0])                       # a00 l0 + xi (a01 lvv + a11 lvw)
+        ph.add(xp=[t(2, "lvv"), t(5, "lvw")], yp=[t(1, "l0")], dst=a[1])
+        ph.add(yp=[t(2, "l0"), t(0, "lvv"), t(3, "lvw")], dst=a[2])
+        ph.add(xp=[t(2, "lvw"), t(4, "lvv")], yp=[t(3, "l0")], dst=a[3])
+        ph.add(xp=[t(5, "lvv")], yp=[t(0, "lvw"), t(4, "l0")], dst=a[4])
+        ph.add(yp=[t(1, "lvw"), t(5, "l0"), t(3, "lvv")], dst=a[5])
+    # ---- doubling step
+    XY, TB, TC, TS, TJ, TE, TNE, YZB, YNZB = TR
+    d1 = Phase("PROD_MUL", "m.d1")
+    A0, A1 = [[a[i]] for i in range(3)], [[a[3 + i]] for i in range(3)]
+    f6_products(d1, A0, A0, 0); f6_products(d1, A1, A1, 6); f6_products(d1, [A0[i] + A1[i] for i in range(3)], [A0[i] + A1[i] for i in range(3)], 12)
+    for (x, y, dst) in [([RX], [RY], XY), ([RY], [RY], TB), ([RZ], [RZ], TC), ([RY, RZ], [RY, RZ], TS), ([RX], [RX], TJ), ([RZ], [ZB], TE), ([RZ], [NZB], TNE),
+                        ([RY], [ZB], YZB), ([RY], [NZB], YNZB)]:
+        d1.add(a=x, b=y, dst=dst)
+    d2 = Phase("COMB_M2", "m.d2")
+    def f6c(ph, t0, dst):
+        aa, bb, cc, k0, k1, k2 = (T[t0 + i] for i in range(6))
+        ph.add(xp=[k0], xm=[bb, cc], yp=[aa], dst=dst[0]); ph.add(xp=[cc], yp=[k1], ym=[aa, bb], dst=dst[1]); ph.add(yp=[k2, bb], ym=[aa, cc], dst=dst[2])
+    f6c(d2, 0, V[0:3]); f6c(d2, 6, V[3:6]); f6c(d2, 12, V[6:9])
+    d2.add(yp=[TS], ym=[TB, TC], dst=MH)                                                        # h = (y + z)^2 - b - c
+    d3 = Phase("COMB_M2", "m.d3")
+    aa, bb, tt = V[0:3], V[3:6], V[6:9]
+    d3.add(xp=[bb[2]], yp=[aa[0]], dst=a[0]); d3.add(yp=[aa[1], bb[0]], dst=a[1]); d3.add(yp=[aa[2], bb[1]], dst=a[2])
+    for k in range(3): d3.add(yp=[tt[k]], ym=[aa[k], bb[k]], dst=a[3 + k])
+    d3.add(xp=[TE], xm=[TB], dst=ML0)                                                           # ell_0 = xi (e - b)
+    d4 = Phase("PROD_MUL", "m.d4")
+    TG, TE12 = TA[0], TA[1]
+    d4.add(a=[XY, XY], b=[TB, TNE, TNE, TNE], dst=RX)                                          # 4 x' = 2xy (b - 3e)
+    d4.add(a=[TB, TE, TE, TE], b=[TB, TE, TE, TE], dst=TG)                                     # (b + 3e)^2
+    d4.add(a=[TE, TE, TE, TE], b=[TE, TE, TE], dst=TE12)                                       # 12 e^2
+    d4.add(a=[TB, TB, TB, TB], b=[MH], dst=RZ)                                                 # 4 z' = 4 b h
+    d4.add(a=[TB, TB, TB, TB], b=[YZB, YZB], dst=ZB); d4.add(a=[TB, TB, TB, TB], b=[YNZB, YNZB], dst=NZB)     # +-(27 - 3i) z' = 4b * 2y * (+-(27 - 3i) z)
+    d4.add(a=[MH], b=[NPY], dst=MLVW); d4.add(a=[TJ, TJ, TJ], b=[PX], dst=MLVV)                # ell_vw yP = -h yP ; ell_vv xP = 3 x^2 xP
+    d5 = Phase("PROD_MUL", "m.d5"); sparse_products(d5)
+    d6 = Phase("COMB_M2", "m.d6"); sparse_combine(d6)
+    d6.add(yp=[TG], ym=[TE12], dst=RY)                                                          # 4 y' = (b + 3e)^2 - 12 e^2
+    DBL = [E(x) for x in (d1, d2, d3, d4, d5, d6)]
+    # ---- addition step R += (qx, qy)  (groups/mod.rs:592-610)
+    def add_step(qx, qy):
+        ZQX, ZQY, TF, TGG, EQX, DQY, TH, TI, TI2, TZG = TA
+        a1 = Phase("PROD_MUL", "m.a1"); a1.add(a=[RZ], b=[qx], dst=ZQX); a1.add(a=[RZ], b=[qy], dst=ZQY)
+        a2 = Phase("COMB_M2", "m.a2"); a2.add(yp=[RX], ym=[ZQX], dst=MD); a2.add(yp=[RY], ym=[ZQY], dst=ME)
+        a3 = Phase("PROD_MUL", "m.a3")
+        a3.add(a=[MD], b=[MD], dst=TF); a3.add(a=[ME], b=[ME], dst=TGG); a3.add(a=[ME], b=[qx], dst=EQX); a3.add(a=[MD], b=[qy], dst=DQY)
+        a3.add(a=[ME], b=[NPX], dst=MLVV); a3.add(a=[MD], b=[PY], dst=MLVW)                     # ell_vv xP = -e xP ; ell_vw yP = d yP
+        a4 = Phase("PROD_MUL", "m.a4")
+        a4.add(a=[MD], b=[TF], dst=TH); a4.add(a=[RX], b=[TF], dst=TI); a4.add(a=[RX, RX], b=[TF], dst=TI2); a4.add(a=[RZ], b=[TGG], dst=TZG)
+        a5 = Phase("COMB_M2", "m.a5")
+        a5.add(yp=[TZG, TH], ym=[TI2], dst=MJ)                                                  # j = z g + h - 2 i
+        a5.add(yp=[TI, TI2], ym=[TZG, TH], dst=MT)                                              # i - j
+        a5.add(xp=[EQX], xm=[DQY], dst=ML0)                                                     # ell_0 = xi (e qx - d qy)
+        a6 = Phase("PROD_MUL", "m.a6"); sparse_products(a6)
+        ET, HY = TA[0], TA[1]                                                                   # (ZQX, ZQY are dead)
+        a6.add(a=[ME], b=[MT], dst=ET); a6.add(a=[TH], b=[RY], dst=HY); a6.add(a=[MD], b=[MJ], dst=RX); a6.add(a=[RZ], b=[TH], dst=RZ)
+        a6.add(a=[ZB], b=[TH], dst=ZB); a6.add(a=[NZB], b=[TH], dst=NZB)                         # (27 - 3i) z' = ((27 - 3i) z) h
+        a7 = Phase("COMB_M2", "m.a7"); sparse_combine(a7); a7.add(yp=[ET], ym=[HY], dst=RY)
+        return [E(x) for x in (a1, a2, a3, a4, a5, a6, a7)]
+    ADD_P, ADD_N = add_step(QX, QY), add_step(QX, NQY)
+    naf = ate_naf()
+    nd = len(naf) - 1
+    for jj in range(nd):
+        prog += DBL
+        dgt = naf[nd - 1 - jj]
+        if dgt: prog += ADD_P if dgt > 0 else ADD_N
+    # ---- pi(Q), then -pi^2(Q)   (groups/mod.rs:578-582; mul_by_q :550-555 commutes with the isomorphism)
+    Q1X, Q1Y, Q2X, Q2Y = IZP, IZQ, IZP2, IZQ2                       # (prologue registers, dead by now)
+    f1 = Phase("PROD_MULC", "m.q1"); f1.add(a=[QX], b=[C_TWX], dst=Q1X, conj=True); f1.add(a=[QY], b=[C_TWY], dst=Q1Y, conj=True)
+    f2 = Phase("PROD_MULC", "m.q2"); f2.add(a=[Q1X], b=[C_TWX], dst=Q2X, conj=True); f2.add(a=[Q1Y], b=[C_NTWY], dst=Q2Y, conj=True)
+    prog += [E(f1)] + add_step(Q1X, Q1Y) + [E(f2)] + add_step(Q2X, Q2Y)
+    return prog
 
 # ------------------------------------------------------------------------------------------------ programs
 class Builder:
@@ -302,6 +502,10 @@ def build():
         if pt: h += put(pt - 1)
     progs["HARD"] = h + END
     progs["FE"] = e + h + END
+    B.nfe = len(B.phases)                                                   # the tables of the final exponentiation come first
+    mil = miller_program(B)
+    progs["MILLER"] = mil + END
+    progs["PAIRING"] = mil + e + h + END
     return B, progs
 
 # ------------------------------------------------------------------------------------------------ executor on exact values
@@ -330,6 +534,13 @@ def run(B, prog, regs):
                     Bv = F2_ZERO
                     for i in ro["b"]: Bv = f2_add(Bv, note(i))
                     val = f2_mul(A, Bv)
+            elif ph.kind == "COMB_M2":
+                X = F2_ZERO; Y = F2_ZERO
+                for i in ro.get("xp", []): X = f2_add(X, note(i))
+                for i in ro.get("xm", []): X = f2_sub(X, note(i))
+                for i in ro.get("yp", []): Y = f2_add(Y, note(i))
+                for i in ro.get("ym", []): Y = f2_sub(Y, note(i))
+                val = f2_add(f2_mul(XI, X), Y)
             else:
                 X = note(ro["xp"]) if "xp" in ro else F2_ZERO
                 for i in ro.get("xm", []): X = f2_sub(X, note(i))
@@ -352,6 +563,7 @@ def fresh_regs():
     regs = [F2_ZERO] * NREG
     for P in (1, 2, 3):
         for j, cst in enumerate(frob_constants(P)): regs[KBASE[P] + j] = cst
+    for r, v in miller_constants().items(): regs[r] = v
     return regs
 
 def self_check(B, progs):
@@ -384,6 +596,19 @@ def self_check(B, progs):
     assert [regs[r] for r in RES] == cyc_el, "EASY"
     regs = with_res(a); run(B, progs["FE"], regs)
     assert [regs[r] for r in RES] == final_exponentiation(a), "FE"
+    # the Miller loop: Jacobian inputs with z != 1; the machine's NAF / isomorphic-curve / division-free value differs from the
+    # reference's by factors the final exponentiation removes, so the comparison is after it - i.e. pairing() itself
+    P, Qa = g1_mul(rnd.randrange(R_ORD)), g2_mul(rnd.randrange(R_ORD))
+    want = final_exponentiation(ref_miller(P, Qa))
+    zp, zq = rnd.randrange(1, Q), rf2()
+    regs = fresh_regs()
+    regs[IN_PX], regs[IN_PY], regs[IN_PZ] = (P[0] * zp * zp % Q, 0), (P[1] * pow(zp, 3, Q) % Q, 0), (zp, 0)
+    zq2 = f2_mul(zq, zq)
+    regs[IN_QX], regs[IN_QY], regs[IN_QZ] = f2_mul(Qa[0], zq2), f2_mul(Qa[1], f2_mul(zq2, zq)), zq
+    r1 = list(regs); run(B, progs["MILLER"], r1)
+    assert final_exponentiation([r1[r] for r in RES]) == want, "MILLER"
+    run(B, progs["PAIRING"], regs)
+    assert [regs[r] for r in RES] == want, "PAIRING"
 
 # ------------------------------------------------------------------------------------------------ emit
 def mont_limbs(a):
@@ -400,7 +625,14 @@ def emit(B, progs, path):
     o.append("constexpr int KBASE_OFF[4] = {0, %d, %d, %d};          // Frobenius multipliers of map P: six registers from here" % tuple(off(KBASE[P]) for P in (1, 2, 3)))
     o.append("// the Frobenius multipliers as the engine's 9 x 29-bit Montgomery limbs (radix 2^261): [3 maps x 6 registers][c0, c1][limb]")
     o.append("BN254_CONSTANT uint32_t KCONST[18][2][9] = {\n    " + ",\n    ".join("{%s, %s}" % (mont_limbs(c[0]), mont_limbs(c[1])) for P in (1, 2, 3) for c in frob_constants(P)) + "};")
-    o.append("constexpr int NPHASES = %d, MULR_PHASE0 = %d;" % (len(B.phases), B.mulr0))
+    mc = sorted(miller_constants().items())
+    o.append("// constants of the Miller program (isomorphic-curve scalings, +-(27 - 3i), twist Frobenius coefficients): register offset, limbs")
+    o.append("constexpr int NMCONST = %d;" % len(mc))
+    o.append("BN254_CONSTANT uint32_t MCONST_OFF[%d] = {%s};" % (len(mc), ", ".join(str(off(r)) for r, _ in mc)))
+    o.append("BN254_CONSTANT uint32_t MCONST[%d][2][9] = {\n    %s};" % (len(mc), ",\n    ".join("{%s, %s}" % (mont_limbs(c[0]), mont_limbs(c[1])) for _, c in mc)))
+    o.append("constexpr int OFF_IN_P = %d, OFF_IN_Q = %d, OFF_C_ONE = %d;      // inputs of the Miller program: P as (x, 0), (y, 0), (z, 0); Q; the constant 1" % (off(IN_PX), off(IN_QX), off(C_ONE)))
+    assert [IN_PY, IN_PZ] == [IN_PX + 1, IN_PX + 2] and [IN_QY, IN_QZ] == [IN_QX + 1, IN_QX + 2] and (IN_PX >> 5) == (IN_PZ >> 5) and (IN_QX >> 5) == (IN_QZ >> 5)
+    o.append("constexpr int NPHASES = %d, NPHASES_FE = %d, MULR_PHASE0 = %d;      // NPHASES_FE: tables 0 .. of the programs without a Miller loop" % (len(B.phases), B.nfe, B.mulr0))
     o.append("// one role per lane pair and phase: 10 source indices (BYTE offsets of even slots, limb 0; REL = relative to the entry's base), dst, flags")
     o.append("struct Role { uint16_t src[10]; uint16_t dst; uint16_t flags; };")
     o.append("BN254_CONSTANT Role ROLES[NPHASES][32] = {")
@@ -429,5 +661,5 @@ if __name__ == "__main__":
     self_check(B, progs)
     counts = {}
     for (op, pid, b) in progs["FE"]: counts[op] = counts.get(op, 0) + 1
-    print("FE program: %d phases" % (len(progs["FE"]) - 1), {k: counts.get(v, 0) for k, v in OPS.items()}, "tables:", len(B.phases))
+    print("FE program: %d phases" % (len(progs["FE"]) - 1), {k: counts.get(v, 0) for k, v in OPS.items()}, "Miller program: %d phases" % (len(progs["MILLER"]) - 1), "tables:", len(B.phases))
     emit(B, progs, sys.argv[1] if len(sys.argv) > 1 else pathlib.Path(__file__).resolve().parents[1] / "bn_amd" / "csrc" / "wave_tables.hpp")

@@ -40,6 +40,10 @@ for m in (1, 2, 8, 64):
     res["tail_ms"][m] = timed(lambda: te.e.gt_product_final_exp_dev(f.data_ptr(), m, one.data_ptr(), te._stream()), reps=10)
 # whole multi-pairing on one GPU: 2^15 and 2^18 pairs (BASELINE configs[3] per-GPU shard and total)
 res["pairing_product_ms"] = {n: timed(lambda: D.pairing_product_sharded(te, P[:n], Q[:n]), reps=5, warm=2) for n in (1, 4, 1 << 15, 1 << 18)}
+for name, thr in (("wave", 1 << 20), ("lane_pair", 0)):
+    os.environ["BN254_WAVE_PAIRING_MAX"] = str(thr); os.environ["BN254_WAVE_FE_MAX"] = str(1024 if thr else 0)
+    res.setdefault("pairing_batch_ms", {})[name] = {n: timed(lambda: te.e.pairing_batch_dev(P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 4, 64, 256, 512, 768, 1024, 2048)}
+os.environ.pop("BN254_WAVE_PAIRING_MAX"); os.environ.pop("BN254_WAVE_FE_MAX")
 res["miller_only_ms"] = {n: timed(lambda: te.e.miller_batch_dev(P.data_ptr(), Q.data_ptr(), f.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 1 << 15, 1 << 16)}
 # by-value pairing through the host-buffer API (what `pairing(p, q)` of lib.rs:181-183 costs a caller)
 e = bn_amd.Engine(0)
