@@ -252,7 +252,7 @@ size_t bn_sub_launch(const bn254_ctx *c, size_t n) {
 // tables and the register file take 52 KB of LDS per pairing: three per CU.  BN254_WAVE_PAIRING_MAX overrides.
 size_t bn_wave_pairing_max() {
     const char *e = getenv("BN254_WAVE_PAIRING_MAX");
-    return e ? (size_t)atol(e) : 512;
+    return e ? (size_t)atol(e) : 2048;
 }
 // naf: the value is only consumed by a final exponentiation, so the shorter NAF schedule may be used (pairing.hpp)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf) {
@@ -279,7 +279,7 @@ int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t
 // while a lane pair needs 2.05 ms for its serial chain); beyond ~2700 the lane-pair kernel's throughput wins (profiles/r03a_*).  BN254_WAVE_FE_MAX overrides.
 size_t bn_wave_fe_max() {
     const char *e = getenv("BN254_WAVE_FE_MAX");
-    return e ? (size_t)atol(e) : 1024;
+    return e ? (size_t)atol(e) : 2048;
 }
 // table: the caller's own table buffer (pipelined path: one per chunk in flight) or NULL for the context's (under a BnScratchGuard)
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table) {
