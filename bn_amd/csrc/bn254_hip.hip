@@ -777,7 +777,7 @@ int bn254_profile_reset(bn254_ctx *ctx) {
 // per-program time of the wave-cooperative machine on ONE wave (bn254_wave_ubench_W): ms for `iters` runs of program `which`
 int bn254_wave_ubench(bn254_ctx *ctx, int which, int iters, double *ms_out) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;
-    if (which < 0 || which > 4 || iters < 1 || !ms_out) return BN254_E_BAD_ARG;
+    if (which < 0 || which > 5 || iters < 1 || !ms_out) return BN254_E_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));

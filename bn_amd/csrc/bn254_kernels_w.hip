@@ -120,14 +120,14 @@ __global__ void __launch_bounds__(64) bn254_gt_tail_W(const uint32_t *in, uint32
 }
 
 // measurement: `iters` runs of one program on one wave (which: 0 cyclotomic squaring = 2 phases, 1 product = 3 phases, 2 slot copy =
-// 1 COMB phase, 3 Frobenius map = 1 PROD phase with conjugation, 4 the whole final exponentiation)
+// 1 COMB phase, 3 Frobenius map = 1 PROD phase with conjugation, 4 the whole final exponentiation, 5 a fused run of five squarings)
 __global__ void __launch_bounds__(64) bn254_wave_ubench_W(int which, int iters, uint32_t *out) {
     __shared__ WaveLds lds;
     WaveDev w = wave_init(lds);
     w.sync();
     if (threadIdx.x < 12) w.st(OFF_RES + 8u * (threadIdx.x >> 1), w.ld((uint32_t)KBASE_OFF[1] + 8u * (threadIdx.x >> 1) + 8u));
     w.sync();
-    const uint32_t *prog = which == 0 ? PROG_CYC : which == 1 ? PROG_MUL : which == 2 ? PROG_PUT0 : which == 3 ? PROG_FROB1 : PROG_FE;
+    const uint32_t *prog = which == 0 ? PROG_CYC : which == 1 ? PROG_MUL : which == 2 ? PROG_PUT0 : which == 3 ? PROG_FROB1 : which == 4 ? PROG_FE : PROG_CYC5;
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) w_run(w, prog);
     w_store_f12(w, OFF_RES, out);

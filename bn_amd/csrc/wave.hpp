@@ -33,14 +33,19 @@ BN_FN Fe fe_cneg(bool flag, const Fe &z) {
 }
 namespace wv {
 
-BN_FN uint32_t w_addr(uint32_t idx, uint32_t base) { return (idx & REL) ? (idx & 0x7fffu) + base : idx; }
+// REL = true: the table may hold indices relative to the program entry's base register (products by a table slot, slot copies)
+template <bool RELX>
+BN_FN uint32_t w_addr(uint32_t idx, uint32_t base) {
+    if constexpr (RELX) return (idx & REL) ? (idx & 0x7fffu) + base : idx;
+    else return idx;
+}
 
-template <int NA, int NB, bool SQR, bool CONJ, class W>
+template <int NA, int NB, bool SQR, bool CONJ, bool RELX, class W>
 BN_FN void w_prod(W &w, const Role &r, uint32_t base) {
     using T = typename W::T;
-    T a = w.ld(w_addr(r.src[0], base));
+    T a = w.ld(w_addr<RELX>(r.src[0], base));
 #pragma unroll
-    for (int k = 1; k < NA; ++k) a = fe_add(a, w.ld(w_addr(r.src[k], base)));
+    for (int k = 1; k < NA; ++k) a = fe_add(a, w.ld(w_addr<RELX>(r.src[k], base)));
     if (NA > 1) a = fe_norm(a);
     if constexpr (CONJ) {                                              // conjugate of the first operand: the odd lane negates (lazy: lb 2, vb 4)
         T n = lane_pick(a, fe_neg<1, 4>(a));
@@ -50,50 +55,65 @@ BN_FN void w_prod(W &w, const Role &r, uint32_t base) {
     if constexpr (SQR) {
         res = f2b_sqr_body(a);
     } else {
-        T b = w.ld(w_addr(r.src[4], base));
+        T b = w.ld(w_addr<RELX>(r.src[4], base));
 #pragma unroll
-        for (int k = 1; k < NB; ++k) b = fe_add(b, w.ld(w_addr(r.src[4 + k], base)));
+        for (int k = 1; k < NB; ++k) b = fe_add(b, w.ld(w_addr<RELX>(r.src[4 + k], base)));
         if (NB > 1) b = fe_norm(b);
         res = f2b_mul_body(a, b);
     }
-    if (r.flags & 1) w.st(w_addr(r.dst, base), res);
+    if (r.flags & 1) w.st(w_addr<RELX>(r.dst, base), res);
 }
 
 // the reduction of one output coefficient: x = R[x0] - R[x1] - R[x2], y = R[y0] + R[y1] - R[y2] - R[y3] as signed lazy limb sums,
 //   M: xi x + y              = fe_lc3_par<9, 1, 1>(x, partner x, y)             (f2_lc_xi<1, 1> of fq2.hpp)
 //   C: 3 xi x + 3 y +- 2 z   = fe_lc4_par<27, 3, 3, 2>(x, partner x, y, +-z)    (f2_lc_xi2 of fq2.hpp; the Granger-Scott update)
-template <bool CYC, class W>
+template <bool CYC, bool RELX, class W>
 BN_FN void w_comb(W &w, const Role &r, uint32_t base) {
     using T = typename W::T;
-    T x = fe_ssub(fe_ssub(w.ld(w_addr(r.src[0], base)), w.ld(w_addr(r.src[1], base))), w.ld(w_addr(r.src[2], base)));
-    T y = fe_ssub(fe_ssub(fe_add(w.ld(w_addr(r.src[3], base)), w.ld(w_addr(r.src[4], base))), w.ld(w_addr(r.src[5], base))), w.ld(w_addr(r.src[6], base)));
+    T x = fe_ssub(fe_ssub(w.ld(w_addr<RELX>(r.src[0], base)), w.ld(w_addr<RELX>(r.src[1], base))), w.ld(w_addr<RELX>(r.src[2], base)));
+    T y = fe_ssub(fe_ssub(fe_add(w.ld(w_addr<RELX>(r.src[3], base)), w.ld(w_addr<RELX>(r.src[4], base))), w.ld(w_addr<RELX>(r.src[5], base))), w.ld(w_addr<RELX>(r.src[6], base)));
     T res;
     if constexpr (CYC) {
-        T z = fe_cneg((r.flags & 2) != 0, w.ld(w_addr(r.src[7], base)));
+        T z = fe_cneg((r.flags & 2) != 0, w.ld(w_addr<RELX>(r.src[7], base)));
         res = fe_lc4_par<27, 3, 3, 2>(x, lane_partner(x), y, z);
     } else {
         res = fe_lc4_par<9, 1, 1, 0>(x, lane_partner(x), y, y);
     }
-    if (r.flags & 1) w.st(w_addr(r.dst, base), res);
+    if (r.flags & 1) w.st(w_addr<RELX>(r.dst, base), res);
+}
+
+// A run of cyclotomic squarings, one phase per squaring: the pair reduces the operand of its NEXT square from the previous products
+// - the Granger-Scott update 3 xi x + 3 y + 2 z with x = R[x0] - R[x1] - R[x2], y = R[y0] - R[y1] - R[y2], z = R[z0] - R[z1] (the
+// (a + b) pairs reduce a' + b' directly: the update is linear) -, keeps it when it is a coefficient of the running value, squares it.
+template <class W>
+BN_FN void w_fuse_sqr(W &w, const Role &r) {
+    using T = typename W::T;
+    T x = fe_ssub(fe_ssub(w.ld(r.src[0]), w.ld(r.src[1])), w.ld(r.src[2]));
+    T y = fe_ssub(fe_ssub(w.ld(r.src[3]), w.ld(r.src[4])), w.ld(r.src[5]));
+    T z = fe_ssub(w.ld(r.src[6]), w.ld(r.src[7]));
+    T a = fe_lc4_par<27, 3, 3, 2>(x, lane_partner(x), y, z);
+    if (r.flags & 2) w.st(r.src[8], a);
+    T res = f2b_sqr_body(a);
+    if (r.flags & 1) w.st(r.dst, res);
 }
 
 // the wider combination of the Miller program: x = R[x0] + R[x1] - R[x2] - R[x3], y = R[y0] + R[y1] + R[y2] - R[y3] - R[y4]; xi x + y
 template <class W>
 BN_FN void w_comb2(W &w, const Role &r, uint32_t base) {
     using T = typename W::T;
-    T x = fe_ssub(fe_ssub(fe_add(w.ld(w_addr(r.src[0], base)), w.ld(w_addr(r.src[1], base))), w.ld(w_addr(r.src[2], base))), w.ld(w_addr(r.src[3], base)));
-    T y = fe_add(fe_add(w.ld(w_addr(r.src[4], base)), w.ld(w_addr(r.src[5], base))), w.ld(w_addr(r.src[6], base)));
-    y = fe_ssub(fe_ssub(y, w.ld(w_addr(r.src[7], base))), w.ld(w_addr(r.src[8], base)));
+    T x = fe_ssub(fe_ssub(fe_add(w.ld(w_addr<false>(r.src[0], base)), w.ld(w_addr<false>(r.src[1], base))), w.ld(w_addr<false>(r.src[2], base))), w.ld(w_addr<false>(r.src[3], base)));
+    T y = fe_add(fe_add(w.ld(w_addr<false>(r.src[4], base)), w.ld(w_addr<false>(r.src[5], base))), w.ld(w_addr<false>(r.src[6], base)));
+    y = fe_ssub(fe_ssub(y, w.ld(w_addr<false>(r.src[7], base))), w.ld(w_addr<false>(r.src[8], base)));
     T res = fe_lc4_par<9, 1, 1, 0>(x, lane_partner(x), y, y);
-    if (r.flags & 1) w.st(w_addr(r.dst, base), res);
+    if (r.flags & 1) w.st(w_addr<false>(r.dst, base), res);
 }
 
 template <class W>
 BN_FN void w_inv(W &w, const Role &r, uint32_t base) {
     using T = typename W::T;
-    Fq2B<T> a = {w.ld(w_addr(r.src[0], base))};
+    Fq2B<T> a = {w.ld(w_addr<false>(r.src[0], base))};
     Fq2B<T> t = f2_inverse(a);
-    if (r.flags & 1) w.st(w_addr(r.dst, base), t.v);
+    if (r.flags & 1) w.st(w_addr<false>(r.dst, base), t.v);
 }
 
 // runs a program (wave_tables.hpp PROG_*): one phase per entry, a wave-level barrier after each
@@ -105,12 +125,15 @@ BN_FN void w_run(W &w, const uint32_t *prog) {
         const uint32_t op = e & 15u, phase = (e >> 4) & 255u, base = e >> 12;
         if (op == OP_END) break;
         const Role r = w.role(phase);
-        if (op == OP_PROD_SQR) w_prod<2, 0, true, false>(w, r, base);
-        else if (op == OP_COMB_C) w_comb<true>(w, r, base);
-        else if (op == OP_PROD_MUL) w_prod<4, 4, false, false>(w, r, base);
-        else if (op == OP_COMB_M) w_comb<false>(w, r, base);
+        if (op == OP_FUSE_SQR) w_fuse_sqr(w, r);
+        else if (op == OP_PROD_SQR) w_prod<2, 0, true, false, false>(w, r, base);
+        else if (op == OP_COMB_C) w_comb<true, false>(w, r, base);
+        else if (op == OP_PROD_MUL) w_prod<4, 4, false, false, false>(w, r, base);
+        else if (op == OP_PROD_MULR) w_prod<4, 4, false, false, true>(w, r, base);
+        else if (op == OP_COMB_M) w_comb<false, false>(w, r, base);
+        else if (op == OP_COMB_MR) w_comb<false, true>(w, r, base);
         else if (op == OP_COMB_M2) w_comb2(w, r, base);
-        else if (op == OP_PROD_MULC) w_prod<1, 1, false, true>(w, r, base);
+        else if (op == OP_PROD_MULC) w_prod<1, 1, false, true, false>(w, r, base);
         else w_inv(w, r, base);
         w.sync();
     }

@@ -243,12 +243,13 @@ EXPORT int hs_g2_decode(const uint8_t *in, uint32_t *o) { return g2_decode_recor
 
 // ---------------------------------------------------------------- the wave-cooperative Fq12 machine (bn_amd/csrc/wave.hpp)
 #include "wavesim.hpp"
-// which: 0 MUL (res * slot0), 1 MULC (res * conj(slot0)), 2 CYC, 3..5 FROB1..3, 6 EASY, 7 HARD, 8 FE.   `b` is only read by 0, 1.
+// which: 0 MUL (res * slot0), 1 MULC (res * conj(slot0)), 2 CYC, 3..5 FROB1..3, 6 EASY, 7 HARD, 8 FE, 9 CYC5 (five squarings as one
+// fused run).   `b` is only read by 0, 1.
 EXPORT void hsw_run(int which, const uint32_t *a, const uint32_t *b, uint32_t *o) {
     using namespace bn254::wv;
     static WaveSimShared sh;
     wavesim_init(sh);
-    const uint32_t *progs[] = {PROG_MUL, PROG_MULC, PROG_CYC, PROG_FROB1, PROG_FROB2, PROG_FROB3, PROG_EASY, PROG_HARD, PROG_FE};
+    const uint32_t *progs[] = {PROG_MUL, PROG_MULC, PROG_CYC, PROG_FROB1, PROG_FROB2, PROG_FROB3, PROG_EASY, PROG_HARD, PROG_FE, PROG_CYC5};
     const uint32_t *prog = progs[which];
     wavesim_run(sh, [&](WaveSim &w) {
         if (which <= 1) {

@@ -57,6 +57,9 @@ def test_tables_against_the_big_integer_model(gen):
     c = M.final_exp_first_chunk(_unflat(a))
     assert run("EASY", a) == _flat(c)
     assert run("CYC", _flat(c)) == _flat(M.f12_cyclotomic_squared(c))
+    c32 = c
+    for _ in range(5): c32 = M.f12_cyclotomic_squared(c32)
+    assert run("CYC5", _flat(c)) == _flat(c32)
     assert run("HARD", _flat(c)) == _flat(M.final_exp_last_chunk(c))
     assert run("FE", a) == _flat(M.final_exponentiation(_unflat(a)))
     # the Miller program: FE(machine Miller loop) == pairing of the oracle's model (groups/mod.rs:764-771), Jacobian inputs
@@ -91,6 +94,9 @@ def test_wave_machine_in_host_simulation(oracle, hs, kats):
         c = oracle.fq12_final_exp_first_chunk(a)
         assert np.array_equal(hs.call("hsw_run", 6, a, z, out_words=96), c)
         assert np.array_equal(hs.call("hsw_run", 2, c, z, out_words=96), oracle.fq12_cyclotomic_squared(c))
+        c32 = c
+        for _ in range(5): c32 = oracle.fq12_cyclotomic_squared(c32)
+        assert np.array_equal(hs.call("hsw_run", 9, c, z, out_words=96), c32)                      # a fused run of five squarings
         assert np.array_equal(hs.call("hsw_run", 8, a, z, out_words=96), oracle.fq12_final_exponentiation(a))
     one = oracle.fq12_one()
     assert np.array_equal(hs.call("hsw_run", 8, one, z, out_words=96), one)

@@ -164,7 +164,10 @@ def slot(s): return 64 + 32 * (s // 3) + 9 * (s % 3)       # table slot s: 6 reg
 def off(reg): return 4 * ((reg >> 5) * PAGE_DW + ((reg & 31) << 1))       # BYTE offset of the register's even slot, limb 0
 def rel(k): return ('rel', k)    # k-th register after the entry's base
 
-OPS = {"PROD_MUL": 0, "PROD_MULC": 1, "PROD_SQR": 2, "COMB_M": 3, "COMB_C": 4, "INV": 5, "COMB_M2": 6, "END": 15}
+# PROD_MULR / COMB_MR are PROD_MUL / COMB_M whose tables contain REL indices (products by a table slot, slot copies): only they pay
+# for the decode of the flag
+# FUSE_SQR: the recombination of one cyclotomic squaring and the products of the NEXT one in a single phase (runs of squarings)
+OPS = {"PROD_MUL": 0, "PROD_MULC": 1, "PROD_SQR": 2, "COMB_M": 3, "COMB_C": 4, "INV": 5, "COMB_M2": 6, "PROD_MULR": 7, "COMB_MR": 8, "FUSE_SQR": 9, "END": 15}
 
 class Phase:
     def __init__(self, kind, name):
@@ -187,6 +190,11 @@ def role_words(kind, ro):
         a = [enc(x) for x in ro["a"]] + [z] * (4 - len(ro["a"]))
         b = [enc(x) for x in ro.get("b", [])] + [z] * (4 - len(ro.get("b", [])))
         return a + b + [z, z] + [enc(ro["dst"]), 1 | (2 if ro.get("conj") else 0)]
+    if kind == "FUSE_SQR":
+        pad = lambda l, n: [enc(x) for x in l] + [z] * (n - len(l))
+        xs = [enc(ro.get("xp", ZERO))] + pad(ro.get("xm", []), 2)
+        ys = [enc(ro.get("yp", ZERO))] + pad(ro.get("ym", []), 2)
+        return xs + ys + [enc(ro.get("zp", ZERO)), enc(ro.get("zm", ZERO)), enc(ro.get("keep", ZERO)), z] + [enc(ro["dst"]), 1 | (2 if "keep" in ro else 0)]
     if kind == "COMB_M2":
         xp, xm, yp, ym = ro.get("xp", []), ro.get("xm", []), ro.get("yp", []), ro.get("ym", [])
         assert len(xp) <= 2 and len(xm) <= 2 and len(yp) <= 3 and len(ym) <= 2
@@ -242,6 +250,44 @@ def cyc_phases():
         else: c.add(yp=[T[3 * g + 2]], ym=[T[3 * g], T[3 * g + 1]], z=z[zi], dst=z[zi])                            # 3 (2ab) + 2 z
     even(0, 0); odd(0, 1, False); even(1, 4); odd(1, 5, False); even(2, 3); odd(2, 2, True)
     return [p, c]
+
+RES1 = list(range(26, 32))         # second bank of the running value (runs of fused squarings alternate between the two)
+def cyc_fused_phases():
+    """Runs of cyclotomic squarings: after the first products, ONE phase per further squaring - every active pair reduces the operand
+    of its NEXT square from the previous products (the Granger-Scott update is linear, so the (a + b) pairs reduce a' + b' directly:
+    3 xi X + 3 Y + 2 (z_b - z_a)) and squares it.  Products and running value alternate between two register banks, so no pair reads
+    what another writes.  Returns (fuse[parity], final_comb[parity]): fuse[p] reads bank p and writes bank 1 - p; final_comb[p]
+    turns the products of bank p into the running value in bank 0."""
+    zi = {0: 0, 4: 1, 3: 2, 2: 3, 1: 4, 5: 5}                                    # z index -> position in RES
+    bank = lambda p: (T[9 * p: 9 * p + 9], RES if p == 0 else RES1)
+    fuse, final = {}, {}
+    for p in (0, 1):
+        (S, Z), (S2, Z2) = bank(p), bank(1 - p)
+        z = lambda i: Z[zi[i]]
+        zn = lambda i: Z2[zi[i]]
+        f = Phase("FUSE_SQR", "cycf%d" % p)
+        # group 0 (a, b) = (z0, z1): next operands from its own products S[0..2]
+        f.add(xp=S[1], yp=S[0], zm=z(0), keep=zn(0), dst=S2[0])
+        f.add(yp=S[2], ym=[S[0], S[1]], zp=z(1), keep=zn(1), dst=S2[1])
+        f.add(xp=S[1], yp=S[2], ym=[S[1]], zp=z(1), zm=z(0), dst=S2[2])
+        # group 1 (a, b) = (z2, z3): next operands z2', z3' come from the products of group 2, S[6..8]
+        f.add(xp=S[8], xm=[S[6], S[7]], zp=z(2), keep=zn(2), dst=S2[3])
+        f.add(xp=S[7], yp=S[6], zm=z(3), keep=zn(3), dst=S2[4])
+        f.add(xp=S[8], xm=[S[6]], yp=S[6], zp=z(2), zm=z(3), dst=S2[5])
+        # group 2 (a, b) = (z4, z5): next operands from the products of group 1, S[3..5]
+        f.add(xp=S[4], yp=S[3], zm=z(4), keep=zn(4), dst=S2[6])
+        f.add(yp=S[5], ym=[S[3], S[4]], zp=z(5), keep=zn(5), dst=S2[7])
+        f.add(xp=S[4], yp=S[5], ym=[S[4]], zp=z(5), zm=z(4), dst=S2[8])
+        fuse[p] = f
+        c = Phase("COMB_C", "cyc.final%d" % p)
+        out = lambda i: RES[zi[i]]
+        def even(g, i): c.add(xp=S[3 * g + 1], yp=[S[3 * g]], z=z(i), zneg=True, dst=out(i))
+        def odd(g, i, xi_):
+            if xi_: c.add(xp=S[3 * g + 2], xm=[S[3 * g], S[3 * g + 1]], z=z(i), dst=out(i))
+            else: c.add(yp=[S[3 * g + 2]], ym=[S[3 * g], S[3 * g + 1]], z=z(i), dst=out(i))
+        even(0, 0); odd(0, 1, False); even(1, 4); odd(1, 5, False); even(2, 3); odd(2, 2, True)
+        final[p] = c
+    return fuse, final
 
 def copy_phase(name, src, dst, neg=()):
     """dst[i] = src[i] (value preserving reduction), or -src[i] for i in neg"""
@@ -412,7 +458,13 @@ class Builder:
             self.index[key] = len(self.phases); self.phases.append(ph)
         return self.index[key]
     def entry(self, ph, base=0):
-        return (OPS[ph.kind], self.pid(ph), off(base))
+        uses_rel = any(w & REL for r in ph.roles for w in role_words(ph.kind, r)[:11])
+        kind = ph.kind
+        if uses_rel:
+            kind = {"PROD_MUL": "PROD_MULR", "COMB_M": "COMB_MR"}[kind]
+        else:
+            base = 0                                             # no relative index in this table: the base is never read
+        return (OPS[kind], self.pid(ph), off(base))
 
 def build():
     B = Builder()
@@ -428,6 +480,21 @@ def build():
     FROB = {P: frob_phase(P) for P in (1, 2, 3)}
     def mul_by(s, conj=False): return [B.entry(ph, slot(s)) for ph in (MULC if conj else MUL)]
     def cyc(): return [B.entry(ph) for ph in CYC]
+    FUSE, FINAL = cyc_fused_phases()
+    def fuse_runs(prog):
+        """k >= 2 consecutive squarings [P C] [P C] ... -> P F F ... F C': k + 1 phases instead of 2k"""
+        one = cyc(); out = []; i = 0
+        while i < len(prog):
+            k = 0
+            while prog[i + 2 * k: i + 2 * k + 2] == one: k += 1
+            if k >= 2:
+                out.append(one[0])
+                out += [B.entry(FUSE[j % 2]) for j in range(k - 1)]
+                out.append(B.entry(FINAL[(k - 1) % 2]))
+                i += 2 * k
+            else:
+                out.append(prog[i]); i += 1
+        return out
     def put(s): return [B.entry(PUT, slot(s))]
     def get(s): return [B.entry(GET, slot(s))]
     END = [(OPS["END"], 0, 0)]
@@ -500,6 +567,8 @@ def build():
         if post == 1: h += [B.entry(CONJ)]
         elif post: h += [B.entry(FROB[post - 1])]
         if pt: h += put(pt - 1)
+    progs["CYC5"] = fuse_runs(cyc() * 5) + END                            # five squarings as one fused run (tests, measurement)
+    h = fuse_runs(h)
     progs["HARD"] = h + END
     progs["FE"] = e + h + END
     B.nfe = len(B.phases)                                                   # the tables of the final exponentiation come first
@@ -534,6 +603,17 @@ def run(B, prog, regs):
                     Bv = F2_ZERO
                     for i in ro["b"]: Bv = f2_add(Bv, note(i))
                     val = f2_mul(A, Bv)
+            elif ph.kind == "FUSE_SQR":
+                X = note(ro["xp"]) if "xp" in ro else F2_ZERO
+                for i in ro.get("xm", []): X = f2_sub(X, note(i))
+                Y = note(ro["yp"]) if "yp" in ro else F2_ZERO
+                for i in ro.get("ym", []): Y = f2_sub(Y, note(i))
+                Z = f2_sub(note(ro["zp"]) if "zp" in ro else F2_ZERO, note(ro["zm"]) if "zm" in ro else F2_ZERO)
+                opnd = f2_add(f2_scale(f2_add(f2_mul(XI, X), Y), 3), f2_scale(Z, 2))
+                if "keep" in ro:
+                    kd = wr_idx(ro["keep"], base)
+                    assert kd not in writes; writes[kd] = pi; out.append((kd, opnd))
+                val = f2_mul(opnd, opnd)
             elif ph.kind == "COMB_M2":
                 X = F2_ZERO; Y = F2_ZERO
                 for i in ro.get("xp", []): X = f2_add(X, note(i))
@@ -592,6 +672,8 @@ def self_check(B, progs):
     c = f12_mul(f12_conj(a), f12_inv(a)); cyc_el = f12_mul(f12_frob(c, 2), c)
     regs = with_res(cyc_el); run(B, progs["CYC"], regs)
     assert [regs[r] for r in RES] == f12_mul(cyc_el, cyc_el), "CYC"
+    regs = with_res(cyc_el); run(B, progs["CYC5"], regs)
+    assert [regs[r] for r in RES] == f12_pow(cyc_el, 32), "CYC5"
     regs = with_res(a); run(B, progs["EASY"], regs)
     assert [regs[r] for r in RES] == cyc_el, "EASY"
     regs = with_res(a); run(B, progs["FE"], regs)

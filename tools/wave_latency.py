@@ -54,5 +54,5 @@ for n in (1, 4, 64):
     t0 = time.perf_counter()
     for _ in range(20): e.pairing_batch(Pn[:n], Qn[:n], outn[:n])
     res.setdefault("host_pairing_batch_ms", {})[n] = (time.perf_counter() - t0) / 20 * 1e3
-res["wave_program_us"] = {name: e.wave_ubench(k, 50 if k == 4 else 400) for k, name in enumerate(("cyclotomic_sqr_2_phases", "product_3_phases", "slot_copy_1_comb", "frobenius_1_prod", "final_exp_574_phases"))}
+res["wave_program_us"] = {name: e.wave_ubench(k, 50 if k == 4 else 400) for k, name in enumerate(("cyclotomic_sqr_2_phases", "product_3_phases", "slot_copy_1_comb", "frobenius_1_prod", "final_exp", "five_fused_squarings_6_phases"))}
 print(json.dumps(res))
