@@ -234,7 +234,7 @@ def bench_gtpow(args, eng, dev, world, rank):
                                "weak", f"{n} Gt values ^ distinct random Fr per GPU per step", {"roofline": rf})), flush=True)
 
 
-PRODUCT_KERNELS = ("miller", "gt_product", "gt_tail", "final_exp_wave", "final_exp")
+PRODUCT_KERNELS = ("miller", "miller_shared", "miller_wave", "gt_product", "gt_tail", "final_exp_wave", "final_exp")
 
 
 def run_product(eng, dev, dist, P, Q, steps, warmup):

@@ -422,7 +422,7 @@ void bn254_ctx_destroy(bn254_ctx *c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (auto &r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-    c->ws.release(); c->exp_tbl.release(); c->pow_tbl.release();
+    c->ws.release(); c->exp_tbl.release(); c->pow_tbl.release(); c->miller_state.release();
     for (auto &b : c->stage) b.release();
     for (auto &s : c->slot) {
         for (auto &b : s.d_in) b.release();
@@ -500,6 +500,15 @@ int bn254_gt_product_final_exp_dev(bn254_ctx *ctx, const void *d_in, size_t m, v
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
     return bn_launch_product_final_exp(ctx, d_in, m, d_out, s);
 }
+// How many pairs share one accumulator f in the multi-pairing's Miller loop (pairing.hpp miller_loop_shared): as many as keep at least
+// one full machine round of lane pairs busy - 4 from four rounds of pairs on (configs[3] on one GPU: 2^18), 2 from two, else the
+// plain kernel (a per-GPU shard of 2^15 must not be folded onto a quarter of the machine).  BN254_MILLER_SHARED=1|2|4 overrides.
+static int miller_shared_m(const bn254_ctx *c, size_t n) {
+    const char *e = getenv("BN254_MILLER_SHARED");
+    if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) return atoi(e);
+    const size_t round = bn_round_pairs(c);
+    return n >= 4 * round ? 4 : n >= 2 * round ? 2 : 1;
+}
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;
     if (!d_partial || (n && (!d_p || !d_q)) || n > 0xffffffffu) return BN254_E_BAD_ARG;
@@ -508,10 +517,26 @@ int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, s
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
-    size_t fbytes = n * 384;
-    rc = ctx->ws.reserve(fbytes + bn_product_tmp_bytes(n)); if (rc) return rc;
-    rc = bn_launch_miller(ctx, d_p, d_q, ctx->ws.p, n, s, true); if (rc) return rc;
-    return bn_launch_product(ctx, ctx->ws.p, n, d_partial, (char *)ctx->ws.p + fbytes, s);
+    const int m = (ctx->mapping.load() == 1 && n > bn_wave_pairing_max()) ? miller_shared_m(ctx, n) : 1;
+    const size_t nv = (n + (size_t)m - 1) / (size_t)m;             // Miller values that reach the product tree
+    const size_t fbytes = nv * 384;
+    rc = ctx->ws.reserve(fbytes + bn_product_tmp_bytes(nv)); if (rc) return rc;
+    if (m == 1) {
+        rc = bn_launch_miller(ctx, d_p, d_q, ctx->ws.p, n, s, true); if (rc) return rc;
+    } else {
+        // sub-launches of at most one round of LANE PAIRS, each with m pairs: one state buffer, reused in stream order
+        const size_t step = bn_sub_launch(ctx, nv);
+        rc = ctx->miller_state.reserve(bn254_miller_shared_state_bytes_B(step * (size_t)m, m)); if (rc) return rc;
+        for (size_t lo = 0; lo < nv; lo += step) {
+            const size_t groups = nv - lo < step ? nv - lo : step, first = lo * (size_t)m;
+            const size_t cnt = n - first < groups * (size_t)m ? n - first : groups * (size_t)m;
+            BnScope sc(ctx, s, "miller_shared");
+            rc = bn254_launch_miller_shared_B((const char *)d_p + first * sizeof(bn_g1), (const char *)d_q + first * sizeof(bn_g2),
+                                              (char *)ctx->ws.p + lo * sizeof(bn_gt), cnt, m, ctx->miller_state.p, s);
+            if (rc) return rc;
+        }
+    }
+    return bn_launch_product(ctx, ctx->ws.p, nv, d_partial, (char *)ctx->ws.p + fbytes, s);
 }
 static int mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream, int normalize) {
     BN_DEV_PROLOGUE(!d_p || !d_k || !d_out, BN_N_MAX);

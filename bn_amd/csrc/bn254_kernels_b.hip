@@ -293,6 +293,87 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     if (live) f12_store(f, out + 96u * pair);
     BN_STAMP_END();
 }
+// ---- the multi-pairing's Miller loop with a shared accumulator (pairing.hpp miller_loop_shared): M pairs per lane pair
+// State of the M pairs in global memory: per lane and pair 17 x 16 bytes - R (27 dwords in 7 groups of 4), the base point (18 in 5),
+// P (18 in 5) -, group-major, then the lane: every access of a wave is one coalesced dwordx4 instruction over 1 KB (ExpTableMem's
+// layout).  Both lanes of a pair hold P (an Fq point) replicated.
+template <int M>
+struct MillerStateMem {
+    uint4 *base;             // wave-uniform
+    uint32_t lane, stride;   // this lane's column, lanes in the launch
+    uint32_t infmask;        // bit i: pair i is (treated as) infinite
+    __device__ __forceinline__ uint32_t row(int i, int g) const { return (uint32_t)(i * 17 + g) * stride + lane; }
+    template <int N, int G0>
+    __device__ __forceinline__ void st_n(int i, const Fe *v) const {             // N field elements -> ceil(9N/4) groups from group G0
+        uint32_t w[((9 * N + 3) / 4) * 4];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int l = 0; l < 9; ++l) w[9 * k + l] = v[k].l[l];
+#pragma unroll
+        for (int l = 9 * N; l < ((9 * N + 3) / 4) * 4; ++l) w[l] = 0;
+#pragma unroll
+        for (int g = 0; g < (9 * N + 3) / 4; ++g) base[row(i, G0 + g)] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+    }
+    template <int N, int G0>
+    __device__ __forceinline__ void ld_n(int i, Fe *v) const {
+        uint32_t w[((9 * N + 3) / 4) * 4];
+#pragma unroll
+        for (int g = 0; g < (9 * N + 3) / 4; ++g) {
+            const uint4 x = base[row(i, G0 + g)];
+            w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int l = 0; l < 9; ++l) v[k].l[l] = w[9 * k + l];
+    }
+    __device__ __forceinline__ void put_r(int i, const G2Proj<F2> &v) const { Fe t[3] = {v.x.v, v.y.v, v.z.v}; st_n<3, 0>(i, t); }
+    __device__ __forceinline__ G2Proj<F2> get_r(int i) const { Fe t[3]; ld_n<3, 0>(i, t); return {{t[0]}, {t[1]}, {t[2]}}; }
+    __device__ __forceinline__ void put_base(int i, const G2Aff<F2> &v) const { Fe t[2] = {v.x.v, v.y.v}; st_n<2, 7>(i, t); }
+    __device__ __forceinline__ G2Aff<F2> get_base(int i) const { Fe t[2]; ld_n<2, 7>(i, t); return {{t[0]}, {t[1]}}; }
+    __device__ __forceinline__ void put_p(int i, const G1Aff<Fe> &v) const { Fe t[2] = {v.x, v.y}; st_n<2, 12>(i, t); }
+    __device__ __forceinline__ G1Aff<Fe> get_p(int i) const { Fe t[2]; ld_n<2, 12>(i, t); return {t[0], t[1]}; }
+    __device__ __forceinline__ bool is_inf(int i) const { return (infmask >> i) & 1u; }
+};
+constexpr size_t MILLER_STATE_BYTES_PER_LANE_AND_PAIR = 17 * 16;
+
+// f_out[t] = prod_{i < M} miller(p[M t + i], q[M t + i])  (pairs beyond n count as infinity -> 1); the values only meet a final exponentiation
+template <int M>
+__device__ __forceinline__ void miller_shared_body(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n, uint4 *state) {
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lp = t >> 1, groups = (n + M - 1) / M;
+    const bool live = lp < groups;
+    MillerStateMem<M> st = {state, t, gridDim.x * BLOCK, 0u};
+#pragma unroll 1
+    for (int i = 0; i < M; ++i) {
+        uint32_t pair = (live ? lp : groups - 1) * M + (uint32_t)i;
+        const bool beyond = pair >= n;
+        if (beyond) pair = n - 1;                                   // keep both lanes active for the DPP exchanges
+        const uint32_t *w1 = g1 + 24u * pair, *w2 = g2 + 48u * pair;
+        if (beyond || words_all_zero(w1 + 16, 8) || words_all_zero(w2 + 32, 16)) st.infmask |= 1u << i;        // groups/mod.rs:766
+        G1Aff<Fe> p;
+        G2Aff<F2> q;
+        pair_prologue<Fe>(f2_scalar_load((const F2 *)nullptr, w1), f2_scalar_load((const F2 *)nullptr, w1 + 8), f2_scalar_load((const F2 *)nullptr, w1 + 16),
+                          f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32), p, q);
+        const Fe t2 = f2_scalar_const((const F2 *)nullptr, k::ISO_T2), t3 = f2_scalar_const((const F2 *)nullptr, k::ISO_T3);      // onto the isomorphic curve
+        p = {fe_mul(p.x, t2), fe_mul(p.y, t3)};
+        q = {f2_scale(q.x, t2), f2_scale(q.y, t3)};
+        st.put_p(i, p); st.put_base(i, q);
+        st.put_r(i, G2Proj<F2>{q.x, q.y, f2_one((const F2 *)nullptr)});
+    }
+    Fq12<F2> f = miller_loop_shared<M, F2, Fe>(st);
+    if (live) f12_store(f, f_out + 96u * lp);
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_shared2_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n, uint4 *state) {
+    BN_KERNEL_PROLOGUE();
+    miller_shared_body<2>(g1, g2, f_out, n, state);
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_shared4_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n, uint4 *state) {
+    BN_KERNEL_PROLOGUE();
+    miller_shared_body<4>(g1, g2, f_out, n, state);
+}
+
 // ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
 constexpr int NCOEFF = 102, COEFF_WORDS = 48;
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_g2_precompute_B(const uint32_t *g2, uint32_t *coeffs, uint32_t n) {
@@ -425,6 +506,17 @@ int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, voi
 int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(bn254_gt_inverse_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (uint32_t *)out, (uint32_t)n);
+    return (int)hipGetLastError();
+}
+// m pairs per lane pair on one accumulator (m = 2 or 4): ceil(n / m) values out; `state`: bn254_miller_shared_state_bytes_B(n, m)
+size_t bn254_miller_shared_state_bytes_B(size_t n, int m) {
+    const size_t groups = (n + m - 1) / m, grid = (2 * groups + BLOCK - 1) / BLOCK;
+    return grid * BLOCK * (size_t)m * MILLER_STATE_BYTES_PER_LANE_AND_PAIR;
+}
+int bn254_launch_miller_shared_B(const void *p, const void *q, void *f, size_t n, int m, void *state, hipStream_t s) {
+    const size_t groups = (n + m - 1) / m;
+    unsigned grid = (unsigned)((2 * groups + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(m == 4 ? bn254_miller_shared4_B : bn254_miller_shared2_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n, (uint4 *)state);
     return (int)hipGetLastError();
 }
 int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s) {

@@ -78,6 +78,7 @@ struct bn254_ctx {
     BnBuf ws;                           // workspace (Miller values, product-tree levels)
     BnBuf exp_tbl;                      // odd-power tables of the windowed exponentiation by u (final_exp_B)
     BnBuf pow_tbl;                      // window tables of Gt::pow (gt_pow_B)
+    BnBuf miller_state;                 // running points of the shared-accumulator Miller loop (miller_shared*_B), one round
     hipEvent_t scratch_ev = nullptr;    // completion of the last launch that used ws / exp_tbl ...
     hipStream_t scratch_stream = nullptr;   // ... and the stream it ran on
     bool scratch_used = false;
@@ -148,6 +149,8 @@ int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_
 extern "C" {
 // bn254_kernels_b.hip
 int bn254_launch_miller_B(const void *p, const void *q, void *f, size_t n, int naf, hipStream_t s);
+size_t bn254_miller_shared_state_bytes_B(size_t n, int m);
+int bn254_launch_miller_shared_B(const void *p, const void *q, void *f, size_t n, int m, void *state, hipStream_t s);
 int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hipStream_t s);
 size_t bn254_final_exp_table_bytes_B(size_t n);
 int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);

@@ -230,6 +230,55 @@ BN_FN Fq12<F2> miller_loop_naf_merged(const G1Aff<S> &p_in, const G2Aff<F2> &q_i
     }
     return f;
 }
+// The multi-pairing's Miller loop with a SHARED accumulator: prod_i f_i = the f of  f <- f^2 * prod_i l_i(P_i)  (a product of Miller
+// values only ever meets one final exponentiation: shootout/main.rs:11-16), so M pairs on one lane pair pay ONE f^2 per doubling
+// step - 12 of the 33 Fq2 products of a step and pair - instead of M.  The price: the running points, the points being added and the
+// affine P_i of all M pairs do not fit in LDS next to f; `st` keeps them in global memory (st.get_r(i) ...).  NAF schedule on the
+// isomorphic curve, as miller_loop_sched<true>.  `st.is_inf(i)`: pair i contributes 1 (groups/mod.rs:766) - its lines are replaced
+// by the constant 1, so f is untouched.  The prologue (st.put_* for every i) is the caller's.
+template <int M, class F2, class S, class Store>
+BN_FN Fq12<F2> miller_loop_shared(Store &st) {
+    Fq12<F2> f = f12_one<F2>();
+    constexpr int ND = k::ATE_NAF_LEN - 1;
+#pragma unroll 1
+    for (int j = 0; j < ND + 2; ++j) {
+        const bool tail = j >= ND;
+        const int digit = tail ? 1 : k::ATE_NAF[ND - 1 - j];
+        if (tail) {
+#pragma unroll 1
+            for (int i = 0; i < M; ++i) {                                            // pi(Q_i), then -pi^2(Q_i)   groups/mod.rs:578-579
+                G2Aff<F2> b = mul_by_q(st.get_base(i));
+                if (j == ND + 1) b.y = f2_neg(b.y);
+                st.put_base(i, b);
+            }
+        }
+#pragma unroll 1
+        for (int pass = tail ? 1 : 0; pass < (digit != 0 ? 2 : 1); ++pass) {
+            BN_MILLER_HOOK(2 * j + pass, 2 * (ND + 2));
+            if (pass == 0 && j != 0) f = f12_sqr(f);                                // ONE squaring for all M pairs
+#pragma unroll 1
+            for (int i = 0; i < M; ++i) {
+                BN_COMPILER_FENCE();
+                G2Proj<F2> r = st.get_r(i);
+                Line<F2> l;
+                if (pass == 0) {
+                    l = doubling_step<true>(r);
+                } else {
+                    G2Aff<F2> b = st.get_base(i);
+                    if (digit < 0) b.y = f2_neg(b.y);
+                    l = addition_step(r, b);
+                }
+                st.put_r(i, r);
+                const G1Aff<S> p = st.get_p(i);
+                F2 x0 = l.ell_0, x4 = f2_scale(l.ell_vw, p.y), x2 = f2_scale(l.ell_vv, p.x);
+                const bool inf = st.is_inf(i);                                      // an infinite pair multiplies by the line 1 + 0 + 0
+                x0 = f2_select(inf, x0, f2_one(F2P)); x4 = f2_select(inf, x4, f2_zero(F2P)); x2 = f2_select(inf, x2, f2_zero(F2P));
+                f = f12_mul_by_024(f, x0, x4, x2);
+            }
+        }
+    }
+    return f;
+}
 template <class F2, class S, class Store>
 BN_FN Fq12<F2> miller_loop(const G1Aff<S> &p, const G2Aff<F2> &q, Store &st) { return miller_loop_sched<false>(p, q, st); }
 template <class F2, class S>

@@ -311,3 +311,35 @@ EXPORT void hsw_pairing(int fe, const uint32_t *g1, const uint32_t *g2, uint32_t
         w_store_f12(w, OFF_RES, o);
     });
 }
+
+// the multi-pairing's Miller loop with a shared accumulator (pairing.hpp miller_loop_shared, bn254_miller_shared{2,4}_B):
+// FE(shared Miller value of m pairs) must equal the product of the m pairings; pairs with z = 0 contribute 1
+template <int M>
+struct MillerStateVarsM {
+    G2Proj<F2B> r[M]; G2Aff<F2B> b[M]; G1Aff<FeP> p[M]; bool inf[M];
+    void put_r(int i, const G2Proj<F2B> &v) { r[i] = v; }
+    G2Proj<F2B> get_r(int i) const { return r[i]; }
+    void put_base(int i, const G2Aff<F2B> &v) { b[i] = v; }
+    G2Aff<F2B> get_base(int i) const { return b[i]; }
+    G1Aff<FeP> get_p(int i) const { return p[i]; }
+    bool is_inf(int i) const { return inf[i]; }
+};
+template <int M>
+static void hsb_shared(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
+    MillerStateVarsM<M> st;
+    for (int i = 0; i < M; ++i) {
+        const uint32_t *w1 = g1 + 24 * i, *w2 = g2 + 48 * i;
+        st.inf[i] = words_all_zero(w1 + 16, 8) || words_all_zero(w2 + 32, 16);
+        G1Aff<FeP> p; G2Aff<F2B> q;
+        pair_prologue<FeP>(f2_scalar_load((F2B *)0, w1), f2_scalar_load((F2B *)0, w1 + 8), f2_scalar_load((F2B *)0, w1 + 16),
+                           f2_load((F2B *)0, w2), f2_load((F2B *)0, w2 + 16), f2_load((F2B *)0, w2 + 32), p, q);
+        const FeP t2 = f2_scalar_const((F2B *)0, k::ISO_T2), t3 = f2_scalar_const((F2B *)0, k::ISO_T3);
+        p = {fe_mul(p.x, t2), fe_mul(p.y, t3)};
+        q = {f2_scale(q.x, t2), f2_scale(q.y, t3)};
+        st.p[i] = p; st.b[i] = q; st.r[i] = G2Proj<F2B>{q.x, q.y, f2_one((F2B *)0)};
+    }
+    f12_store(final_exponentiation(miller_loop_shared<M, F2B, FeP>(st)), o);
+}
+EXPORT void hsb_pairing_product_shared(int m, const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
+    if (m == 2) hsb_shared<2>(g1, g2, o); else hsb_shared<4>(g1, g2, o);
+}

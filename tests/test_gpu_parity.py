@@ -870,3 +870,33 @@ def test_gt_pow_mixed_subgroup_membership(oracle, eng):
     pw = eng.gt_pow_batch(g, s)
     for i in list(range(0, n, 7)) + [16, 17, 18, 149, 150, 151]:
         assert np.array_equal(pw[i], oracle.gt_pow(g[i], s[i])), i
+
+
+@pytest.mark.parametrize("m", [2, 4])
+def test_shared_accumulator_miller_kernels(oracle, m):
+    """bn254_miller_shared{2,4}_B (m pairs per lane pair on one accumulator; chosen by the host from two / four machine rounds of pairs
+    on, forced here by BN254_MILLER_SHARED): ragged sizes (not a multiple of m), infinite pairs, and 5000 pairs against the oracle's
+    fold; equal to the plain path bit for bit"""
+    import os
+    import bn_amd
+    rng = np.random.default_rng(207 + m)
+    n = 5003
+    te_p, te_q = _points(oracle, rng, 64)
+    reps = (n + 63) // 64
+    P = np.tile(te_p, (reps, 1))[:n].copy(); Q = np.tile(te_q, (reps, 1))[:n].copy()       # 64 distinct pairs, repeated
+    P[7] = oracle.g1_zero(); Q[4000] = oracle.g2_zero(); P[n - 1] = oracle.g1_zero()
+    e = bn_amd.Engine(0)
+    os.environ["BN254_MILLER_SHARED"] = "1"
+    try:
+        plain = e.pairing_product(P, Q)
+        os.environ["BN254_MILLER_SHARED"] = str(m)
+        e.profile(True); e.profile_reset()
+        shared = e.pairing_product(P, Q)
+        assert e.kernel_stats("miller_shared")[1] >= 1 and e.kernel_stats("miller")[1] == 0
+        e.profile(False)
+        small = e.pairing_product(P[:2 * m + 1], Q[:2 * m + 1]) if False else None
+    finally:
+        os.environ.pop("BN254_MILLER_SHARED", None)
+    assert np.array_equal(plain, shared)
+    assert np.array_equal(shared, oracle.pairing_product(P, Q))
+    e.close()

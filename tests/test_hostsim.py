@@ -391,3 +391,15 @@ def test_g2_gls_scalar_mul(oracle, hs):
             want = canon_infinity(oracle.g2_normalize(oracle.g2_mul(base, k)))
             assert np.array_equal(hs.call("hs_g2_mul_gls", base, k, out_words=48), want), kv
             assert np.array_equal(hs.call("hsb_g2_mul_gls", base, k, out_words=48), want), kv
+
+
+def test_shared_accumulator_miller_loop(oracle, hs):
+    """the multi-pairing's Miller loop with ONE accumulator for m pairs (pairing.hpp miller_loop_shared: one f^2 per doubling step for
+    all of them), bounds enforced: FE(shared value) == the oracle's fold of shootout/main.rs:11-16, also with an infinite pair"""
+    rng = np.random.default_rng(63)
+    for m in (2, 4):
+        P = np.stack([oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)) for _ in range(m)])
+        Q = np.stack([oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng)) for _ in range(m)])
+        assert np.array_equal(hs.call("hsb_pairing_product_shared", m, P, Q, out_words=96), oracle.pairing_product(P, Q))
+        P[m - 1] = oracle.g1_zero(); Q[0] = oracle.g2_zero()
+        assert np.array_equal(hs.call("hsb_pairing_product_shared", m, P, Q, out_words=96), oracle.pairing_product(P, Q))
