@@ -63,6 +63,11 @@
 #define BN_EXP_HOOK(step, total) ((void)0)
 #endif
 #include "bn254_constants.hpp"
+// GPU builds run the multiplier leaves and the 64-bit chains of the fused reductions as inline-asm instruction chains (same
+// arithmetic; -DBN_NO_ASM_LEAF / -DBN_NO_ASM_REDUCE restore the C++ bodies, which the host simulation always uses)
+#if !defined(BN_HOSTSIM) && !defined(BN_NO_ASM_LEAF)
+#define BN_ASM_LEAF 1
+#endif
 
 #if defined(BN_BOUNDS)
 #include <cstdio>
@@ -372,6 +377,48 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
     const int64_t kq = (te * (int64_t)k::FE_MU24) >> 45;     // floor; kq <= floor(value/q), kq >= value/q - 2
     Fe r;
     int64_t carry = 0;
+#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM) && !defined(BN_NO_ASM_REDUCE)
+    // GPU: the 64-bit chain of a limb as ONE asm statement of v_mad_i64_i32 (carry - kq q_i + narrow sum + the wide terms), like the
+    // multiplier leaves (fe_asm.hpp): the compiler otherwise builds it from sign extensions, 64-bit adds and - in some contexts -
+    // v_mul_lo / v_mul_hi pairs.  Same arithmetic, limb for limb.
+    const int32_t nkq = (int32_t)(0 - kq);
+    constexpr int NWIDE = (C1 != 0 && !N1) + (C2 != 0 && !N2) + (C3 != 0 && !N3) + (C4 != 0 && !N4);
+    constexpr bool ANY_NARROW = N1 || N2 || N3 || N4;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int32_t nsum = 0;
+        if (N1) nsum += C1 * (int32_t)x.l[i];
+        if (N2) { int32_t yy = C2 * (int32_t)y.l[i]; nsum += neg2 ? -yy : yy; }
+        if (N3) nsum += C3 * (int32_t)z.l[i];
+        if (N4) nsum += C4 * (int32_t)w.l[i];
+        // the wide terms in order; a term that is absent multiplies by the inline constant 0 (never emitted: see the switch on NWIDE)
+        int32_t wc[4], wv[4];
+        int nw = 0;
+        if (C1 != 0 && !N1) { wc[nw] = C1; wv[nw] = (int32_t)x.l[i]; ++nw; }
+        if (C2 != 0 && !N2) { wc[nw] = c2; wv[nw] = (int32_t)y.l[i]; ++nw; }
+        if (C3 != 0 && !N3) { wc[nw] = C3; wv[nw] = (int32_t)z.l[i]; ++nw; }
+        if (C4 != 0 && !N4) { wc[nw] = C4; wv[nw] = (int32_t)w.l[i]; ++nw; }
+        int64_t t = carry;
+        const uint32_t qi = k::Q[i];
+        if constexpr (NWIDE == 0) {
+            if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(nsum) : "vcc");
+            else asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(t) : "v"(nkq), "s"(qi) : "vcc");
+        } else if constexpr (NWIDE == 1) {
+            if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(nsum), "v"(wc[0]), "v"(wv[0]) : "vcc");
+            else asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(wc[0]), "v"(wv[0]) : "vcc");
+        } else if constexpr (NWIDE == 2) {
+            if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0\n\tv_mad_i64_i32 %0, vcc, %6, %7, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(nsum), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]) : "vcc");
+            else asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]) : "vcc");
+        } else if constexpr (NWIDE == 3) {
+            if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0\n\tv_mad_i64_i32 %0, vcc, %6, %7, %0\n\tv_mad_i64_i32 %0, vcc, %8, %9, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(nsum), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]) : "vcc");
+            else asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]) : "vcc");
+        } else {
+            asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]), "v"(wc[3]), "v"(wv[3]) : "vcc");
+            if constexpr (ANY_NARROW) t += (int64_t)nsum;
+        }
+        if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         int32_t nsum = 0;
@@ -386,6 +433,7 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
         if (C4 != 0 && !N4) t += (int64_t)C4 * (int64_t)(int32_t)w.l[i];
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
+#endif
     // floor() loses < 1 and the margins of `te` ~3e-4, so kq > value/q - 1.001 and the result is < 1.001 q
     BN_SETB(r, 1, 2);
     BN_VERIFY(r, "fe_lc4_core");
@@ -435,8 +483,7 @@ BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any l
 // statement (fe_asm.hpp, tools/gen_asm_leaf.py): the compiler otherwise splits each column sum into two chains and joins them with
 // a 64-bit add (16 v_lshl_add_u64 per product); +3.6 % pairings/s (profiles/r03_ab_asm_leaf.txt).  The host simulation - and
 // -DBN_NO_ASM_LEAF - use the C++ bodies, which also carry the bound checks.
-#if !defined(BN_HOSTSIM) && !defined(BN_NO_ASM_LEAF)
-#define BN_ASM_LEAF 1
+#if defined(BN_ASM_LEAF)
 }  // namespace bn254
 #include "fe_asm.hpp"
 namespace bn254 {

@@ -129,6 +129,8 @@ BN_FN void w_run(W &w, const uint32_t *prog) {
         else if (op == OP_PROD_SQR) w_prod<2, 0, true, false, false>(w, r, base);
         else if (op == OP_COMB_C) w_comb<true, false>(w, r, base);
         else if (op == OP_PROD_MUL) w_prod<4, 4, false, false, false>(w, r, base);
+        else if (op == OP_PROD_MUL1) w_prod<1, 1, false, false, false>(w, r, base);
+        else if (op == OP_PROD_MUL2) w_prod<2, 2, false, false, false>(w, r, base);
         else if (op == OP_PROD_MULR) w_prod<4, 4, false, false, true>(w, r, base);
         else if (op == OP_COMB_M) w_comb<false, false>(w, r, base);
         else if (op == OP_COMB_MR) w_comb<false, true>(w, r, base);

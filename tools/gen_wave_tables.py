@@ -167,7 +167,9 @@ def rel(k): return ('rel', k)    # k-th register after the entry's base
 # PROD_MULR / COMB_MR are PROD_MUL / COMB_M whose tables contain REL indices (products by a table slot, slot copies): only they pay
 # for the decode of the flag
 # FUSE_SQR: the recombination of one cyclotomic squaring and the products of the NEXT one in a single phase (runs of squarings)
-OPS = {"PROD_MUL": 0, "PROD_MULC": 1, "PROD_SQR": 2, "COMB_M": 3, "COMB_C": 4, "INV": 5, "COMB_M2": 6, "PROD_MULR": 7, "COMB_MR": 8, "FUSE_SQR": 9, "END": 15}
+# PROD_MUL1 / PROD_MUL2: PROD_MUL whose roles gather at most one / two registers per operand (the generic kind always gathers 4 + 4)
+OPS = {"PROD_MUL": 0, "PROD_MULC": 1, "PROD_SQR": 2, "COMB_M": 3, "COMB_C": 4, "INV": 5, "COMB_M2": 6, "PROD_MULR": 7, "COMB_MR": 8, "FUSE_SQR": 9,
+       "PROD_MUL1": 10, "PROD_MUL2": 11, "END": 15}
 
 class Phase:
     def __init__(self, kind, name):
@@ -464,6 +466,9 @@ class Builder:
             kind = {"PROD_MUL": "PROD_MULR", "COMB_M": "COMB_MR"}[kind]
         else:
             base = 0                                             # no relative index in this table: the base is never read
+            if kind == "PROD_MUL":
+                terms = max(max(len(r["a"]), len(r.get("b", []))) for r in ph.roles)
+                kind = "PROD_MUL1" if terms <= 1 else "PROD_MUL2" if terms <= 2 else "PROD_MUL"
         return (OPS[kind], self.pid(ph), off(base))
 
 def build():
