@@ -476,7 +476,7 @@ int bn254_pairing_batch_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, vo
 }
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;
-    if (!d_out || (n && !d_in) || n > 0xffffffffu) return BN254_E_BAD_ARG;
+    if (!d_out || (n && !d_in) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;      // one launch: 32-bit word offsets in the kernel
     BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
@@ -511,7 +511,7 @@ static int miller_shared_m(const bn254_ctx *c, size_t n) {
 }
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream) {
     int rc = bn_get_ctx(ctx); if (rc) return rc;
-    if (!d_partial || (n && (!d_p || !d_q)) || n > 0xffffffffu) return BN254_E_BAD_ARG;
+    if (!d_partial || (n && (!d_p || !d_q)) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;      // (the Miller values of all n meet ONE product launch)
     if (n == 0) return bn254_gt_product_dev(ctx, nullptr, 0, d_partial, stream);
     BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));
