@@ -65,7 +65,7 @@
 #define BN_EXP_HOOK(step, total) bn_fair_priority_time()
 #endif
 #ifndef BN_B_FAIR_SHIFT
-#define BN_B_FAIR_SHIFT 21
+#define BN_B_FAIR_SHIFT 20          // 2^20 cycles: re-measured after the asm leaves (profiles/r03_ab_fair_policy.txt; 21 before)
 #endif
 #include <hip/hip_runtime.h>
 #include <cstdlib>
