@@ -12,7 +12,7 @@
 #define BN_LEAF_MUL __device__ __forceinline__
 #define BN_LEAF_RED __device__ __forceinline__
 #ifndef BN_MUL_WAVES
-#define BN_MUL_WAVES 2        // resident waves per SIMD the G1 kernel is compiled for
+#define BN_MUL_WAVES 3        // resident waves per SIMD the G1 kernels are compiled for (167 VGPRs, no spills; 2: -1 %, 4: spills)
 #endif
 #include <hip/hip_runtime.h>
 #include <type_traits>
