@@ -373,15 +373,20 @@ int bn_launch_pairing(bn254_ctx *c, const void *p, const void *q, void *out, siz
     return bn_launch_final_exp(c, out, out, n, s, table);
 }
 
-int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize) {
+// The normalising kernels keep every lane's window table (640 B) in a buffer: sub-launches of 2^18 lanes (168 MB) reuse one.
+constexpr size_t BN_MUL_LANES_PER_LAUNCH = (size_t)1 << 18;
+int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize, BnBuf *table) {
     const size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
     const bool mapping_b = ctx->mapping.load() == 1;
-    return bn_for_parts(n, BN_LAUNCH_MAX, [&](size_t lo, size_t cnt) -> int {
+    const size_t step = (mapping_b && normalize) ? BN_MUL_LANES_PER_LAUNCH / (g == 1 ? 1 : 2) : BN_LAUNCH_MAX;
+    BnBuf *t = table ? table : &ctx->mul_tbl;
+    if (mapping_b && normalize) { int rc = t->reserve(bn254_mul_table_bytes_M(g, n < step ? n : step)); if (rc) return rc; }
+    return bn_for_parts(n, step, [&](size_t lo, size_t cnt) -> int {
         const void *p = (const char *)d_p + lo * ps, *k = (const char *)d_k + lo * sizeof(bn_fr);
         void *o = (char *)d_out + lo * ps;
         BnScope sc(ctx, s, g == 1 ? "g1_mul" : "g2_mul");
         if (mapping_b)          // registers-resident chains; G2 in the lane-pair mapping (bn254_kernels_mul.hip)
-            return g == 1 ? bn254_launch_g1_mul_M(p, k, o, cnt, normalize, s) : bn254_launch_g2_mul_M(p, k, o, cnt, normalize, s);
+            return g == 1 ? bn254_launch_g1_mul_M(p, k, o, cnt, normalize, t->p, s) : bn254_launch_g2_mul_M(p, k, o, cnt, normalize, t->p, s);
         if (g == 1)
             hipLaunchKernelGGL(bn254_g1_mul_k, dim3(grid_for(cnt)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)o, (uint32_t)cnt, normalize);
         else
@@ -422,7 +427,7 @@ void bn254_ctx_destroy(bn254_ctx *c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (auto &r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-    c->ws.release(); c->exp_tbl.release(); c->pow_tbl.release(); c->miller_state.release();
+    c->ws.release(); c->exp_tbl.release(); c->pow_tbl.release(); c->miller_state.release(); c->mul_tbl.release();
     for (auto &b : c->stage) b.release();
     for (auto &s : c->slot) {
         for (auto &b : s.d_in) b.release();
@@ -540,6 +545,7 @@ int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, s
 }
 static int mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, void *stream, int normalize) {
     BN_DEV_PROLOGUE(!d_p || !d_k || !d_out, BN_N_MAX);
+    BnScratchGuard gd(ctx, s); if (gd.rc) return gd.rc;          // the window tables are context-owned scratch
     return bn_mul_dev(ctx, g, d_p, d_k, d_out, n, s, normalize);
 }
 int bn254_g1_mul_batch_dev(bn254_ctx *c, const void *p, const void *k, void *o, size_t n, void *s) { return mul_dev(c, 1, p, k, o, n, s, 1); }

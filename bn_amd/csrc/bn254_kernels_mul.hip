@@ -25,41 +25,79 @@ namespace {
 constexpr int BLOCK = 64;
 typedef Fq2B<Fe> F2;
 
+// The affine window table of a lane in global memory: [lane][entry 1..8][18 dwords padded to 80 bytes] - a lane reads the entry of
+// ITS digit as five 16-byte loads from one or two cache lines (curve.hpp AffTableVars explains why not a private array).
+constexpr uint32_t AFF_ENTRY_U4 = 5, AFF_LANE_U4 = 8 * AFF_ENTRY_U4;                 // 80 B per entry, 640 B per lane
+template <class F>
+struct AffTableMem {
+    uint4 *base;             // this lane's 8 entries
+    __device__ __forceinline__ static void split(const Fe &a, const Fe &b, uint32_t *w) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { w[i] = a.l[i]; w[9 + i] = b.l[i]; }
+        w[18] = 0; w[19] = 0;
+    }
+    __device__ __forceinline__ void put_fe(int i, const Fe &x, const Fe &y) const {
+        uint32_t w[20];
+        split(x, y, w);
+        uint4 *e = base + (uint32_t)(i - 1) * AFF_ENTRY_U4;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) e[g] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+    }
+    __device__ __forceinline__ void get_fe(int i, Fe &x, Fe &y) const {
+        const uint4 *e = base + (uint32_t)(i - 1) * AFF_ENTRY_U4;
+        uint32_t w[20];
+#pragma unroll
+        for (int g = 0; g < 5; ++g) { const uint4 v = e[g]; w[4 * g] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w; }
+#pragma unroll
+        for (int i2 = 0; i2 < 9; ++i2) { x.l[i2] = w[i2]; y.l[i2] = w[9 + i2]; }
+    }
+    // G1: (x, y) are Fe; G2 in the lane-pair mapping: this lane's components of (x, y)
+    __device__ __forceinline__ void put(int i, const Aff<FqField> &v) const { put_fe(i, v.x, v.y); }
+    __device__ __forceinline__ void put(int i, const Aff<Fq2Field<Fq2B<Fe>>> &v) const { put_fe(i, v.x.v, v.y.v); }
+    __device__ __forceinline__ Aff<F> get(int i) const {
+        Aff<F> r;
+        if constexpr (std::is_same<F, FqField>::value) get_fe(i, r.x, r.y);
+        else get_fe(i, r.x.v, r.y.v);
+        return r;
+    }
+};
+
 // NORMALIZE is a template parameter, i.e. each flavour is its OWN kernel: with a run-time flag the reference chain and the GLV /
 // windowed chain were register-allocated together (round 2: 74 spilled VGPRs in the G1 kernel).
 template <class F, bool NORMALIZE>
-__device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km) {
+__device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km, uint4 *table, uint32_t lane) {
     uint32_t kw[8], raw[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) kw[i] = km[i];
     fr_from_mont(kw, raw);
     if constexpr (NORMALIZE) {
-        if constexpr (std::is_same<F, FqField>::value) return jac_normalize<F>(scalar_mul_glv(p, raw));      // G1: GLV + signed windows
-        else return jac_normalize<F>(scalar_mul_gls<F2>(p, raw));                                             // G2: GLS, four signed-window streams
+        AffTableMem<F> tab = {table + (size_t)lane * AFF_LANE_U4};
+        if constexpr (std::is_same<F, FqField>::value) return jac_normalize<F>(scalar_mul_glv(p, raw, tab));      // G1: GLV + signed windows
+        else return jac_normalize<F>(scalar_mul_gls<F2>(p, raw, tab));                                             // G2: GLS, four signed-window streams
     } else {
         return scalar_mul_reference_chain<F>(p, raw);
     }
 }
 
 template <bool NORMALIZE>
-__device__ __forceinline__ void g1_mul_body(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
+__device__ __forceinline__ void g1_mul_body(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, uint4 *table) {
     uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= n) return;
     const uint32_t *w = p + 24u * idx;
     Jac<FqField> pt = {fe_from_u32x8(w), fe_from_u32x8(w + 8), fe_from_u32x8(w + 16)};
-    Jac<FqField> r = run_chain<FqField, NORMALIZE>(pt, k + 8u * idx);
+    Jac<FqField> r = run_chain<FqField, NORMALIZE>(pt, k + 8u * idx, table, idx);
     uint32_t *o = out + 24u * idx;
     fe_to_u32x8(r.x, o); fe_to_u32x8(r.y, o + 8); fe_to_u32x8(r.z, o + 16);
 }
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_MUL_WAVES, BN_MUL_WAVES))) bn254_g1_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
-    g1_mul_body<true>(p, k, out, n);
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_MUL_WAVES, BN_MUL_WAVES))) bn254_g1_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, uint4 *table) {
+    g1_mul_body<true>(p, k, out, n, table);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_MUL_WAVES, BN_MUL_WAVES))) bn254_g1_mul_chain_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
-    g1_mul_body<false>(p, k, out, n);
+    g1_mul_body<false>(p, k, out, n, nullptr);
 }
 
 template <bool NORMALIZE>
-__device__ __forceinline__ void g2_mul_body(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
+__device__ __forceinline__ void g2_mul_body(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, uint4 *table) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -67,17 +105,17 @@ __device__ __forceinline__ void g2_mul_body(const uint32_t *p, const uint32_t *k
     const uint32_t *w = p + 48u * pair;
     typedef Fq2Field<F2> F;
     Jac<F> pt = {f2_load((const F2 *)nullptr, w), f2_load((const F2 *)nullptr, w + 16), f2_load((const F2 *)nullptr, w + 32)};
-    Jac<F> r = run_chain<F, NORMALIZE>(pt, k + 8u * pair);
+    Jac<F> r = run_chain<F, NORMALIZE>(pt, k + 8u * pair, table, t);
     if (live) {
         uint32_t *o = out + 48u * pair;
         f2_store(r.x, o); f2_store(r.y, o + 16); f2_store(r.z, o + 32);
     }
 }
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
-    g2_mul_body<true>(p, k, out, n);
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_mul_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, uint4 *table) {
+    g2_mul_body<true>(p, k, out, n, table);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) bn254_g2_mul_chain_M(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n) {
-    g2_mul_body<false>(p, k, out, n);
+    g2_mul_body<false>(p, k, out, n, nullptr);
 }
 // a[i] + b[i]  (or a[i] - b[i] = a[i] + (-b[i]): lib.rs:103-114,146-157, groups/mod.rs:275-347): the reference's add-2007-bl
 // with its zero / equal-point branches, so the Jacobian limbs returned are the reference's own
@@ -125,14 +163,21 @@ int bn254_launch_g2_add_M(const void *a, const void *b, void *out, size_t n, int
     hipLaunchKernelGGL(bn254_g2_add_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)b, (uint32_t *)out, (uint32_t)n, negate_b);
     return (int)hipGetLastError();
 }
-int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s) {
+// `table` (normalize != 0 only): bn254_mul_table_bytes_M(g, n) bytes of scratch for the window tables of this launch
+size_t bn254_mul_table_bytes_M(int g, size_t n) {
+    const size_t lanes = g == 1 ? (n + BLOCK - 1) / BLOCK * BLOCK : (2 * n + BLOCK - 1) / BLOCK * BLOCK;
+    return lanes * AFF_LANE_U4 * sizeof(uint4);
+}
+int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, void *table, hipStream_t s) {
     unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(normalize ? bn254_g1_mul_M : bn254_g1_mul_chain_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
+    if (normalize) hipLaunchKernelGGL(bn254_g1_mul_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, (uint4 *)table);
+    else hipLaunchKernelGGL(bn254_g1_mul_chain_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
-int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s) {
+int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, void *table, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(normalize ? bn254_g2_mul_M : bn254_g2_mul_chain_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
+    if (normalize) hipLaunchKernelGGL(bn254_g2_mul_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, (uint4 *)table);
+    else hipLaunchKernelGGL(bn254_g2_mul_chain_M, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n);
     return (int)hipGetLastError();
 }
 }

@@ -135,7 +135,7 @@ int bn_mul_batch_pipelined(bn254_ctx *ctx, int g, const void *p, const bn_fr *k,
     j.in[0] = (const char *)p; j.in_stride[0] = ps;
     j.in[1] = (const char *)k; j.in_stride[1] = sizeof(bn_fr);
     j.out = (char *)out; j.out_stride = ps;
-    j.launch = [ctx, g](BnSlot &s, size_t cnt) { return bn_mul_dev(ctx, g, s.d_in[0].p, s.d_in[1].p, s.d_out.p, cnt, s.stream, 1); };
+    j.launch = [ctx, g](BnSlot &s, size_t cnt) { return bn_mul_dev(ctx, g, s.d_in[0].p, s.d_in[1].p, s.d_out.p, cnt, s.stream, 1, &s.tbl); };
     return run_map(j);
 }
 

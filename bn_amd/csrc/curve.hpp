@@ -132,8 +132,19 @@ BN_COARSE Jac<F> jac_madd_flags(const Jac<F> &p, const Aff<F> &q, bool pz, bool 
 // tab[1..N] in, aff[1..N] out; returns Zc.  An infinite input point gives Zc = 0 and the chain's result z = 0: infinity again.
 // CONJ_EXTRA (G2 only): every entry is rescaled by conj(Zc) as well, so that the common z becomes Zc conj(Zc) = norm(Zc), an element
 // of Fq - the isomorphism (x, y) -> (x s^2, y s^3) commutes with the Frobenius-twist endomorphism psi exactly when s is in Fq.
-template <class F, int N, bool CONJ_EXTRA = false>
-BN_FN typename F::T table_to_common_z(const Jac<F> *tab, Aff<F> *aff) {
+// Where the affine window table lives.  Default: a per-lane array (host simulation, one-lane mapping).  The kernels keep it in a
+// buffer laid out [lane][entry][18 dwords padded to 80 bytes] (bn254_kernels_mul.hip AffTableMem): the entry a lane reads depends
+// on ITS digit, and private (scratch) memory is interleaved across lanes dword by dword - a lane-indexed private array makes every
+// dword load of a wave touch up to 64 different 256-byte rows (measured: 32-51 GB of traffic per 2^20 G1 multiplications, 11 % of
+// the kernel's time, profiles/r03m_pmc_side.txt); 80 contiguous bytes per lane cost two cache lines.
+template <class F>
+struct AffTableVars {
+    Aff<F> e[9];
+    BN_FN void put(int i, const Aff<F> &v) { e[i] = v; }
+    BN_FN Aff<F> get(int i) const { return e[i]; }
+};
+template <class F, int N, bool CONJ_EXTRA = false, class Tab>
+BN_FN typename F::T table_to_common_z(const Jac<F> *tab, Tab &aff) {
     using T = typename F::T;
     T pre[N + 1];                                             // pre[i] = Z_1 ... Z_i
     pre[1] = tab[1].z;
@@ -145,8 +156,7 @@ BN_FN typename F::T table_to_common_z(const Jac<F> *tab, Aff<F> *aff) {
     for (int i = N; i >= 1; --i) {
         T s = i > 1 ? F::mul(pre[i - 1], suf) : suf;
         T s2 = F::sqr(s);
-        aff[i].x = F::mul(tab[i].x, s2);
-        aff[i].y = F::mul(tab[i].y, F::mul(s2, s));
+        aff.put(i, Aff<F>{F::mul(tab[i].x, s2), F::mul(tab[i].y, F::mul(s2, s))});
         if (i > 1) suf = F::mul(suf, tab[i].z);
     }
     return pre[N];
@@ -237,8 +247,8 @@ BN_FN Jac<F> scalar_mul_windowed(const Jac<F> &p, const uint32_t *k_raw) {
 // 4-bit SIGNED (Booth) windows over the affine table 1P .. 8P on the isomorphic curve (table_to_common_z): 252 doublings + 64 mixed
 // additions + a table of 4 doublings, 3 additions and 52 products - against scalar_mul_windowed's 64 full additions and 14-operation
 // table of 16 Jacobian entries.  A table entry is 2 field elements and there are 8 of them: a third of the private memory.
-template <class F>
-BN_FN Jac<F> scalar_mul_booth_affine(const Jac<F> &p, const uint32_t *k_raw) {
+template <class F, class Tab>
+BN_FN Jac<F> scalar_mul_booth_affine(const Jac<F> &p, const uint32_t *k_raw, Tab &aff) {
     const bool p_inf = F::is_zero(p.z);
     Jac<F> tab[9];
     tab[1] = p;
@@ -249,9 +259,7 @@ BN_FN Jac<F> scalar_mul_booth_affine(const Jac<F> &p, const uint32_t *k_raw) {
     tab[6] = jac_double(tab[3]);
     tab[5] = jac_add_flags(tab[4], p, p_inf, p_inf);
     tab[7] = jac_add_flags(tab[6], p, p_inf, p_inf);
-    Aff<F> aff[9];
     const typename F::T zc = table_to_common_z<F, 8>(tab, aff);
-    aff[0] = {F::zero(), F::one()};
     Jac<F> res = {F::zero(), F::one(), F::zero()};
     bool res_inf = true;
 #pragma unroll 1
@@ -262,7 +270,7 @@ BN_FN Jac<F> scalar_mul_booth_affine(const Jac<F> &p, const uint32_t *k_raw) {
         }
         const int d = booth_digit_256(k_raw, w);               // k < r < 2^254: the top window needs no carry
         const int ad = d < 0 ? -d : d;
-        Aff<F> q = aff[ad];
+        Aff<F> q = aff.get(ad ? ad : 1);                        // digit 0: the operand is ignored (q_inf)
         q.y = F::select(d < 0, q.y, F::template lc3<-1, 0, 0>(q.y, q.y, q.y));
         const bool q_inf = p_inf || ad == 0;
         res = jac_madd_flags(res, q, res_inf, q_inf);
@@ -346,7 +354,8 @@ BN_FN int booth_digit(const uint32_t *mag, int i) {
 }
 constexpr int GLV_WINDOWS = 33;          // 4 * 33 = 132 bits >= 129 + the Booth sign bit
 
-BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) {
+template <class Tab>
+BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw, Tab &aff) {
     using F = FqField;
     const GlvSplit g = glv_decompose(k_raw);
     const bool p_inf = F::is_zero(p.z);
@@ -359,10 +368,7 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) 
     tab[6] = jac_double(tab[3]);
     tab[5] = jac_add_flags(tab[4], p, p_inf, p_inf);
     tab[7] = jac_add_flags(tab[6], p, p_inf, p_inf);
-    tab[0] = {F::zero(), F::one(), F::zero()};
-    Aff<F> aff[9];                                            // the table on the isomorphic curve where it is affine (table_to_common_z)
-    const Fe zc = table_to_common_z<F, 8>(tab, aff);
-    aff[0] = {F::zero(), F::one()};
+    const Fe zc = table_to_common_z<F, 8>(tab, aff);          // the table on the isomorphic curve where it is affine
     const Fe beta = fe_const(k::GLV_BETA);
     Jac<F> res = {F::zero(), F::one(), F::zero()};
     bool res_inf = true;
@@ -377,7 +383,7 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) 
             const int d = booth_digit(half ? g.m2 : g.m1, w);
             const int ad = d < 0 ? -d : d;
             const bool negate = (d < 0) != (half ? g.neg2 : g.neg1);
-            Aff<F> q = aff[ad];
+            Aff<F> q = aff.get(ad ? ad : 1);                      // digit 0: the operand is ignored (q_inf)
             if (half) q.x = fe_mul(q.x, beta);                    // phi(j P): the endomorphism commutes with the isomorphism
             q.y = F::select(negate, q.y, F::template lc3<-1, 0, 0>(q.y, q.y, q.y));
             const bool q_inf = p_inf || ad == 0;
@@ -437,8 +443,8 @@ BN_FN GlsSplit gls_decompose(const uint32_t *k_raw) {
 }
 constexpr int GLS_WINDOWS = 18;          // 4 * 18 = 72 bits >= 67 + the Booth sign bit
 
-template <class F2>
-BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_t *k_raw) {
+template <class F2, class Tab>
+BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_t *k_raw, Tab &aff) {
     using F = Fq2Field<F2>;
     const GlsSplit g = gls_decompose(k_raw);
     const bool p_inf = F::is_zero(p.z);
@@ -451,10 +457,8 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
     tab[6] = jac_double(tab[3]);
     tab[5] = jac_add_flags(tab[4], p, p_inf, p_inf);
     tab[7] = jac_add_flags(tab[6], p, p_inf, p_inf);
-    Aff<F> aff[9];
     const F2 zc = table_to_common_z<F, 8, true>(tab, aff);       // entries affine for the common z = norm(zc), an element of Fq
     const F2 zn = f2_mul(zc, f2_conj(zc));
-    aff[0] = {F::zero(), F::one()};
     Jac<F> res = {F::zero(), F::one(), F::zero()};
     bool res_inf = true;
 #pragma unroll 1
@@ -468,7 +472,7 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
             const int d = booth_digit<3>(g.m[j], w);
             const int ad = d < 0 ? -d : d;
             const bool negate = ((d < 0) != g.neg[j]) != (j >= 2);            // psi^2, psi^3 carry a minus sign on y
-            Aff<F> q = aff[ad];
+            Aff<F> q = aff.get(ad ? ad : 1);                       // digit 0: the operand is ignored (q_inf)
             if (j == 1) {
                 q.x = f2_mul_const(f2_conj_lazy(q.x), k::TWIST_MUL_BY_Q_X); q.y = f2_mul_const(f2_conj_lazy(q.y), k::TWIST_MUL_BY_Q_Y);
             } else if (j == 2) {
@@ -485,6 +489,11 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
     res.z = F::mul(res.z, zn);                                     // back from the isomorphic curve
     return res;
 }
+
+// the same chains with the table in a local array (host simulation)
+BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) { AffTableVars<FqField> t; return scalar_mul_glv(p, k_raw, t); }
+template <class F2> BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_t *k_raw) { AffTableVars<Fq2Field<F2>> t; return scalar_mul_gls<F2>(p, k_raw, t); }
+template <class F> BN_FN Jac<F> scalar_mul_booth_affine(const Jac<F> &p, const uint32_t *k_raw) { AffTableVars<F> t; return scalar_mul_booth_affine<F>(p, k_raw, t); }
 
 // lib.rs:88-95 (normalize): (x/z^2, y/z^3, 1).  Infinity is returned as G::zero() = (0, 1, 0) (groups/mod.rs:208-214): that is
 // what the reference holds for every valid input that multiplies to zero (k = 0 or p = 0; k < r excludes the rest), while

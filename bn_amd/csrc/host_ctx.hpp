@@ -78,6 +78,7 @@ struct bn254_ctx {
     BnBuf ws;                           // workspace (Miller values, product-tree levels)
     BnBuf exp_tbl;                      // odd-power tables of the windowed exponentiation by u (final_exp_B)
     BnBuf pow_tbl;                      // window tables of Gt::pow (gt_pow_B)
+    BnBuf mul_tbl;                      // affine window tables of the scalar-multiplication kernels (one sub-launch)
     BnBuf miller_state;                 // running points of the shared-accumulator Miller loop (miller_shared*_B), one round
     hipEvent_t scratch_ev = nullptr;    // completion of the last launch that used ws / exp_tbl ...
     hipStream_t scratch_stream = nullptr;   // ... and the stream it ran on
@@ -144,7 +145,8 @@ int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStr
 int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *out, hipStream_t s);   // scratch guard held by the caller
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s);
 size_t bn_product_tmp_bytes(size_t n);
-int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize);
+// table: the caller's own buffer (pipelined path: the slot's) or NULL for the context's (then under a BnScratchGuard)
+int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize, BnBuf *table = nullptr);
 
 extern "C" {
 // bn254_kernels_b.hip
@@ -167,8 +169,9 @@ int bn254_launch_gt_tail_W(const void *in, size_t groups, unsigned m, void *out,
 void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, size_t *grid, size_t *scratch_bytes, size_t *counter_words);
 int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, void *scratch, void *counters, void *out, hipStream_t s);
 // bn254_kernels_mul.hip
-int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);
-int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, hipStream_t s);
+size_t bn254_mul_table_bytes_M(int g, size_t n);
+int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, void *table, hipStream_t s);
+int bn254_launch_g2_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, void *table, hipStream_t s);
 int bn254_launch_g1_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s);
 int bn254_launch_g2_add_M(const void *a, const void *b, void *out, size_t n, int negate_b, hipStream_t s);
 }
