@@ -440,11 +440,45 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // lane pair's own digit - at most 9 (16) different 1 KB rows per instruction instead of 64 different cache lines with the round-2
 // [lane][entry] layout.  Inputs in the cyclotomic subgroup (checked on the device: every value the reference's API can produce)
 // take the signed-window Granger-Scott chain (pairing.hpp gt_pow_cyclotomic), anything else the general one.
+#ifndef BN_POW_TABLE_ENTRY_MAJOR
+// [lane][entry][half][7 x 16 bytes]: the entry a lane reads depends on ITS digit, so contiguous 224-byte runs per lane (two cache
+// lines each) beat the entry-major rows (every lane's 16 bytes from a different 1 KB row: 4x the traffic, profiles/r03m_pmc_side.txt)
+struct PowTableLane {
+    uint4 *base;             // this lane's 16 x 2 x 7 vectors
+    __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
+        uint4 *p = base + (uint32_t)(slot * 2 + half) * 7u;
+        uint32_t w[28];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { w[i] = v.c0.v.l[i]; w[9 + i] = v.c1.v.l[i]; w[18 + i] = v.c2.v.l[i]; }
+        w[27] = 0;
+#pragma unroll
+        for (int g = 0; g < 7; ++g) p[g] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+    }
+    __device__ __forceinline__ Fq6<F2> ld6(int slot, int half) const {
+        const uint4 *p = base + (uint32_t)(slot * 2 + half) * 7u;
+        uint32_t w[28];
+#pragma unroll
+        for (int g = 0; g < 7; ++g) { const uint4 x = p[g]; w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w; }
+        Fq6<F2> v;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { v.c0.v.l[i] = w[i]; v.c1.v.l[i] = w[9 + i]; v.c2.v.l[i] = w[18 + i]; }
+        return v;
+    }
+    __device__ __forceinline__ void put(int i, const Fq12<F2> &v) const { st6(i, 0, v.c0); st6(i, 1, v.c1); }
+    __device__ __forceinline__ Fq6<F2> c0(int i) const { return ld6(i, 0); }
+    __device__ __forceinline__ Fq6<F2> c1(int i) const { return ld6(i, 1); }
+};
+#endif
 constexpr size_t POW_TABLE_DWORDS_PER_LANE = 16 * 2 * 7 * 4;
 // the general chain as a real function: it is the rare path, and inlined next to the cyclotomic chain the two were register-allocated
 // together (97 spilled VGPRs)
-__device__ __noinline__ void gt_pow_general_cold(const Fq12<F2> *base, const uint32_t *raw, const ExpTableMem *tbl, Fq12<F2> *res) {
-    ExpTableMem t = *tbl;
+#ifdef BN_POW_TABLE_ENTRY_MAJOR
+typedef ExpTableMem PowTable;
+#else
+typedef PowTableLane PowTable;
+#endif
+__device__ __noinline__ void gt_pow_general_cold(const Fq12<F2> *base, const uint32_t *raw, const PowTable *tbl, Fq12<F2> *res) {
+    PowTable t = *tbl;
     *res = gt_pow_windowed(*base, raw, t);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table, int force_general) {
@@ -457,7 +491,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 #pragma unroll
     for (int i = 0; i < 8; ++i) kw[i] = k[8u * pair + i];
     fr_from_mont(kw, raw);
-    ExpTableMem tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
+#ifdef BN_POW_TABLE_ENTRY_MAJOR
+    PowTable tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
+#else
+    PowTable tbl = {(uint4 *)table + (size_t)t * (POW_TABLE_DWORDS_PER_LANE / 4)};
+#endif
     const Fq12<F2> base = f12_load<F2>(a + 96u * pair);
     Fq12<F2> res;
     if (!force_general && __all(gt_is_cyclotomic(base))) res = gt_pow_cyclotomic(base, raw, tbl);          // wave-uniform choice
