@@ -159,7 +159,9 @@ struct WaveDevR {                                   // the machine with only the
 #pragma unroll
         for (int i = 0; i < 9; ++i) *(uint32_t *)(regs + off + 256u * i) = v.l[i];
     }
-    __device__ __forceinline__ Role role(uint32_t phase) const { return roles[(phase - MULR_PHASE0) * 32u + (threadIdx.x >> 1)]; }
+    __device__ __forceinline__ Role role(uint32_t phase) const {                        // (the END word names phase 0: its role is fetched ahead, never used)
+        return roles[(phase < (uint32_t)MULR_PHASE0 ? 0u : phase - MULR_PHASE0) * 32u + (threadIdx.x >> 1)];
+    }
     __device__ __forceinline__ int pair() const { return (int)(threadIdx.x >> 1); }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 };

@@ -119,12 +119,16 @@ BN_FN void w_inv(W &w, const Role &r, uint32_t base) {
 // runs a program (wave_tables.hpp PROG_*): one phase per entry, a wave-level barrier after each
 template <class W>
 BN_FN void w_run(W &w, const uint32_t *prog) {
+    // the role of the NEXT phase is fetched while this one computes (a role read is an LDS round trip in front of the gathers,
+    // which are another: at one wave per SIMD nothing else hides them)
+    uint32_t e = prog[0];
+    Role r = w.role((e >> 4) & 255u);
 #pragma unroll 1
     for (int pc = 0;; ++pc) {
-        const uint32_t e = prog[pc];
-        const uint32_t op = e & 15u, phase = (e >> 4) & 255u, base = e >> 12;
+        const uint32_t op = e & 15u, base = e >> 12;
         if (op == OP_END) break;
-        const Role r = w.role(phase);
+        const uint32_t e_next = prog[pc + 1];
+        const Role r_next = w.role((e_next >> 4) & 255u);
         if (op == OP_FUSE_SQR) w_fuse_sqr(w, r);
         else if (op == OP_PROD_SQR) w_prod<2, 0, true, false, false>(w, r, base);
         else if (op == OP_COMB_C) w_comb<true, false>(w, r, base);
@@ -138,6 +142,7 @@ BN_FN void w_run(W &w, const uint32_t *prog) {
         else if (op == OP_PROD_MULC) w_prod<1, 1, false, true, false>(w, r, base);
         else w_inv(w, r, base);
         w.sync();
+        e = e_next; r = r_next;
     }
 }
 
