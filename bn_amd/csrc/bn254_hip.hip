@@ -306,13 +306,32 @@ int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStr
 }
 // reduces n Fq12 values at `in` to one at `out`; `tmp` >= bn_product_tmp_bytes(n).  Lane-pair mapping: ONE launch (lane chunks ->
 // wave-cooperative fold -> arrival tree over the waves, bn254_kernels_w.hip); one-lane mapping (test double): a launch per level.
-static unsigned product_chunk(size_t n) { return (unsigned)((n + 65535) / 65536); }      // at most 2^16 lane pairs = two waves per SIMD
+// Shape of the one-launch product tree, read off profiles/r03p_product_shape_sweep.txt.  Three ways to multiply, three prices:
+// a lane pair multiplies two values in ~20-30 us but 32 of them do so at once per wave (`chunk` values per lane pair, then `bfly`
+// butterfly levels across the pairs of a wave); the wave machine multiplies two values in ~2.7 us but one product at a time
+// (what is left of a wave's `per_wave` partial products); a level of the arrival tree across waves costs ~5 us (product + publish).
+// Few values: many small waves (the tree's log2 beats the serial fold).  Many: full waves, about one wave per SIMD of groups.
+struct ProductShape { unsigned chunk, per_wave, bfly; };
+static ProductShape product_shape(size_t n) {
+    ProductShape ps;
+    if (n <= 64) ps = {1u, 2u, 0u};
+    else if (n <= 2048) ps = {1u, 4u, 0u};
+    else if (n <= 8192) ps = {1u, 8u, 0u};
+    else if (n <= 16384) ps = {1u, 32u, 2u};
+    else if (n < 65536) ps = {2u, 32u, 2u};
+    else ps = {(unsigned)((n + 32767) / 32768), 32u, 2u};
+    if (const char *e = getenv("BN254_PRODUCT_CHUNK")) { const long v = atol(e); if (v >= 1 && v <= 4096) ps.chunk = (unsigned)v; }
+    if (const char *e = getenv("BN254_PRODUCT_PER_WAVE")) { const long v = atol(e); if (v >= 1 && v <= 32) ps.per_wave = (unsigned)v; }
+    if (const char *e = getenv("BN254_PRODUCT_BFLY")) { const long v = atol(e); if (v >= 0 && v <= 5) ps.bfly = (unsigned)v; }
+    return ps;
+}
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s) {
     if (c->mapping.load() == 1) {
         size_t grid, sb, cw;
-        bn254_gt_reduce_sizes_W(n, product_chunk(n), &grid, &sb, &cw);
+        const ProductShape ps = product_shape(n);
+        bn254_gt_reduce_sizes_W(n, ps.chunk, ps.per_wave, &grid, &sb, &cw);
         BnScope sc(c, s, "gt_product");
-        return bn254_launch_gt_reduce_W(in, n, product_chunk(n), tmp, (char *)tmp + sb, out, s);
+        return bn254_launch_gt_reduce_W(in, n, ps.chunk, ps.per_wave, ps.bfly, tmp, (char *)tmp + sb, out, s);
     }
     const uint32_t chunk = 4;
     const uint32_t *src = (const uint32_t *)in;
@@ -334,9 +353,10 @@ int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *t
     return BN254_OK;
 }
 // out = final_exponentiation(in[0] * ... * in[m-1]): the tail of a sharded multi-pairing (the partial products of the ranks, then
-// the ONE final exponentiation).  Up to 64 values: one wave-cooperative launch; more: product tree, then the exponentiation.
+// the ONE final exponentiation).  Up to 16 values: one wave-cooperative launch (15 products in a row cost what the second launch
+// and the tree's levels would); more: product tree, then the exponentiation.
 int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *out, hipStream_t s) {
-    if (c->mapping.load() == 1 && m >= 1 && m <= 64) {
+    if (c->mapping.load() == 1 && m >= 1 && m <= 16) {
         BnScope sc(c, s, "gt_tail");
         return bn254_launch_gt_tail_W(in, 1, (unsigned)m, out, 1, s);
     }
@@ -346,7 +366,8 @@ int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *ou
 }
 size_t bn_product_tmp_bytes(size_t n) {
     size_t grid, sb, cw;
-    bn254_gt_reduce_sizes_W(n ? n : 1, product_chunk(n ? n : 1), &grid, &sb, &cw);
+    const ProductShape ps = product_shape(n ? n : 1);
+    bn254_gt_reduce_sizes_W(n ? n : 1, ps.chunk, ps.per_wave, &grid, &sb, &cw);
     const size_t a = 2 * ((n + 3) / 4) * 384 + 384, b = sb + cw * sizeof(uint32_t) + 256;
     return a > b ? a : b;
 }

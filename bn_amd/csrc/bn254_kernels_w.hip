@@ -136,9 +136,10 @@ __global__ void __launch_bounds__(64) bn254_wave_ubench_W(int which, int iters, 
 // ---- the multi-pairing product tree in ONE launch (lane chunks -> wave -> grid, last arriver continues) ------------
 // in[0..n) Fq12 values (384-byte images) -> out[0] = their product (fq12.rs:295-307 folded, shootout/main.rs:11-16; the order is
 // free: Fq12 is commutative and every value is exact).
-//   (a) lane pair g of the grid multiplies the `chunk` consecutive values of its group in the lane-pair mapping (full-width work);
-//   (b) the 32 partial products of a wave are folded by the wave-cooperative product (31 x ~2.5 us instead of five butterfly levels
-//       of a 20 us lane-pair product);
+//   (a) lane pair g of the grid (the first `per_wave` pairs of each wave) multiplies the `chunk` consecutive values of its group in
+//       the lane-pair mapping (full-width work);
+//   (b) the partial products of a wave: `bfly` butterfly levels of lane-pair products (all pairs at once, each level halves what
+//       is left), then the wave-cooperative product folds the rest one after the other (~2.7 us each instead of ~20 us);
 //   (c) waves meet pairwise in a binary tree over the wave index: each arrival publishes its value and takes a ticket on the node;
 //       the FIRST arriver exits, the SECOND one multiplies the two values and moves up - nobody ever waits, so the grid may be
 //       larger than what is resident.  Publication is plain stores -> agent-scope release -> ticket; consumption is ticket ->
@@ -171,8 +172,21 @@ __device__ __forceinline__ void put_f12(const WaveDevR &w, uint32_t reg0, const 
     w.st(reg0, f.c0.c0.v); w.st(reg0 + 8, f.c0.c1.v); w.st(reg0 + 16, f.c0.c2.v);
     w.st(reg0 + 24, f.c1.c0.v); w.st(reg0 + 32, f.c1.c1.v); w.st(reg0 + 40, f.c1.c2.v);
 }
+__device__ __forceinline__ Fe xchg_fe(const Fe &a, int lane_xor) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__shfl_xor((int)a.l[i], lane_xor, 64);
+    return r;
+}
+// the same value as held by the lane pair `lane_xor / 2` pairs away
+__device__ __forceinline__ Fq12<F2> xchg_f12(const Fq12<F2> &f, int lane_xor) {
+    Fq12<F2> r;
+    r.c0.c0.v = xchg_fe(f.c0.c0.v, lane_xor); r.c0.c1.v = xchg_fe(f.c0.c1.v, lane_xor); r.c0.c2.v = xchg_fe(f.c0.c2.v, lane_xor);
+    r.c1.c0.v = xchg_fe(f.c1.c0.v, lane_xor); r.c1.c1.v = xchg_fe(f.c1.c1.v, lane_xor); r.c1.c2.v = xchg_fe(f.c1.c2.v, lane_xor);
+    return r;
+}
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-bn254_gt_reduce_W(const uint32_t *in, uint32_t n, uint32_t chunk, uint32_t *scratch, uint32_t *counters, uint32_t *out) {
+bn254_gt_reduce_W(const uint32_t *in, uint32_t n, uint32_t chunk, uint32_t per_wave, uint32_t bfly, uint32_t *scratch, uint32_t *counters, uint32_t *out) {
     __shared__ struct { uint32_t regs[2 * PAGE_DW]; uint32_t roles[3 * 32 * 6]; } lds;
     {
         const uint32_t *src = (const uint32_t *)&ROLES[MULR_PHASE0][0];
@@ -183,17 +197,24 @@ bn254_gt_reduce_W(const uint32_t *in, uint32_t n, uint32_t chunk, uint32_t *scra
     WaveDevR w = {(char *)lds.regs + 4u * (threadIdx.x & 1u), (const Role *)lds.roles};
     const uint32_t pair = threadIdx.x >> 1;
     // (a) this lane pair's group
-    const uint32_t groups = (n + chunk - 1) / chunk, g = blockIdx.x * 32u + pair;
-    const bool live = g < groups;
+    const uint32_t groups = (n + chunk - 1) / chunk, g = blockIdx.x * per_wave + pair;
+    const bool live = pair < per_wave && g < groups;
     const uint32_t lo = live ? g * chunk : 0u, hi = live ? (lo + chunk < n ? lo + chunk : n) : 1u;
     Fq12<F2> acc = f12_load<F2>(in + 96u * lo);
 #pragma unroll 1
     for (uint32_t j = lo + 1; j < hi; ++j) acc = f12_mul_o(acc, f12_load<F2>(in + 96u * j));
-    // (b) fold the wave's live partial products
-    const uint32_t live_pairs = groups - blockIdx.x * 32u < 32u ? groups - blockIdx.x * 32u : 32u;      // >= 1 by the grid size
+    // (b) fold the wave's live partial products: `bfly` butterfly levels of lane-pair products (all pairs at once: pair p takes
+    // the value of pair p ^ d), then the wave-cooperative product over what is left (every 2^bfly-th pair)
+    const uint32_t live_pairs = groups - blockIdx.x * per_wave < per_wave ? groups - blockIdx.x * per_wave : per_wave;      // >= 1 by the grid size
+    uint32_t stride = 1;
+    if (bfly && live_pairs > 1) {
+        if (!live) acc = f12_one<F2>();
+#pragma unroll 1
+        for (; stride < (1u << bfly) && stride < live_pairs; stride <<= 1) acc = f12_mul_o(acc, xchg_f12(acc, 2 * stride));
+    }
     if (pair == 0) put_f12(w, OFF_RES, acc);
 #pragma unroll 1
-    for (uint32_t j = 1; j < live_pairs; ++j) {
+    for (uint32_t j = stride; j < live_pairs; j += stride) {
         if (pair == j) put_f12(w, OFF_OPND, acc);
         w.sync();
         w_run(w, PROG_MULR);
@@ -237,17 +258,17 @@ bn254_gt_reduce_W(const uint32_t *in, uint32_t n, uint32_t chunk, uint32_t *scra
 
 extern "C" {
 // scratch bytes and counter words the product tree needs for `n` values in groups of `chunk`
-void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, size_t *grid, size_t *scratch_bytes, size_t *counter_words) {
-    const size_t groups = (n + chunk - 1) / chunk, waves = (groups + 31) / 32;
+void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, unsigned per_wave, size_t *grid, size_t *scratch_bytes, size_t *counter_words) {
+    const size_t groups = (n + chunk - 1) / chunk, waves = (groups + per_wave - 1) / per_wave;
     // tree levels have ceil(c/2) nodes each: sum over levels of the values published <= 2 waves + log2(waves), tickets <= waves + log2(waves)
     *grid = waves; *scratch_bytes = (2 * waves + 64) * NODE_DWORDS * sizeof(uint32_t); *counter_words = waves + 64;
 }
-int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, void *scratch, void *counters, void *out, hipStream_t s) {
+int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, unsigned per_wave, unsigned bfly, void *scratch, void *counters, void *out, hipStream_t s) {
     size_t grid, sb, cw;
-    bn254_gt_reduce_sizes_W(n, chunk, &grid, &sb, &cw);
+    bn254_gt_reduce_sizes_W(n, chunk, per_wave, &grid, &sb, &cw);
     hipError_t e = hipMemsetAsync(counters, 0, cw * sizeof(uint32_t), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bn254_gt_reduce_W, dim3((unsigned)grid), dim3(64), 0, s, (const uint32_t *)in, (uint32_t)n, chunk, (uint32_t *)scratch, (uint32_t *)counters, (uint32_t *)out);
+    hipLaunchKernelGGL(bn254_gt_reduce_W, dim3((unsigned)grid), dim3(64), 0, s, (const uint32_t *)in, (uint32_t)n, chunk, per_wave, bfly, (uint32_t *)scratch, (uint32_t *)counters, (uint32_t *)out);
     return (int)hipGetLastError();
 }
 int bn254_launch_wave_ubench_W(int which, int iters, void *out, hipStream_t s) {

@@ -166,8 +166,8 @@ int bn254_launch_wave_ubench_W(int which, int iters, void *out, hipStream_t s);
 int bn254_launch_final_exp_W(const void *f, void *out, size_t n, hipStream_t s);
 int bn254_launch_pairing_W(const void *p, const void *q, void *out, size_t n, int final_exp, hipStream_t s);
 int bn254_launch_gt_tail_W(const void *in, size_t groups, unsigned m, void *out, int final_exp, hipStream_t s);
-void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, size_t *grid, size_t *scratch_bytes, size_t *counter_words);
-int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, void *scratch, void *counters, void *out, hipStream_t s);
+void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, unsigned per_wave, size_t *grid, size_t *scratch_bytes, size_t *counter_words);
+int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, unsigned per_wave, unsigned bfly, void *scratch, void *counters, void *out, hipStream_t s);
 // bn254_kernels_mul.hip
 size_t bn254_mul_table_bytes_M(int g, size_t n);
 int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, void *table, hipStream_t s);

@@ -169,7 +169,8 @@ int bn254_final_exp_batch_dev(bn254_ctx *ctx, const void *d_f, void *d_out, size
 int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out, void *stream);
 /* d_out[0] = final_exponentiation(d_in[0] * ... * d_in[m-1]), m >= 1: the tail of a sharded multi-pairing - the ranks' partial
    products after their exchange, then the ONE final exponentiation (fq12.rs:41-88 behind the fold of shootout/main.rs:11-16).
-   Up to 64 values it is a single wave-cooperative launch (one Fq12 spread over a wave, ~0.5 ms instead of 2.9 ms). */
+   Up to 16 values it is a single wave-cooperative launch (one Fq12 spread over a wave, ~0.5 ms instead of 2.9 ms); more go through
+   the one-launch product tree first. */
 int bn254_gt_product_final_exp_dev(bn254_ctx *ctx, const void *d_in, size_t m, void *d_out, void *stream);
 /* local part of a sharded multi-pairing: un-exponentiated product of the Miller values of n pairs -> one Fq12 */
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream);

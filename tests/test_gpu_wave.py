@@ -113,6 +113,12 @@ def test_one_launch_product_tree_matches_fold(oracle, te):
     for m in (1000, 4097, 65536, 70001, n):
         got = _host(te.gt_product(vals[:m].contiguous()))
         assert np.array_equal(got, _fold(oracle, host[:m])), m
+    # every shape of the tree the host could pick (bn254_hip.hip product_shape), ragged against each of its three parameters
+    want = {m: _fold(oracle, host[:m]) for m in (1, 2, 33, 1000, 4097)}
+    for c, L, B in ((1, 2, 0), (3, 5, 1), (2, 32, 3), (7, 12, 2), (1, 32, 5), (4, 1, 0), (2, 3, 5)):
+        with _env(BN254_PRODUCT_CHUNK=c, BN254_PRODUCT_PER_WAVE=L, BN254_PRODUCT_BFLY=B):
+            for m, w in want.items():
+                assert np.array_equal(_host(te.gt_product(vals[:m].contiguous())), w), (c, L, B, m)
     # the arrival tree is a race by design (first arriver leaves, second continues): the value must not depend on who wins
     ref = te.gt_product(vals)
     for _ in range(20):
@@ -120,10 +126,10 @@ def test_one_launch_product_tree_matches_fold(oracle, te):
 
 
 def test_product_final_exp_tail(oracle, te):
-    """bn254_gt_product_final_exp_dev: what rank 0 runs after the all-gather of the sharded multi-pairing (one launch up to 64 values)"""
+    """bn254_gt_product_final_exp_dev: what rank 0 runs after the all-gather of the sharded multi-pairing (one launch up to 16 values, product tree + exponentiation above)"""
     rng = np.random.default_rng(303)
     vals = _rand_fq12(oracle, rng, 66)
-    for m in (1, 2, 8, 64, 66):
+    for m in (1, 2, 8, 16, 17, 64, 66):
         want = oracle.fq12_final_exponentiation(_fold(oracle, vals[:m]))
         assert np.array_equal(_host(te.product_final_exp(_dev(te, vals[:m]))), want), m
 
