@@ -900,3 +900,79 @@ def test_shared_accumulator_miller_kernels(oracle, m):
     assert np.array_equal(plain, shared)
     assert np.array_equal(shared, oracle.pairing_product(P, Q))
     e.close()
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_rccl_exchange_between_distinct_gpus(oracle):
+    """the one branch no single-GPU box can run: bn254_multi_* over DISTINCT devices (ncclCommInitAll over the device list, grouped
+    ncclAllGather of the 384-byte partials, one final exponentiation).  Skipped unless the box has two GPUs."""
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    import os
+    import bn_amd
+    rng = np.random.default_rng(401)
+    n = 301
+    P, Q = _points(oracle, rng, n)
+    P[7] = oracle.g1_zero(); Q[9] = oracle.g2_zero()
+    want_b = oracle.pairing_batch(P, Q); want_p = oracle.pairing_product(P, Q)
+    devs = list(range(min(_gpu_count(), 8)))
+    for kind in ("rccl", "peer"):
+        old = os.environ.get("BN254_MULTI_EXCHANGE")
+        os.environ["BN254_MULTI_EXCHANGE"] = kind
+        try:
+            m = bn_amd.MultiEngine(devs)
+            assert m.exchange == kind
+            assert np.array_equal(m.pairing_batch(P, Q), want_b), kind
+            for _ in range(3):
+                assert np.array_equal(m.pairing_product(P, Q), want_p), kind
+            assert np.array_equal(m.pairing_product(P[:1], Q[:1]), oracle.pairing_product(P[:1], Q[:1]))
+            m.close()
+        finally:
+            if old is None: os.environ.pop("BN254_MULTI_EXCHANGE", None)
+            else: os.environ["BN254_MULTI_EXCHANGE"] = old
+
+
+NCCL_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [%(root)r, %(root)r + "/oracle", %(root)r + "/tests"]
+import bn_amd
+from bn_amd import distributed as D
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", rank)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+eng = D.TorchEngine(bn_amd.Engine(rank), dev)
+n = %(n)d
+lo, hi = D.shard_range(n, rank, world)
+P, Q = D.synthetic_points(eng, lo, hi)
+gt = D.pairing_product_sharded(eng, P, Q)
+torch.cuda.synchronize()
+np.save(%(out)r + f".{rank}.npy", gt.cpu().numpy().view(np.uint64).reshape(1, 48))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sharded_product_over_rccl_world2(oracle, tmp_path):
+    """one process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI): shards, all_gather_into_tensor of the partials,
+    single final exponentiation - bit-exact on both ranks.  Skipped unless the box has two GPUs."""
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    import os, pathlib, subprocess, sys
+    from bn_amd import distributed as D
+    root = pathlib.Path(__file__).resolve().parents[1]
+    n = 300
+    script = tmp_path / "worker.py"
+    script.write_text(NCCL_WORKER % {"root": str(root), "n": n, "out": str(tmp_path / "res")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    k1 = D.synthetic_scalars(0, n, 0); k2 = D.synthetic_scalars(0, n, 1)
+    P = oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (n, 1)), k1); Q = oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (n, 1)), k2)
+    want = oracle.pairing_product(P, Q)
+    for r in range(2):
+        assert np.array_equal(np.load(str(tmp_path / f"res.{r}.npy"))[0], want), r
