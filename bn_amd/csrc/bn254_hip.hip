@@ -594,7 +594,7 @@ int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, voi
 int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream) {
     BN_DEV_PROLOGUE(!d_a || !d_k || !d_out, BN_N_MAX);
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
-    // ONE window table (16 x 216 B per lane of a sub-launch), reused by every sub-launch in stream order: 450 MB at a full round
+    // ONE window table (33 x 224 B per lane of a sub-launch), reused by every sub-launch in stream order: 970 MB at a full round
     // whatever the batch size (round 2 allocated 6.9 KB x n)
     const size_t step = bn_sub_launch(ctx, n);
     rc = ctx->pow_tbl.reserve(bn254_gt_pow_table_bytes_B(step)); if (rc) return rc;

@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // [lane][entry][half][7 x 16 bytes]: the entry a lane reads depends on ITS digit, so contiguous 224-byte runs per lane (two cache
 // lines each) beat the entry-major rows (every lane's 16 bytes from a different 1 KB row: 4x the traffic, profiles/r03m_pmc_side.txt)
 struct PowTableLane {
-    uint4 *base;             // this lane's 16 x 2 x 7 vectors
+    uint4 *base;             // this lane's 33 x 2 x 7 vectors
     __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
         uint4 *p = base + (uint32_t)(slot * 2 + half) * 7u;
         uint32_t w[28];
@@ -469,7 +469,7 @@ struct PowTableLane {
     __device__ __forceinline__ Fq6<F2> c1(int i) const { return ld6(i, 1); }
 };
 #endif
-constexpr size_t POW_TABLE_DWORDS_PER_LANE = 16 * 2 * 7 * 4;
+constexpr size_t POW_TABLE_DWORDS_PER_LANE = GT_GLS_ENTRIES * 2 * 7 * 4;          // 33 entries of 216 B: 7.4 KB per lane
 // the general chain as a real function: it is the rare path, and inlined next to the cyclotomic chain the two were register-allocated
 // together (97 spilled VGPRs)
 #ifdef BN_POW_TABLE_ENTRY_MAJOR
@@ -481,7 +481,11 @@ __device__ __noinline__ void gt_pow_general_cold(const Fq12<F2> *base, const uin
     PowTable t = *tbl;
     *res = gt_pow_windowed(*base, raw, t);
 }
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table, int force_general) {
+__device__ __noinline__ void gt_pow_strict_cold(const Fq12<F2> *base, const uint32_t *raw, const PowTable *tbl, Fq12<F2> *res) {
+    PowTable t = *tbl;
+    *res = gt_pow_cyclotomic(*base, raw, t);
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table, int mode) {
     BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
@@ -498,7 +502,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 #endif
     const Fq12<F2> base = f12_load<F2>(a + 96u * pair);
     Fq12<F2> res;
-    if (!force_general && __all(gt_is_cyclotomic(base))) res = gt_pow_cyclotomic(base, raw, tbl);          // wave-uniform choice
+    // wave-uniform choice.  mode 0: Frobenius decomposition when every element of the wave is cyclotomic (exact for values of order
+    // r - all the reference's Gt can hold), 2: the one-dimensional signed-window chain (exact for ANY cyclotomic element), 1 or a
+    // non-cyclotomic element in the wave: the general chain (exact for any Fq12)
+    const bool cyc = mode != 1 && __all(gt_is_cyclotomic(base));
+    if (cyc && mode == 0) res = gt_pow_gls(base, raw, tbl);
+    else if (cyc) gt_pow_strict_cold(&base, raw, &tbl, &res);
     else gt_pow_general_cold(&base, raw, &tbl, &res);
     if (live) f12_store(res, out + 96u * pair);
 }
@@ -537,8 +546,11 @@ size_t bn254_gt_pow_table_bytes_B(size_t n) {
 }
 int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    static const int force_general = getenv("BN254_GT_POW_GENERAL") ? atoi(getenv("BN254_GT_POW_GENERAL")) : 0;      // A/B experiments
-    hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, (uint32_t *)table, force_general);
+    // BN254_GT_POW_MODE: 0 (default) Frobenius decomposition for cyclotomic input, 2 strict (one-dimensional chain for cyclotomic
+    // input: no assumption on the order), 1 the general chain for everything
+    const char *e = getenv("BN254_GT_POW_MODE");
+    const int mode = e ? atoi(e) : 0;
+    hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, (uint32_t *)table, mode < 0 || mode > 2 ? 0 : mode);
     return (int)hipGetLastError();
 }
 int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s) {

@@ -490,6 +490,56 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
     return res;
 }
 
+// Gt::pow with the Frobenius endomorphism (Galbraith-Scott in the target group).  pi(f) = f^q, and on elements of ORDER r the
+// exponent only counts mod r, where q = lambda = 6u^2 - the same eigenvalue psi has on G2 (e(P, psi Q) = e(P, Q)^q).  So with the
+// decomposition of scalar_mul_gls, f^k = prod_i pi^i(f)^(k_i), |k_i| < 2^67: 68 cyclotomic squarings instead of 252, the four Booth
+// digit streams share the accumulator (72 products), conj() is the inverse.  The table holds one, then a^1 .. a^8 under pi^0 .. pi^3
+// (a Frobenius map is five Fq2 products by constants: 24 of them here instead of 54 on the fly).
+// PRECONDITION: base has order dividing r - true of every value the reference's API can produce (lib.rs:165-183: Gt::one, pairing(),
+// products, powers and inverses of such; the Fq12 inside Gt is private and Gt has no decoder).  The caller has checked that base is
+// cyclotomic, which every such value is; order r itself would cost an exponentiation to check - the strict mode of the kernel
+// (gt_pow_cyclotomic) is exact for ANY cyclotomic element instead.
+constexpr int GT_GLS_ENTRIES = 1 + 4 * 8;
+template <class F2, class Tbl>
+BN_FN Fq12<F2> gt_pow_gls(const Fq12<F2> &base, const uint32_t *k_raw, Tbl &tbl) {
+    const GlsSplit g = gls_decompose(k_raw);
+    tbl.put(0, f12_one<F2>());
+    tbl.put(1, base);
+#pragma unroll 1
+    for (int e = 2; e <= 8; ++e) {                 // a^e = (a^(e/2))^2 for even e, a^(e-1) * a for odd e
+        Fq12<F2> v;
+        if ((e & 1) == 0) v = f12_cyclotomic_sqr(Fq12<F2>{tbl.c0(e >> 1), tbl.c1(e >> 1)});
+        else v = f12_mul_src(Fq12<F2>{tbl.c0(e - 1), tbl.c1(e - 1)}, Fq12Slot<F2, Tbl>{tbl, 1}, false);
+        tbl.put(e, v);
+    }
+#pragma unroll 1
+    for (int e = 1; e <= 8; ++e) {
+        const Fq12<F2> v = {tbl.c0(e), tbl.c1(e)};
+        tbl.put(8 + e, f12_frobenius<1>(v));
+        tbl.put(16 + e, f12_frobenius<2>(v));
+        tbl.put(24 + e, f12_frobenius<3>(v));
+    }
+    Fq12<F2> res = f12_one<F2>();
+#pragma unroll 1
+    for (int w = GLS_WINDOWS - 1; w >= 0; --w) {
+        if (w != GLS_WINDOWS - 1) {
+#pragma unroll 1
+            for (int d = 0; d < 4; ++d) res = f12_cyclotomic_sqr(res);
+        }
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int d = booth_digit<3>(g.m[j], w);
+            const int ad = d < 0 ? -d : d;
+            const bool neg = (d < 0) != g.neg[j];
+            // res * conj(t) = conj(conj(res) * t): the sign goes on the running value, the table operand takes the plain path
+            res.c1 = f6_cond_neg(neg, res.c1);
+            res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, ad ? 8 * j + ad : 0}, false);
+            res.c1 = f6_cond_neg(neg, res.c1);
+        }
+    }
+    return res;
+}
+
 // the same chains with the table in a local array (host simulation)
 BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw) { AffTableVars<FqField> t; return scalar_mul_glv(p, k_raw, t); }
 template <class F2> BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_t *k_raw) { AffTableVars<Fq2Field<F2>> t; return scalar_mul_gls<F2>(p, k_raw, t); }

@@ -514,7 +514,7 @@ BN_FN bool gt_is_cyclotomic(const Fq12<F2> &a) {
 }
 template <class F2>
 struct PowTableVars {
-    Fq12<F2> s_[16];
+    Fq12<F2> s_[33];
     BN_FN void put(int i, const Fq12<F2> &v) { s_[i] = v; }
     BN_FN Fq6<F2> c0(int i) const { return s_[i].c0; }
     BN_FN Fq6<F2> c1(int i) const { return s_[i].c1; }

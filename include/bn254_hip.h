@@ -108,6 +108,12 @@ int bn254_g2_add_batch(bn254_ctx *ctx, const bn_g2 *a, const bn_g2 *b, bn_g2 *ou
 int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, size_t n);
 int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_coeffs *coeffs, int shared, bn_gt *out, size_t n);
 int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n);
+/* Gt::pow (lib.rs:171).  a[i] are Gt VALUES - what the reference's type holds: Gt::one, pairing() and products, powers, inverses of
+   such (the Fq12 inside Gt is private and Gt has no decoder), all of order r.  On those the device exponentiates through the
+   Frobenius decomposition (k = k0 + k1 q + k2 q^2 + k3 q^3 mod r: 68 cyclotomic squarings and 72 products instead of 252 and 64),
+   which needs the order to divide r.  An element that is not even cyclotomic is detected and takes the general chain
+   (fields/mod.rs:35-46 as written).  Environment BN254_GT_POW_MODE=2 selects the one-dimensional cyclotomic chain, exact for ANY
+   cyclotomic element; =1 the general chain for everything.  One window table of 7.4 KB per lane of a sub-launch lives in the context. */
 int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n);
 /* out[i] = a[i]^-1 in Fq12 (Gt::inverse, lib.rs:172 -> fields/fq12.rs:284-292); a[i] must be non-zero, as every Gt value is */
 int bn254_gt_inverse_batch(bn254_ctx *ctx, const bn_gt *a, bn_gt *out, size_t n);

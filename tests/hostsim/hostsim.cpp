@@ -269,6 +269,13 @@ EXPORT void hsb_gt_pow_cyclotomic(const uint32_t *a, const uint32_t *k, uint32_t
     PowTableVars<F2B> tbl;
     f12_store(gt_pow_cyclotomic(f12_load<F2B>(a), raw, tbl), o);
 }
+// Gt::pow through the Frobenius decomposition (the default path of bn254_gt_pow_B for cyclotomic input)
+EXPORT void hsb_gt_pow_gls(const uint32_t *a, const uint32_t *k, uint32_t *o) {
+    uint32_t raw[8];
+    fr_from_mont(k, raw);
+    PowTableVars<F2B> tbl;
+    f12_store(gt_pow_gls(f12_load<F2B>(a), raw, tbl), o);
+}
 EXPORT int hsb_gt_is_cyclotomic(const uint32_t *a) { return gt_is_cyclotomic(f12_load<F2B>(a)) ? 1 : 0; }
 // what bn254_gt_pow_B executes for one element: membership test, then the chain it selects
 EXPORT void hsb_gt_pow_auto(const uint32_t *a, const uint32_t *k, uint32_t *o) {
@@ -276,7 +283,7 @@ EXPORT void hsb_gt_pow_auto(const uint32_t *a, const uint32_t *k, uint32_t *o) {
     fr_from_mont(k, raw);
     PowTableVars<F2B> tbl;
     const Fq12<F2B> base = f12_load<F2B>(a);
-    f12_store(gt_is_cyclotomic(base) ? gt_pow_cyclotomic(base, raw, tbl) : gt_pow_windowed(base, raw, tbl), o);
+    f12_store(gt_is_cyclotomic(base) ? gt_pow_gls(base, raw, tbl) : gt_pow_windowed(base, raw, tbl), o);
 }
 
 // G2 * Fr through the GLS chain (what bn254_g2_mul_batch runs), normalized; and the 4-dimensional decomposition itself

@@ -976,3 +976,36 @@ def test_sharded_product_over_rccl_world2(oracle, tmp_path):
     want = oracle.pairing_product(P, Q)
     for r in range(2):
         assert np.array_equal(np.load(str(tmp_path / f"res.{r}.npy"))[0], want), r
+
+
+def test_gt_pow_modes(oracle, eng):
+    """Gt::pow's three chains (BN254_GT_POW_MODE): the Frobenius decomposition (default; needs order r, which every value of the
+    reference's Gt type has), the one-dimensional cyclotomic chain and the general chain agree with fields/mod.rs:35-46 on pairing
+    values; a cyclotomic element of another order (the easy part of the final exponentiation applied to an arbitrary Fq12 - not
+    constructible through the reference's API) is exact in the strict and general modes"""
+    import os
+    rng = np.random.default_rng(402)
+    n = 70
+    P, Q = _points(oracle, rng, n)
+    g = eng.pairing_batch(P, Q)
+    g[3] = oracle.fq12_one()
+    sv = _scalars(rng, n); sv[:6] = [0, 1, M.R_ORD - 1, M.R_ORD - 2, (1 << 253) + 11, 6 * M.U * M.U % M.R_ORD]
+    s = _fr(oracle, sv)
+    want = np.stack([oracle.gt_pow(g[i], s[i]) for i in range(n)])
+    old = os.environ.get("BN254_GT_POW_MODE")
+    try:
+        for mode in ("0", "2", "1"):
+            os.environ["BN254_GT_POW_MODE"] = mode
+            assert np.array_equal(eng.gt_pow_batch(g, s), want), mode
+        raw = oracle.miller_only(P[0], Q[0])
+        # f^(q^6 - 1) then ^(q^2 + 1): cyclotomic, but of order dividing (q^4 - q^2 + 1), not r
+        cyc = oracle.fq12_final_exp_first_chunk(raw)              # fq12.rs:41-52
+        batch = np.tile(cyc, (4, 1))
+        for mode in ("2", "1"):
+            os.environ["BN254_GT_POW_MODE"] = mode
+            got = eng.gt_pow_batch(batch, s[6:10])
+            for i in range(4):
+                assert np.array_equal(got[i], oracle.gt_pow(cyc, s[6 + i])), (mode, i)
+    finally:
+        if old is None: os.environ.pop("BN254_GT_POW_MODE", None)
+        else: os.environ["BN254_GT_POW_MODE"] = old

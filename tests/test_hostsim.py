@@ -366,6 +366,10 @@ def test_gt_pow_cyclotomic_chain(oracle, hs):
     for kv in [0, 1, 2, 7, 8, 9, 15, 16, 0x88888888, M.R_ORD - 1, M.R_ORD - 2, (1 << 253) + 5] + [int.from_bytes(rng.bytes(40), "little") % M.R_ORD for _ in range(4)]:
         ke = oracle.fp_from_int(FR, kv)
         assert np.array_equal(hs.call("hsb_gt_pow_cyclotomic", g, ke, out_words=96), oracle.gt_pow(g, ke)), kv
+        # the default chain: Frobenius decomposition (exact on order-r elements, which is what the reference's Gt holds)
+        assert np.array_equal(hs.call("hsb_gt_pow_gls", g, ke, out_words=96), oracle.gt_pow(g, ke)), kv
+    one = oracle.fq12_one()
+    assert np.array_equal(hs.call("hsb_gt_pow_gls", one, oracle.fp_from_int(FR, M.R_ORD - 3), out_words=96), one)
     ke = _fr(oracle, rng)
     assert np.array_equal(hs.call("hsb_gt_pow_auto", g, ke, out_words=96), oracle.gt_pow(g, ke))
     assert np.array_equal(hs.call("hsb_gt_pow_auto", rnd, ke, out_words=96), oracle.gt_pow(rnd, ke))
