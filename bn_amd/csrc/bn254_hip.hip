@@ -248,11 +248,12 @@ size_t bn_sub_launch(const bn254_ctx *c, size_t n) {
 }
 
 // Up to this many pairings (or Miller loops whose value only meets a final exponentiation) per call run ONE PER WAVE - the whole
-// pairing as a program of the wave machine, ~1.2 ms - instead of one per lane pair (2.3 + 0.6 ms whatever the count).  The role
-// tables and the register file take 52 KB of LDS per pairing: three per CU.  BN254_WAVE_PAIRING_MAX overrides.
+// pairing as a program of the wave machine - instead of one per lane pair (4.2 ms whatever the count).  A workgroup needs 11.5 KB
+// of LDS, thirteen fit a CU: 1.05 ms up to 1024 pairings (one wave per SIMD), 1.5 ms at 2048, 2.1 ms at 3072, 3.2 ms at 4096,
+// 4.4 ms at 6144 where the lane-pair kernels are level (profiles/r03s_wave_roles_ab.txt).  BN254_WAVE_PAIRING_MAX overrides.
 size_t bn_wave_pairing_max() {
     const char *e = getenv("BN254_WAVE_PAIRING_MAX");
-    return e ? (size_t)atol(e) : 2048;
+    return e ? (size_t)atol(e) : 5120;
 }
 // naf: the value is only consumed by a final exponentiation, so the shorter NAF schedule may be used (pairing.hpp)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf) {
@@ -275,11 +276,12 @@ int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t
     hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
-// Up to this many final exponentiations per call run ONE PER WAVE (bn254_kernels_w.hip: 0.6 ms up to 1024 - one wave per SIMD -
-// while a lane pair needs 2.05 ms for its serial chain); beyond ~2700 the lane-pair kernel's throughput wins (profiles/r03a_*).  BN254_WAVE_FE_MAX overrides.
+// Up to this many final exponentiations per call run ONE PER WAVE (bn254_kernels_w.hip: 0.48 ms up to 1024 - one wave per SIMD -,
+// 0.69 ms at 2048, 1.4 ms at 4096, while a lane pair needs 1.97 ms for its serial chain whatever the count; level at ~6000:
+// profiles/r03s_wave_roles_ab.txt).  BN254_WAVE_FE_MAX overrides.
 size_t bn_wave_fe_max() {
     const char *e = getenv("BN254_WAVE_FE_MAX");
-    return e ? (size_t)atol(e) : 2048;
+    return e ? (size_t)atol(e) : 5120;
 }
 // table: the caller's own table buffer (pipelined path: one per chunk in flight) or NULL for the context's (under a BnScratchGuard)
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table) {

@@ -3,10 +3,12 @@
 // shootout/main.rs:11-16), the combination of the per-GPU partial products, and batches too small to fill the chip - where the
 // lane-pair kernels of bn254_kernels_b.hip take 2.1 ms per final exponentiation whatever the batch size.
 //
-// One workgroup = one wave = one Fq12.  LDS: the register file of the machine (5 pages x 9 limbs x 64 slots = 11.5 KB) and a copy
-// of the role tables (52 phases x 32 pairs x 24 B = 40 KB) - every role fetch of the ~1130 phases of a pairing is an LDS read, not
-// a global one.  A wave has a SIMD to itself (occupancy is not the point here: the chain is serial), so the leaves
-// may use the whole register file.
+// One workgroup = one wave = one Fq12.  LDS: the register file of the machine (5 pages x 9 limbs x 64 slots = 11.5 KB), nothing
+// else - the role tables (55 phases x 32 pairs x 24 B = 42 KB, the same for every wave) stay in global memory: L2 hits, and the
+// interpreter asks for the next phase's role while this phase computes.  A copy per workgroup in LDS was no faster for one pairing
+// (1.045 against 1.052 ms) and held a CU to three workgroups, one wave per SIMD - and a lone wave leaves half of the multiplier idle
+// (it issues a v_mad_u64_u32 every ~8 cycles whatever the dependencies: profiles/r03s_ubench_chain.txt).  With 11.5 KB a CU takes
+// thirteen: 1024 pairings cost what one does, 2048 1.5 ms instead of 3.2 ms (profiles/r03s_wave_roles_ab.txt).
 #define BN_COARSE __device__ __forceinline__
 #define BN_LEAF_MUL __device__ __forceinline__
 #define BN_LEAF_RED __device__ __forceinline__
@@ -23,7 +25,6 @@ constexpr int ROLE_DWORDS_PER_PHASE = 32 * (int)(sizeof(Role) / 4);
 struct WaveDev {
     using T = Fe;
     char *regs;              // register file in LDS, already offset to this lane's component (even lane c0, odd lane c1)
-    const Role *roles;       // LDS copy of ROLES
     __device__ __forceinline__ Fe ld(uint32_t off) const {
         Fe v;
 #pragma unroll
@@ -34,28 +35,17 @@ struct WaveDev {
 #pragma unroll
         for (int i = 0; i < 9; ++i) *(uint32_t *)(regs + off + 256u * i) = v.l[i];
     }
-    __device__ __forceinline__ Role role(uint32_t phase) const { return roles[phase * 32u + (threadIdx.x >> 1)]; }
+    __device__ __forceinline__ Role role(uint32_t phase) const { return ((const Role *)&ROLES[0][0])[phase * 32u + (threadIdx.x >> 1)]; }
     __device__ __forceinline__ int pair() const { return (int)(threadIdx.x >> 1); }
     __device__ __forceinline__ void sync() const { __syncthreads(); }        // single-wave workgroup: a wave-level barrier
 };
+struct WaveLds { uint32_t regs[NPAGES * PAGE_DW]; };
 
-// NP = number of role tables resident: NPHASES_FE for the programs without a Miller loop (20 KB: a workgroup takes 32 KB of LDS, four
-// fit a CU - 1024 exponentiations in flight on the chip), NPHASES for the whole pairing (52 KB: three per CU)
-template <int NP>
-struct WaveLdsT {
-    uint32_t regs[NPAGES * PAGE_DW];
-    uint32_t roles[NP * ROLE_DWORDS_PER_PHASE];
-};
-typedef WaveLdsT<NPHASES_FE> WaveLds;
-
-// role tables -> LDS, register file zeroed, Frobenius multipliers (and the Miller program's constants) into their registers
-template <int NP>
-__device__ __forceinline__ WaveDev wave_init(WaveLdsT<NP> &l) {
-    const uint32_t *src = (const uint32_t *)&ROLES[0][0];
-    for (int i = threadIdx.x; i < NP * ROLE_DWORDS_PER_PHASE; i += 64) l.roles[i] = src[i];
+// register file zeroed, Frobenius multipliers (and the Miller program's constants) into their registers
+__device__ __forceinline__ WaveDev wave_init(WaveLds &l) {
     for (int i = threadIdx.x; i < NPAGES * PAGE_DW; i += 64) l.regs[i] = 0;
     __syncthreads();
-    WaveDev w = {(char *)l.regs + 4u * (threadIdx.x & 1u), (const Role *)l.roles};
+    WaveDev w = {(char *)l.regs + 4u * (threadIdx.x & 1u)};
     const uint32_t j = threadIdx.x >> 1;
     if (j < 18) {
         Fe c;
@@ -87,7 +77,7 @@ __global__ void __launch_bounds__(64) bn254_final_exp_W(const uint32_t *f_in, ui
 // the isomorphic curve (six phases per doubling step, seven per addition step), the final exponentiation.  ~1.2 ms for one pairing
 // where the lane-pair kernels need 2.3 + 0.6 ms; one workgroup per pairing, for batches that cannot fill the chip anyway.
 __global__ void __launch_bounds__(64) bn254_pairing_W(const uint32_t *g1, const uint32_t *g2, uint32_t *out, int final_exp) {
-    __shared__ WaveLdsT<NPHASES> lds;
+    __shared__ WaveLds lds;
     WaveDev w = wave_init(lds);
     const uint32_t *w1 = g1 + 24u * blockIdx.x, *w2 = g2 + 48u * blockIdx.x;
     uint32_t zp = 0, zq = 0;
@@ -146,10 +136,9 @@ __global__ void __launch_bounds__(64) bn254_wave_ubench_W(int which, int iters, 
 //       agent-scope acquire -> plain loads (cdna_hip_programming.md G16: per-XCD L2s are not coherent with each other).
 // `counters` (one u32 per tree node, < gridDim.x of them) must be zero at launch; `scratch` holds 108 dwords per node.
 typedef Fq2B<Fe> F2;
-struct WaveDevR {                                   // the machine with only the product's three role tables resident
+struct WaveDevR {                                   // the machine on a register file of two pages (the product's operands and temporaries)
     using T = Fe;
     char *regs;
-    const Role *roles;
     __device__ __forceinline__ Fe ld(uint32_t off) const {
         Fe v;
 #pragma unroll
@@ -160,9 +149,7 @@ struct WaveDevR {                                   // the machine with only the
 #pragma unroll
         for (int i = 0; i < 9; ++i) *(uint32_t *)(regs + off + 256u * i) = v.l[i];
     }
-    __device__ __forceinline__ Role role(uint32_t phase) const {                        // (the END word names phase 0: its role is fetched ahead, never used)
-        return roles[(phase < (uint32_t)MULR_PHASE0 ? 0u : phase - MULR_PHASE0) * 32u + (threadIdx.x >> 1)];
-    }
+    __device__ __forceinline__ Role role(uint32_t phase) const { return ((const Role *)&ROLES[0][0])[phase * 32u + (threadIdx.x >> 1)]; }
     __device__ __forceinline__ int pair() const { return (int)(threadIdx.x >> 1); }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 };
@@ -187,14 +174,10 @@ __device__ __forceinline__ Fq12<F2> xchg_f12(const Fq12<F2> &f, int lane_xor) {
 }
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bn254_gt_reduce_W(const uint32_t *in, uint32_t n, uint32_t chunk, uint32_t per_wave, uint32_t bfly, uint32_t *scratch, uint32_t *counters, uint32_t *out) {
-    __shared__ struct { uint32_t regs[2 * PAGE_DW]; uint32_t roles[3 * 32 * 6]; } lds;
-    {
-        const uint32_t *src = (const uint32_t *)&ROLES[MULR_PHASE0][0];
-        for (int i = threadIdx.x; i < 3 * 32 * 6; i += 64) lds.roles[i] = src[i];
-        for (int i = threadIdx.x; i < 2 * PAGE_DW; i += 64) lds.regs[i] = 0;
-    }
+    __shared__ struct { uint32_t regs[2 * PAGE_DW]; } lds;
+    for (int i = threadIdx.x; i < 2 * PAGE_DW; i += 64) lds.regs[i] = 0;
     __syncthreads();
-    WaveDevR w = {(char *)lds.regs + 4u * (threadIdx.x & 1u), (const Role *)lds.roles};
+    WaveDevR w = {(char *)lds.regs + 4u * (threadIdx.x & 1u)};
     const uint32_t pair = threadIdx.x >> 1;
     // (a) this lane pair's group
     const uint32_t groups = (n + chunk - 1) / chunk, g = blockIdx.x * per_wave + pair;

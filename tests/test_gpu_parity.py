@@ -623,7 +623,7 @@ def test_bench_multi_rank_control_flow(tmp_path):
     env = dict(os.environ, BN254_BENCH_SHARE_GPU="1", BN254_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096"],
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8192"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -887,6 +887,7 @@ def test_shared_accumulator_miller_kernels(oracle, m):
     P[7] = oracle.g1_zero(); Q[4000] = oracle.g2_zero(); P[n - 1] = oracle.g1_zero()
     e = bn_amd.Engine(0)
     os.environ["BN254_MILLER_SHARED"] = "1"
+    os.environ["BN254_WAVE_PAIRING_MAX"] = "0"                   # 5003 pairs would otherwise run one per wave (bn_wave_pairing_max)
     try:
         plain = e.pairing_product(P, Q)
         os.environ["BN254_MILLER_SHARED"] = str(m)
@@ -894,9 +895,8 @@ def test_shared_accumulator_miller_kernels(oracle, m):
         shared = e.pairing_product(P, Q)
         assert e.kernel_stats("miller_shared")[1] >= 1 and e.kernel_stats("miller")[1] == 0
         e.profile(False)
-        small = e.pairing_product(P[:2 * m + 1], Q[:2 * m + 1]) if False else None
     finally:
-        os.environ.pop("BN254_MILLER_SHARED", None)
+        os.environ.pop("BN254_MILLER_SHARED", None); os.environ.pop("BN254_WAVE_PAIRING_MAX", None)
     assert np.array_equal(plain, shared)
     assert np.array_equal(shared, oracle.pairing_product(P, Q))
     e.close()

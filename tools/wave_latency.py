@@ -26,7 +26,7 @@ P, Q = D.synthetic_points(te, 0, nmax)
 f = te.empty(nmax, 48)
 te.e.miller_batch_dev(P.data_ptr(), Q.data_ptr(), f.data_ptr(), nmax, te._stream())
 out = te.empty(nmax, 48)
-for n in (1, 8, 64, 256, 512, 1024, 2048, 4096, 8192):
+for n in (1, 8, 64, 256, 1024, 2048, 4096, 6144, 8192):
     row = {}
     for name, thr in (("wave", 1 << 20), ("lane_pair", 0)):
         os.environ["BN254_WAVE_FE_MAX"] = str(thr)
@@ -42,7 +42,7 @@ for m in (1, 2, 8, 64):
 res["pairing_product_ms"] = {n: timed(lambda: D.pairing_product_sharded(te, P[:n], Q[:n]), reps=5, warm=2) for n in (1, 4, 1 << 15, 1 << 18)}
 for name, thr in (("wave", 1 << 20), ("lane_pair", 0)):
     os.environ["BN254_WAVE_PAIRING_MAX"] = str(thr); os.environ["BN254_WAVE_FE_MAX"] = str(1024 if thr else 0)
-    res.setdefault("pairing_batch_ms", {})[name] = {n: timed(lambda: te.e.pairing_batch_dev(P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 4, 64, 256, 512, 768, 1024, 2048)}
+    res.setdefault("pairing_batch_ms", {})[name] = {n: timed(lambda: te.e.pairing_batch_dev(P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 4, 64, 256, 768, 1024, 2048, 3072, 4096, 6144)}
 os.environ.pop("BN254_WAVE_PAIRING_MAX"); os.environ.pop("BN254_WAVE_FE_MAX")
 res["miller_only_ms"] = {n: timed(lambda: te.e.miller_batch_dev(P.data_ptr(), Q.data_ptr(), f.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 1 << 15, 1 << 16)}
 # by-value pairing through the host-buffer API (what `pairing(p, q)` of lib.rs:181-183 costs a caller)
