@@ -1,7 +1,7 @@
 // The WAVE-COOPERATIVE Fq12 machine: one Fq12 operation spread over the 32 lane pairs of a wave, for the latency-bound tails of
 // the path - the single final exponentiation of a multi-pairing (fq12.rs:41-88 after the fold of shootout/main.rs:11-16), the last
 // levels of its Fq12 product tree, and batches too small to fill the chip.  In the lane-pair kernels (bn254_kernels_b.hip) a
-// final exponentiation is a 2.1 ms serial chain on TWO lanes whatever the batch size; here every Fq2 product of an Fq12 product
+// final exponentiation is a 2.0 ms serial chain on TWO lanes whatever the batch size; here every Fq2 product of an Fq12 product
 // (18, Karatsuba) or of a Granger-Scott squaring (9 Fq2 squarings) runs on its own lane pair at the same time.
 //
 // Data: a register file of Fq2 values in LDS, [page][limb][slot]: a register = two adjacent slots (even lane: c0, odd lane: c1),
@@ -119,8 +119,8 @@ BN_FN void w_inv(W &w, const Role &r, uint32_t base) {
 // runs a program (wave_tables.hpp PROG_*): one phase per entry, a wave-level barrier after each
 template <class W>
 BN_FN void w_run(W &w, const uint32_t *prog) {
-    // the role of the NEXT phase is fetched while this one computes (a role read is an LDS round trip in front of the gathers,
-    // which are another: at one wave per SIMD nothing else hides them)
+    // the role of the NEXT phase is fetched while this one computes: the tables live in global memory (an L2 hit of a few hundred
+    // nanoseconds, a third of a phase), and the gathers that need the role are an LDS round trip of their own
     uint32_t e = prog[0];
     Role r = w.role((e >> 4) & 255u);
 #pragma unroll 1

@@ -719,7 +719,7 @@ def emit(B, progs, path):
     o.append("BN254_CONSTANT uint32_t MCONST[%d][2][9] = {\n    %s};" % (len(mc), ",\n    ".join("{%s, %s}" % (mont_limbs(c[0]), mont_limbs(c[1])) for _, c in mc)))
     o.append("constexpr int OFF_IN_P = %d, OFF_IN_Q = %d, OFF_C_ONE = %d;      // inputs of the Miller program: P as (x, 0), (y, 0), (z, 0); Q; the constant 1" % (off(IN_PX), off(IN_QX), off(C_ONE)))
     assert [IN_PY, IN_PZ] == [IN_PX + 1, IN_PX + 2] and [IN_QY, IN_QZ] == [IN_QX + 1, IN_QX + 2] and (IN_PX >> 5) == (IN_PZ >> 5) and (IN_QX >> 5) == (IN_QZ >> 5)
-    o.append("constexpr int NPHASES = %d, NPHASES_FE = %d, MULR_PHASE0 = %d;      // NPHASES_FE: tables 0 .. of the programs without a Miller loop" % (len(B.phases), B.nfe, B.mulr0))
+    o.append("constexpr int NPHASES = %d, NPHASES_FE = %d, MULR_PHASE0 = %d;      // tables 0 .. NPHASES_FE-1 serve the programs without a Miller loop, MULR_PHASE0 .. +2 the product of the tree" % (len(B.phases), B.nfe, B.mulr0))
     o.append("// one role per lane pair and phase: 10 source indices (BYTE offsets of even slots, limb 0; REL = relative to the entry's base), dst, flags")
     o.append("struct Role { uint16_t src[10]; uint16_t dst; uint16_t flags; };")
     o.append("BN254_CONSTANT Role ROLES[NPHASES][32] = {")
