@@ -34,7 +34,7 @@
  *
  * Sizes: n is limited by device memory only.  Batches are cut internally into sub-launches of at most one machine round, and the
  * context-owned tables (final exponentiation: 4 KB, Gt::pow: 14.8 KB per pairing) are sized for ONE round - 264 MB / 970 MB on an
- * MI355X whatever n is.  Up to 2048 pairings or final exponentiations per call (the tail of every multi-pairing: exactly one) run one per
+ * MI355X whatever n is.  Up to 5120 pairings or final exponentiations per call (the tail of every multi-pairing: exactly one) run one per
  * WAVE instead of one per lane pair: a pairing in 1.0 ms instead of 4.2 ms, a final exponentiation in 0.5 ms instead of 2.0 ms.
  *
  * Ownership: the caller owns every buffer passed in; the library owns device memory and streams inside a context and keeps
