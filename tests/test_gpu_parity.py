@@ -321,9 +321,15 @@ def test_miller_values_equal_reference_schedule(oracle, mapping):
 def test_golden_fixtures_on_gpu(eng, goldens):
     """the committed fixtures (tests/golden/pairing_goldens.npz: edge scalars 1, 2, r-1, ... then seeded random) through every
     host-buffer entry point - this test does not touch the oracle at all"""
+    import os
     g = goldens
     n = g["k1"].shape[0]
-    assert np.array_equal(eng.pairing_batch(g["g1"], g["g2"]), g["gt"])
+    assert np.array_equal(eng.pairing_batch(g["g1"], g["g2"]), g["gt"])                    # a batch this small: one pairing per wave
+    os.environ["BN254_WAVE_PAIRING_MAX"] = "0"; os.environ["BN254_WAVE_FE_MAX"] = "0"
+    try:
+        assert np.array_equal(eng.pairing_batch(g["g1"], g["g2"]), g["gt"])                # and through the lane-pair kernels
+    finally:
+        os.environ.pop("BN254_WAVE_PAIRING_MAX"); os.environ.pop("BN254_WAVE_FE_MAX")
     one1 = np.tile(g["g1"][0], (n, 1)); one2 = np.tile(g["g2"][10], (n, 1))          # scalars1[0] == scalars2[10] == 1: the generators
     assert int(g["scalars1"][0]) == 1 and int(g["scalars2"][10]) == 1
     assert np.array_equal(eng.g1_mul_batch(one1, g["k1"]), g["g1"]) and np.array_equal(eng.g2_mul_batch(one2, g["k2"]), g["g2"])
