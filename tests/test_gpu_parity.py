@@ -1003,6 +1003,17 @@ def test_gt_pow_modes(oracle, eng):
         for mode in ("0", "2", "1"):
             os.environ["BN254_GT_POW_MODE"] = mode
             assert np.array_equal(eng.gt_pow_batch(g, s), want), mode
+        # 20 000 pairing values ^ distinct random scalars: the Frobenius chain against the one-dimensional one, all of them
+        import torch
+        from bn_amd import distributed as D
+        te = D.TorchEngine(eng, torch.device("cuda", 0))
+        big = 20000
+        Pd, Qd = D.synthetic_points(te, 777, 777 + big)
+        gd = te.pairing_batch(Pd, Qd)
+        kd = D.synthetic_scalars_device(te, 1 << 25, (1 << 25) + big, 0)
+        os.environ["BN254_GT_POW_MODE"] = "0"; a = te.gt_pow(gd, kd); torch.cuda.synchronize()
+        os.environ["BN254_GT_POW_MODE"] = "2"; b = te.gt_pow(gd, kd); torch.cuda.synchronize()
+        assert torch.equal(a, b)
         raw = oracle.miller_only(P[0], Q[0])
         # f^(q^6 - 1) then ^(q^2 + 1): cyclotomic, but of order dividing (q^4 - q^2 + 1), not r
         cyc = oracle.fq12_final_exp_first_chunk(raw)              # fq12.rs:41-52
