@@ -515,9 +515,9 @@ BN_FN Fq12<F2> gt_pow_gls(const Fq12<F2> &base, const uint32_t *k_raw, Tbl &tbl)
 #pragma unroll 1
     for (int e = 1; e <= 8; ++e) {
         const Fq12<F2> v = {tbl.c0(e), tbl.c1(e)};
-        tbl.put(8 + e, f12_frobenius<1>(v));
-        tbl.put(16 + e, f12_frobenius<2>(v));
-        tbl.put(24 + e, f12_frobenius<3>(v));
+        tbl.put(8 + e, f12_frobenius_one<1>(v));
+        tbl.put(16 + e, f12_frobenius_one<2>(v));
+        tbl.put(24 + e, f12_frobenius_one<3>(v));
     }
     Fq12<F2> res = f12_one<F2>();
 #pragma unroll 1

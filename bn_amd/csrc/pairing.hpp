@@ -506,8 +506,8 @@ BN_FN Fq12<F2> gt_pow_cyclotomic(const Fq12<F2> &base, const uint32_t *k_raw, Tb
 // a in the cyclotomic subgroup of Fq12, i.e. a^(q^4 - q^2 + 1) = 1  <=>  frob^4(a) * a == frob^2(a)   (two Frobenius maps, one product)
 template <class F2>
 BN_FN bool gt_is_cyclotomic(const Fq12<F2> &a) {
-    const Fq12<F2> a2 = f12_frobenius<2>(a);
-    const Fq12<F2> a4 = f12_frobenius<2>(a2);
+    const Fq12<F2> a2 = f12_frobenius_one<2>(a);
+    const Fq12<F2> a4 = f12_frobenius_one<2>(a2);
     const Fq12<F2> l = f12_mul_o(a4, a);
     return f2_is_zero(f2_sub<1, 4>(l.c0.c0, a2.c0.c0)) & f2_is_zero(f2_sub<1, 4>(l.c0.c1, a2.c0.c1)) & f2_is_zero(f2_sub<1, 4>(l.c0.c2, a2.c0.c2)) &
            f2_is_zero(f2_sub<1, 4>(l.c1.c0, a2.c1.c0)) & f2_is_zero(f2_sub<1, 4>(l.c1.c1, a2.c1.c1)) & f2_is_zero(f2_sub<1, 4>(l.c1.c2, a2.c1.c2));

@@ -158,6 +158,23 @@ BN_OUTER Fq12<F2> f12_frobenius(const Fq12<F2> &a) {
     return {f6_frobenius<P>(a.c0), f6_scale(c1, g)};
 }
 
+// The same map with ONE constant per coefficient: the reference maps c1 through the Fq6 map and then scales it by FROB12_C1 - seven
+// Fq2 products; with the products of the constants tabulated it is five, and for P = 2 all five lie in Fq - a scaling of each
+// component.  Same field elements, hence the same bytes.  Used by Gt::pow (24 maps per element).  NOT by the final-exponentiation
+// kernel: replacing its four maps moved the register allocation of that kernel's hot loops (15-22 spills per step appeared in the
+// squaring and product blocks, 3.40 -> 3.96 ms: profiles/r03y_ab_frobenius.txt) - the compiler allocates across these calls.
+template <int P, class F2>
+BN_OUTER Fq12<F2> f12_frobenius_one(const Fq12<F2> &a) {
+    if constexpr (P == 2) {
+        auto sc = [&](const F2 &x, int i) { return f2_scale(x, f2_scalar_const(F2P, k::FROB2_S[i])); };
+        return {{a.c0.c0, sc(a.c0.c1, 0), sc(a.c0.c2, 1)}, {sc(a.c1.c0, 2), sc(a.c1.c1, 3), sc(a.c1.c2, 4)}};
+    } else {
+        return {f6_frobenius<P>(a.c0),
+                {f2_mul_const(f2_conj_lazy(a.c1.c0), k::FROB12_C1[P]), f2_mul_const(f2_conj_lazy(a.c1.c1), k::FROB12_C1C1[P]),
+                 f2_mul_const(f2_conj_lazy(a.c1.c2), k::FROB12_C1C2[P])}};
+    }
+}
+
 // fq12.rs:107-176: f * (x0 + x2 v^2 + x4 v w), 13 Fq2 products; (ell_0, ell_vw, ell_vv) -> (x0, x4, x2) as in the reference.
 // Same 13 products and the same sums as the reference, but ordered so that every product dies as early as possible (each
 // output coefficient is finished as soon as its inputs exist): the live set stays inside the 256-VGPR budget of a wave that
