@@ -166,6 +166,20 @@ def test_wave_pairing_matches_oracle_and_lane_pair_kernels(oracle, te):
     assert torch.equal(a, b)
     Pn = Pd[:8].cpu().numpy().view(np.uint64); Qn = Qd[:8].cpu().numpy().view(np.uint64)
     assert np.array_equal(a[:8].cpu().numpy().view(np.uint64), oracle.pairing_batch(Pn, Qn))
+    # either side of the host's default threshold (bn_wave_pairing_max = 5120: thirteen workgroups per CU, several waves per SIMD)
+    big = 5121
+    Pb, Qb = D.synthetic_points(te, 20000, 20000 + big)
+    e2 = te.e
+    e2.profile(True); e2.profile_reset()
+    w = te.pairing_batch(Pb[:5120].contiguous(), Qb[:5120].contiguous()); torch.cuda.synchronize()
+    assert e2.kernel_stats("pairing_wave")[1] == 1 and e2.kernel_stats("miller")[1] == 0
+    e2.profile_reset()
+    l = te.pairing_batch(Pb, Qb); torch.cuda.synchronize()
+    assert e2.kernel_stats("pairing_wave")[1] == 0 and e2.kernel_stats("miller")[1] == 1
+    e2.profile(False)
+    assert torch.equal(w, l[:5120])
+    with _env(BN254_WAVE_PAIRING_MAX=1 << 20, BN254_WAVE_FE_MAX=1 << 20):
+        assert torch.equal(te.pairing_batch(Pb, Qb), l)
 
 
 def test_single_pairing_latency_path(oracle, te):
