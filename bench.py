@@ -75,6 +75,10 @@ def _max_over_ranks(dist, dev, elapsed):
 
 def timed_steps(dist, dev, fn, steps, warmup):
     """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks"""
+    # a barrier BEFORE the warm-up as well: the first collective of a process group takes tens of milliseconds (lazy set-up), the
+    # GPU idles meanwhile, and after ~5 ms of idling the next few steps run up to 20 % slower (clock ramp: 8.7, 8.1, 7.6, 7.4 ms
+    # instead of 7.2) - with the set-up paid here the barrier that opens the timed region costs 30 us and nothing ramps
+    _barrier(dist, dev)
     for _ in range(warmup):
         fn()
     _barrier(dist, dev)
