@@ -146,17 +146,29 @@ def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=No
 
 
 def cpu_baseline(batch_p, batch_q):
-    """reference-faithful CPU port on all host cores, bounded sample (~20 s of CPU work)"""
+    """reference-faithful CPU port on all host cores, bounded sample (~20 s of CPU work), and beside it the same schedule with the
+    CPU's native 64 x 64 -> 128 multiply (`native128`): the reference builds every 64-bit MAC from 32-bit halves
+    (src/arith.rs:441-478), which handicaps it on a CPU that has the wide multiplier - both figures are the same 36 938-product chain"""
     sys.path.insert(0, str(ROOT / "oracle"))
     import bn_oracle
+    import numpy as np
     bn_oracle.build()
-    o = bn_oracle.Oracle()
     cores = bn_oracle.usable_cpus()          # respects a cgroup CPU quota (the GPU box grants 16 of its 256 hardware threads)
-    t0 = time.perf_counter(); o.pairing_batch(batch_p[:8], batch_q[:8], nthreads=1); t1 = (time.perf_counter() - t0) / 8
-    n = int(min(len(batch_p), max(cores, min(4096, 20.0 / t1))))   # ~20 s of single-thread work
-    t0 = time.perf_counter(); o.pairing_batch(batch_p[:n], batch_q[:n], nthreads=cores); dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "pairings/s", "cores": cores, "kind": "port", "one_thread_ms_per_pairing": t1 * 1e3,
-            "sample": f"{n} pairings of the same synthetic batch on {cores} threads ({dt:.2f} s wall); 1 thread: {t1 * 1e3:.2f} ms/pairing"}
+
+    def run(o, share):
+        t0 = time.perf_counter(); ref = o.pairing_batch(batch_p[:8], batch_q[:8], nthreads=1); t1 = (time.perf_counter() - t0) / 8
+        n = int(min(len(batch_p), max(cores, min(4096, share / t1))))   # ~`share` seconds of single-thread work
+        t0 = time.perf_counter(); o.pairing_batch(batch_p[:n], batch_q[:n], nthreads=cores); dt = time.perf_counter() - t0
+        return n, dt, t1, ref
+    n, dt, t1, ref = run(bn_oracle.Oracle(), 20.0)
+    out = {"value": n / dt, "unit": "pairings/s", "cores": cores, "kind": "port", "one_thread_ms_per_pairing": t1 * 1e3,
+           "sample": f"{n} pairings of the same synthetic batch on {cores} threads ({dt:.2f} s wall); 1 thread: {t1 * 1e3:.2f} ms/pairing"}
+    n2, dt2, t2, ref2 = run(bn_oracle.Oracle(native128=True), 10.0)
+    out["native128"] = {"value": n2 / dt2, "unit": "pairings/s", "cores": cores, "one_thread_ms_per_pairing": t2 * 1e3,
+                        "same_bytes_as_port": bool(np.array_equal(ref, ref2)),
+                        "what": "the same chain built with -DBNO_NATIVE128 (unsigned __int128 MACs instead of the reference's 32-bit halves): "
+                                f"{n2} pairings on {cores} threads ({dt2:.2f} s wall)"}
+    return out
 
 
 def host_api_rate(gpu_index, Pn, Qn, reps=5):

@@ -252,7 +252,13 @@ struct ExpTableMem {
     uint32_t stride;         // lanes in the launch
     // 32-bit element index (the table is far below 2^32 x 16 bytes): with a per-lane slot (Gt::pow's digit) the address is ONE VGPR
     // offset on the scalar base instead of a 64-bit pointer per access
+#ifdef BN_AB_ALIAS_SCRATCH
+    // TIMING EXPERIMENT ONLY (wrong results): every slot of every lane aliases slot 0 of one of 8192 lanes - a 1.8 MB footprint that
+    // stays in the L2 -, so the kernel runs the same instruction stream with (almost) no HBM traffic: what the table's traffic costs
+    __device__ __forceinline__ uint32_t row(int, int half) const { return (uint32_t)(half * 7) * stride + (lane & 8191u); }
+#else
     __device__ __forceinline__ uint32_t row(int slot, int half) const { return (uint32_t)((slot * 2 + half) * 7) * stride + lane; }
+#endif
     __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
         const uint32_t r = row(slot, half);
         uint32_t w[28];
@@ -302,7 +308,11 @@ struct MillerStateMem {
     uint4 *base;             // wave-uniform
     uint32_t lane, stride;   // this lane's column, lanes in the launch
     uint32_t infmask;        // bit i: pair i is (treated as) infinite
+#ifdef BN_AB_ALIAS_SCRATCH
+    __device__ __forceinline__ uint32_t row(int, int g) const { return (uint32_t)g * stride + (lane & 8191u); }      // timing experiment, see ExpTableMem
+#else
     __device__ __forceinline__ uint32_t row(int i, int g) const { return (uint32_t)(i * 17 + g) * stride + lane; }
+#endif
     template <int N, int G0>
     __device__ __forceinline__ void st_n(int i, const Fe *v) const {             // N field elements -> ceil(9N/4) groups from group G0
         uint32_t w[((9 * N + 3) / 4) * 4];
@@ -498,7 +508,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 #ifdef BN_POW_TABLE_ENTRY_MAJOR
     PowTable tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
 #else
+#ifdef BN_AB_ALIAS_SCRATCH
+    PowTable tbl = {(uint4 *)table + (size_t)(t & 63u) * (POW_TABLE_DWORDS_PER_LANE / 4)};       // timing experiment: 64 lanes' tables (475 KB) for everybody
+#else
     PowTable tbl = {(uint4 *)table + (size_t)t * (POW_TABLE_DWORDS_PER_LANE / 4)};
+#endif
 #endif
     const Fq12<F2> base = f12_load<F2>(a + 96u * pair);
     Fq12<F2> res;

@@ -71,7 +71,13 @@ __device__ __forceinline__ Jac<F> run_chain(const Jac<F> &p, const uint32_t *km,
     for (int i = 0; i < 8; ++i) kw[i] = km[i];
     fr_from_mont(kw, raw);
     if constexpr (NORMALIZE) {
+#ifdef BN_AB_ALIAS_SCRATCH
+        // TIMING EXPERIMENT ONLY (wrong results): all waves use the tables of the first 64 lanes (40 KB: cache resident) - the same
+        // instruction stream without the HBM traffic of 640 B of table per lane
+        AffTableMem<F> tab = {table + (size_t)(lane & 63u) * AFF_LANE_U4};
+#else
         AffTableMem<F> tab = {table + (size_t)lane * AFF_LANE_U4};
+#endif
         if constexpr (std::is_same<F, FqField>::value) return jac_normalize<F>(scalar_mul_glv(p, raw, tab));      // G1: GLV + signed windows
         else return jac_normalize<F>(scalar_mul_gls<F2>(p, raw, tab));                                             // G2: GLS, four signed-window streams
     } else {

@@ -63,9 +63,40 @@ BN_COARSE Jac<F> jac_double(const Jac<F> &p) {
     { T yz = F::mul(p.y, p.z); r.z = F::sum(yz, yz); }
     return r;
 }
-// out-of-line copy for the never-taken equal-points branch below (keeps the inlined builds small)
+// out-of-line copy for the never-taken equal-points branch below (keeps the inlined builds small).  On the GPU the operands travel
+// BY VALUE as <9 x i32> vectors (fe.hpp, "leaf calling convention"): a Jac handed over by reference has to live in private memory,
+// and the compiler then stores the running point there after EVERY addition of a scalar-multiplication chain, branch taken or not
+// - 27 dwords x 99 steps = 10.7 KB of HBM writes per G1 multiplication (round 3: profiles/r03z_pmc_side.txt, WRITE_SIZE 2.5 GB per
+// 2^18).  Only the result comes back through memory, inside the cold block.
 template <class F>
-BN_OUTER Jac<F> jac_double_cold(const Jac<F> &p) { return jac_double(p); }
+BN_OUTER Jac<F> jac_double_cold_ref(const Jac<F> &p) { return jac_double(p); }
+#if defined(BN_HOSTSIM)
+template <class F>
+BN_FN Jac<F> jac_double_cold(const Jac<F> &p) { return jac_double_cold_ref(p); }
+#else
+BN_FN u32x9 jac_coord_vec(const Fe &a) { return bn_tov(a); }
+template <class T> BN_FN u32x9 jac_coord_vec(const Fq2B<T> &a) { return bn_tov(a.v); }
+BN_FN u32x9 jac_coord_vec(const Fq2A &a) { return bn_tov(a.c0); }                 // never used: two-Fe coordinates take the by-reference path
+BN_FN void jac_coord_set(Fe &a, u32x9 v) { a = bn_unv(v); }
+template <class T> BN_FN void jac_coord_set(Fq2B<T> &a, u32x9 v) { a.v = bn_unv(v); }
+BN_FN void jac_coord_set(Fq2A &, u32x9) {}
+template <class F>
+BN_OUTER void jac_double_cold_vec(u32x9 x, u32x9 y, u32x9 z, Jac<F> *out) {
+    Jac<F> p;
+    jac_coord_set(p.x, x); jac_coord_set(p.y, y); jac_coord_set(p.z, z);
+    *out = jac_double(p);
+}
+template <class F>
+BN_FN Jac<F> jac_double_cold(const Jac<F> &p) {
+    if constexpr (sizeof(typename F::T) == sizeof(Fe)) {
+        Jac<F> d;
+        jac_double_cold_vec<F>(jac_coord_vec(p.x), jac_coord_vec(p.y), jac_coord_vec(p.z), &d);
+        return d;
+    } else {
+        return jac_double_cold_ref(p);
+    }
+}
+#endif
 // groups/mod.rs:275-311, all branches (zero operands, equal points) as per-lane selects; the doubling for equal points is a
 // divergent branch that no lane takes for valid prime-order inputs and scalars < r.  pz / qz: "p (q) is the point at infinity".
 template <class F>

@@ -1,14 +1,25 @@
 #!/bin/bash
 # kernel experiments: build_variants/lib_<name>.so from the working tree with extra hipcc flags, then
 #   BN254_LIB_PATH=build_variants/lib_<name>.so python bench.py --no-cpu-baseline --no-host-api
-# Only the lane-pair kernel file is recompiled (that is where the experiments are); the other objects come from the last
-# regular build (bn_amd/csrc/build/).  usage: tools/build_variant.sh NAME [extra hipcc flags...]
+# Only the units named in UNITS are recompiled with the flags (default: the lane-pair kernel file, where most experiments are);
+# the other objects come from the last regular build (bn_amd/csrc/build/).
+# usage: [UNITS="bn254_kernels_b bn254_kernels_mul"] tools/build_variant.sh NAME [extra hipcc flags...]
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_variants
 name=$1; shift
 B=bn_amd/csrc/build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c bn_amd/csrc/bn254_kernels_b.hip -o build_variants/kb_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/bn254_hip.o build_variants/kb_$name.o $B/bn254_kernels_mul.o $B/bn254_kernels_w.o $B/bn254_multi.o -ldl -lpthread -o build_variants/lib_$name.so
-rm -f build_variants/kb_$name.o
+UNITS=${UNITS:-bn254_kernels_b}
+objs=""
+for u in bn254_hip bn254_kernels_b bn254_kernels_mul bn254_kernels_w bn254_multi; do
+  if [[ " $UNITS " == *" $u "* ]]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c bn_amd/csrc/$u.hip -o build_variants/${u}_$name.o &
+    objs="$objs build_variants/${u}_$name.o"
+  else
+    objs="$objs $B/$u.o"
+  fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -ldl -lpthread -o build_variants/lib_$name.so
+rm -f build_variants/*_$name.o
 echo built build_variants/lib_$name.so
