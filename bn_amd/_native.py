@@ -20,6 +20,8 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_ctx_destroy": [_VP],
     "bn254_error_string": [C.c_int],
     "bn254_ctx_set_mapping": [_VP, C.c_int],
+    "bn254_ctx_set_option": [_VP, C.c_int, C.c_long],
+    "bn254_ctx_get_option": [_VP, C.c_int, C.POINTER(C.c_long)],
     "bn254_pairing_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_pairing_product": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_g1_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
@@ -44,7 +46,10 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_gt_pow_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_gt_inverse_batch": [_VP, _VP, _VP, _SZ],
     "bn254_gt_inverse_batch_dev": [_VP, _VP, _VP, _SZ, _VP],
+    "bn254_exp_by_neg_z_dev": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_multi_create": [C.POINTER(C.c_int), C.c_int, C.POINTER(_VP)],
+    "bn254_multi_create_ex": [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(_VP)],
+    "bn254_multi_set_option": [_VP, C.c_int, C.c_long],
     "bn254_multi_destroy": [_VP],
     "bn254_multi_device_count": [_VP],
     "bn254_multi_exchange_kind": [_VP],
@@ -154,6 +159,12 @@ def lib():
         l.bn254_multi_ctx.restype = C.c_void_p
         _lib = l
     return _lib
+
+
+# BN254_OPT_* of include/bn254_hip.h
+OPTIONS = {"wave_pairing_max": 1, "wave_fe_max": 2, "quad_max": 3, "miller_shared": 4, "gt_pow_mode": 5, "product_chunk": 6,
+           "product_per_wave": 7, "product_bfly": 8, "round_pairs": 9, "pipeline_chunk": 10, "pipeline_slots": 11}
+EXCHANGE = {"auto": -1, "peer": 0, "rccl": 1}
 
 
 class Bn254Error(RuntimeError):

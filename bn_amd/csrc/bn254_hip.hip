@@ -229,16 +229,68 @@ int bn_get_ctx(bn254_ctx *&ctx) {
     return BN254_OK;
 }
 
+// ---- tunables (include/bn254_hip.h BN254_OPT_*).  Raw values live in the context, < 0 meaning "default"; the defaults are functions of
+// the device's CU count, so a partition or a smaller part gets thresholds that fit it.
+// The ONLY place this library reads its debug environment (BN254_RCCL_PATH, a file path, is read where RCCL is loaded): once per
+// process, into the seed values every new context starts from.
+namespace {
+struct DebugEnv { long opt[BN254_OPT_COUNT_]; int exchange; };
+const DebugEnv &bn_debug_env() {
+    static DebugEnv env;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (long &v : env.opt) v = -1;
+        env.exchange = BN254_EXCHANGE_AUTO;
+        static const struct { const char *name; int key; } vars[] = {
+            {"BN254_WAVE_PAIRING_MAX", BN254_OPT_WAVE_PAIRING_MAX}, {"BN254_WAVE_FE_MAX", BN254_OPT_WAVE_FE_MAX}, {"BN254_QUAD_MAX", BN254_OPT_QUAD_MAX},
+            {"BN254_MILLER_SHARED", BN254_OPT_MILLER_SHARED}, {"BN254_GT_POW_MODE", BN254_OPT_GT_POW_MODE}, {"BN254_PRODUCT_CHUNK", BN254_OPT_PRODUCT_CHUNK},
+            {"BN254_PRODUCT_PER_WAVE", BN254_OPT_PRODUCT_PER_WAVE}, {"BN254_PRODUCT_BFLY", BN254_OPT_PRODUCT_BFLY}, {"BN254_ROUND_PAIRS", BN254_OPT_ROUND_PAIRS},
+            {"BN254_PIPELINE_CHUNK", BN254_OPT_PIPELINE_CHUNK}, {"BN254_PIPELINE_SLOTS", BN254_OPT_PIPELINE_SLOTS}};
+        for (const auto &v : vars)
+            if (const char *e = getenv(v.name)) { const long x = atol(e); if (x >= 0) env.opt[v.key] = x; }
+        if (const char *e = getenv("BN254_MULTI_EXCHANGE")) env.exchange = !strcmp(e, "peer") ? BN254_EXCHANGE_PEER : !strcmp(e, "rccl") ? BN254_EXCHANGE_RCCL : BN254_EXCHANGE_AUTO;
+    });
+    return env;
+}
+// is `value` acceptable for `key`?  (negative values are always accepted: "restore the default")
+bool bn_opt_valid(int key, long v) {
+    switch (key) {
+        case BN254_OPT_WAVE_PAIRING_MAX: case BN254_OPT_WAVE_FE_MAX: case BN254_OPT_QUAD_MAX: return true;
+        case BN254_OPT_MILLER_SHARED: return v == 0 || v == 1 || v == 2 || v == 4;
+        case BN254_OPT_GT_POW_MODE: return v <= 2;
+        case BN254_OPT_PRODUCT_CHUNK: return v >= 1 && v <= 4096;
+        case BN254_OPT_PRODUCT_PER_WAVE: return v >= 1 && v <= 32;
+        case BN254_OPT_PRODUCT_BFLY: return v <= 5;
+        case BN254_OPT_ROUND_PAIRS: case BN254_OPT_PIPELINE_CHUNK: return v >= 1;
+        case BN254_OPT_PIPELINE_SLOTS: return v >= 1 && v <= BN_MAX_SLOTS;
+        default: return false;
+    }
+}
+}  // namespace
+int bn_debug_multi_exchange() { return bn_debug_env().exchange; }
+long bn_opt(const bn254_ctx *c, int key) {
+    const long v = c->opt[key].load(std::memory_order_relaxed);
+    if (v >= 0) return v;
+    const long cus = c->cus > 0 ? c->cus : 256;
+    switch (key) {
+        // one pairing / exponentiation per WAVE: a workgroup needs 11.5 KB of LDS, thirteen fit a CU; 1.05 ms up to 4 per CU (one wave per
+        // SIMD), 1.5 ms at 8, 2.1 ms at 12, 3.2 ms at 16 per CU, level with the lane-pair kernels (4.2 ms whatever the count) at ~24 per CU
+        // (profiles/r03s_wave_roles_ab.txt, r03z_wave_latency.json: 256 CUs) - the default switches at 20 per CU
+        case BN254_OPT_WAVE_PAIRING_MAX: case BN254_OPT_WAVE_FE_MAX: return 20 * cus;
+        case BN254_OPT_QUAD_MAX: return BN254_HAVE_QUAD ? 64 * cus : 0;
+        case BN254_OPT_MILLER_SHARED: case BN254_OPT_GT_POW_MODE: return 0;
+        case BN254_OPT_ROUND_PAIRS: return 256 * cus;
+        case BN254_OPT_PIPELINE_SLOTS: return 2;
+        default: return -1;                  // product shape, pipeline chunk: decided per call from the size
+    }
+}
+
 // Launch granularity of the lane-pair kernels.  One "round" = 256 pairings per CU = two resident waves on every SIMD: the shape the
 // s_setprio hand-over of bn254_kernels_b.hip is tuned for (inside a 2^18 launch every 2^16 cost 6 % more than alone, and a box with
 // fewer than 256 CUs ran a fixed 2^16 launch as 1 + a fraction rounds: profiles/r02r_*).  Larger batches are issued as equal
 // sub-launches of at most one round, which also bounds the context-owned tables (final exponentiation: 4 KB, Gt::pow: 6.9 KB per
-// pairing OF ONE SUB-LAUNCH, not of the batch).  BN254_ROUND_PAIRS overrides (experiments).
-size_t bn_round_pairs(const bn254_ctx *c) {
-    static const long forced = getenv("BN254_ROUND_PAIRS") ? atol(getenv("BN254_ROUND_PAIRS")) : 0;
-    if (forced > 0) return (size_t)forced;
-    return (size_t)256 * (size_t)(c->cus > 0 ? c->cus : 256);
-}
+// pairing OF ONE SUB-LAUNCH, not of the batch).  BN254_OPT_ROUND_PAIRS overrides (experiments).
+size_t bn_round_pairs(const bn254_ctx *c) { return (size_t)bn_opt(c, BN254_OPT_ROUND_PAIRS); }
 // as few sub-launches as possible with none above one round, all of (nearly) the same size: a ragged tail of a few pairings
 // would cost a whole kernel latency (one wave takes as long as a full machine)
 size_t bn_sub_launch(const bn254_ctx *c, size_t n) {
@@ -248,16 +300,11 @@ size_t bn_sub_launch(const bn254_ctx *c, size_t n) {
 }
 
 // Up to this many pairings (or Miller loops whose value only meets a final exponentiation) per call run ONE PER WAVE - the whole
-// pairing as a program of the wave machine - instead of one per lane pair (4.2 ms whatever the count).  A workgroup needs 11.5 KB
-// of LDS, thirteen fit a CU: 1.05 ms up to 1024 pairings (one wave per SIMD), 1.5 ms at 2048, 2.1 ms at 3072, 3.2 ms at 4096,
-// 4.4 ms at 6144 where the lane-pair kernels are level (profiles/r03s_wave_roles_ab.txt).  BN254_WAVE_PAIRING_MAX overrides.
-size_t bn_wave_pairing_max() {
-    const char *e = getenv("BN254_WAVE_PAIRING_MAX");
-    return e ? (size_t)atol(e) : 5120;
-}
+// pairing as a program of the wave machine - instead of one per lane pair (4.2 ms whatever the count): BN254_OPT_WAVE_PAIRING_MAX.
+static size_t bn_wave_pairing_max(const bn254_ctx *c) { return (size_t)bn_opt(c, BN254_OPT_WAVE_PAIRING_MAX); }
 // naf: the value is only consumed by a final exponentiation, so the shorter NAF schedule may be used (pairing.hpp)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf) {
-    if (c->mapping.load() == 1 && naf && n <= bn_wave_pairing_max()) {
+    if (c->mapping.load() == 1 && naf && n <= bn_wave_pairing_max(c)) {
         BnScope sc(c, s, "miller_wave");
         return bn254_launch_pairing_W(p, q, f, n, 0, s);
     }
@@ -277,15 +324,11 @@ int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t
     return (int)hipGetLastError();
 }
 // Up to this many final exponentiations per call run ONE PER WAVE (bn254_kernels_w.hip: 0.48 ms up to 1024 - one wave per SIMD -,
-// 0.69 ms at 2048, 1.4 ms at 4096, while a lane pair needs 1.97 ms for its serial chain whatever the count; level at ~6000:
-// profiles/r03s_wave_roles_ab.txt).  BN254_WAVE_FE_MAX overrides.
-size_t bn_wave_fe_max() {
-    const char *e = getenv("BN254_WAVE_FE_MAX");
-    return e ? (size_t)atol(e) : 5120;
-}
+// 0.69 ms at 2048, 1.4 ms at 4096, while a lane pair needs 1.97 ms for its serial chain whatever the count): BN254_OPT_WAVE_FE_MAX.
+static size_t bn_wave_fe_max(const bn254_ctx *c) { return (size_t)bn_opt(c, BN254_OPT_WAVE_FE_MAX); }
 // table: the caller's own table buffer (pipelined path: one per chunk in flight) or NULL for the context's (under a BnScratchGuard)
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table) {
-    if (c->mapping.load() == 1 && n <= bn_wave_fe_max()) {
+    if (c->mapping.load() == 1 && n <= bn_wave_fe_max(c)) {
         BnScope sc(c, s, "final_exp_wave");
         return bn254_launch_final_exp_W(f, out, n, s);
     }
@@ -314,7 +357,7 @@ int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStr
 // (what is left of a wave's `per_wave` partial products); a level of the arrival tree across waves costs ~5 us (product + publish).
 // Few values: many small waves (the tree's log2 beats the serial fold).  Many: full waves, about one wave per SIMD of groups.
 struct ProductShape { unsigned chunk, per_wave, bfly; };
-static ProductShape product_shape(size_t n) {
+static ProductShape product_shape(const bn254_ctx *c, size_t n) {
     ProductShape ps;
     if (n <= 64) ps = {1u, 2u, 0u};
     else if (n <= 2048) ps = {1u, 4u, 0u};
@@ -322,15 +365,16 @@ static ProductShape product_shape(size_t n) {
     else if (n <= 16384) ps = {1u, 32u, 2u};
     else if (n < 65536) ps = {2u, 32u, 2u};
     else ps = {(unsigned)((n + 32767) / 32768), 32u, 2u};
-    if (const char *e = getenv("BN254_PRODUCT_CHUNK")) { const long v = atol(e); if (v >= 1 && v <= 4096) ps.chunk = (unsigned)v; }
-    if (const char *e = getenv("BN254_PRODUCT_PER_WAVE")) { const long v = atol(e); if (v >= 1 && v <= 32) ps.per_wave = (unsigned)v; }
-    if (const char *e = getenv("BN254_PRODUCT_BFLY")) { const long v = atol(e); if (v >= 0 && v <= 5) ps.bfly = (unsigned)v; }
+    const long ch = bn_opt(c, BN254_OPT_PRODUCT_CHUNK), pw = bn_opt(c, BN254_OPT_PRODUCT_PER_WAVE), bf = bn_opt(c, BN254_OPT_PRODUCT_BFLY);
+    if (ch >= 1) ps.chunk = (unsigned)ch;
+    if (pw >= 1) ps.per_wave = (unsigned)pw;
+    if (bf >= 0) ps.bfly = (unsigned)bf;
     return ps;
 }
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s) {
     if (c->mapping.load() == 1) {
         size_t grid, sb, cw;
-        const ProductShape ps = product_shape(n);
+        const ProductShape ps = product_shape(c, n);
         bn254_gt_reduce_sizes_W(n, ps.chunk, ps.per_wave, &grid, &sb, &cw);
         BnScope sc(c, s, "gt_product");
         return bn254_launch_gt_reduce_W(in, n, ps.chunk, ps.per_wave, ps.bfly, tmp, (char *)tmp + sb, out, s);
@@ -362,13 +406,13 @@ int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *ou
         BnScope sc(c, s, "gt_tail");
         return bn254_launch_gt_tail_W(in, 1, (unsigned)m, out, 1, s);
     }
-    int rc = c->ws.reserve(bn_product_tmp_bytes(m)); if (rc) return rc;
+    int rc = c->ws.reserve(bn_product_tmp_bytes(c, m)); if (rc) return rc;
     if ((rc = bn_launch_product(c, in, m, out, c->ws.p, s))) return rc;
     return bn_launch_final_exp(c, out, out, 1, s, nullptr);
 }
-size_t bn_product_tmp_bytes(size_t n) {
+size_t bn_product_tmp_bytes(const bn254_ctx *c, size_t n) {
     size_t grid, sb, cw;
-    const ProductShape ps = product_shape(n ? n : 1);
+    const ProductShape ps = product_shape(c, n ? n : 1);
     bn254_gt_reduce_sizes_W(n ? n : 1, ps.chunk, ps.per_wave, &grid, &sb, &cw);
     const size_t a = 2 * ((n + 3) / 4) * 384 + 384, b = sb + cw * sizeof(uint32_t) + 256;
     return a > b ? a : b;
@@ -388,7 +432,7 @@ constexpr size_t BN_LAUNCH_MAX = (size_t)1 << 22;       // units per launch wher
 // out[i] = pairing(p[i], q[i]).  Small batches: Miller loop + final exponentiation per WAVE, one launch; otherwise the lane-pair
 // kernels, the Miller values written to `out` and exponentiated in place (same 384-byte slots).
 int bn_launch_pairing(bn254_ctx *c, const void *p, const void *q, void *out, size_t n, hipStream_t s, BnBuf *table) {
-    if (c->mapping.load() == 1 && n <= bn_wave_pairing_max()) {
+    if (c->mapping.load() == 1 && n <= bn_wave_pairing_max(c)) {
         BnScope sc(c, s, "pairing_wave");
         return bn254_launch_pairing_W(p, q, out, n, 1, s);
     }
@@ -435,6 +479,7 @@ int bn254_ctx_create(int device, bn254_ctx **out) {
     if (!c) return BN254_E_ALLOC;
     c->device = device;
     if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->cus = 256;
+    for (int k = 0; k < BN254_OPT_COUNT_; ++k) c->opt[k].store(k >= 1 && bn_opt_valid(k, bn_debug_env().opt[k]) ? bn_debug_env().opt[k] : -1);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return (int)e; }
     *out = c;
@@ -474,7 +519,21 @@ const char *bn254_error_string(int code) {
 }
 int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping) {
     if (!ctx || (mapping != 0 && mapping != 1)) return BN254_E_BAD_ARG;
-    ctx->mapping.store(mapping);        // atomic: calls already in flight keep the mapping they read at their first launch
+    // atomic; every launch helper reads it for itself, so a call in flight may run its Miller loops under one mapping and its final
+    // exponentiation under the other - the values handed over are the reference's images, the result is the same bytes
+    ctx->mapping.store(mapping);
+    return BN254_OK;
+}
+int bn254_ctx_set_option(bn254_ctx *ctx, int key, long value) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (key < 1 || key >= BN254_OPT_COUNT_ || (value >= 0 && !bn_opt_valid(key, value))) return BN254_E_BAD_ARG;
+    ctx->opt[key].store(value < 0 ? -1 : value);
+    return BN254_OK;
+}
+int bn254_ctx_get_option(bn254_ctx *ctx, int key, long *value) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (key < 1 || key >= BN254_OPT_COUNT_ || !value) return BN254_E_BAD_ARG;
+    *value = bn_opt(ctx, key);
     return BN254_OK;
 }
 
@@ -516,7 +575,7 @@ int bn254_gt_product_dev(bn254_ctx *ctx, const void *d_in, size_t n, void *d_out
         return BN254_OK;
     }
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
-    rc = ctx->ws.reserve(bn_product_tmp_bytes(n)); if (rc) return rc;
+    rc = ctx->ws.reserve(bn_product_tmp_bytes(ctx, n)); if (rc) return rc;
     return bn_launch_product(ctx, d_in, n, d_out, ctx->ws.p, s);
 }
 int bn254_gt_product_final_exp_dev(bn254_ctx *ctx, const void *d_in, size_t m, void *d_out, void *stream) {
@@ -530,10 +589,10 @@ int bn254_gt_product_final_exp_dev(bn254_ctx *ctx, const void *d_in, size_t m, v
 }
 // How many pairs share one accumulator f in the multi-pairing's Miller loop (pairing.hpp miller_loop_shared): as many as keep at least
 // one full machine round of lane pairs busy - 4 from four rounds of pairs on (configs[3] on one GPU: 2^18), 2 from two, else the
-// plain kernel (a per-GPU shard of 2^15 must not be folded onto a quarter of the machine).  BN254_MILLER_SHARED=1|2|4 overrides.
+// plain kernel (a per-GPU shard of 2^15 must not be folded onto a quarter of the machine).  BN254_OPT_MILLER_SHARED = 1|2|4 overrides.
 static int miller_shared_m(const bn254_ctx *c, size_t n) {
-    const char *e = getenv("BN254_MILLER_SHARED");
-    if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) return atoi(e);
+    const long forced = bn_opt(c, BN254_OPT_MILLER_SHARED);
+    if (forced == 1 || forced == 2 || forced == 4) return (int)forced;
     const size_t round = bn_round_pairs(c);
     return n >= 4 * round ? 4 : n >= 2 * round ? 2 : 1;
 }
@@ -545,10 +604,10 @@ int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, s
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
-    const int m = (ctx->mapping.load() == 1 && n > bn_wave_pairing_max()) ? miller_shared_m(ctx, n) : 1;
+    const int m = (ctx->mapping.load() == 1 && n > bn_wave_pairing_max(ctx)) ? miller_shared_m(ctx, n) : 1;
     const size_t nv = (n + (size_t)m - 1) / (size_t)m;             // Miller values that reach the product tree
     const size_t fbytes = nv * 384;
-    rc = ctx->ws.reserve(fbytes + bn_product_tmp_bytes(nv)); if (rc) return rc;
+    rc = ctx->ws.reserve(fbytes + bn_product_tmp_bytes(ctx, nv)); if (rc) return rc;
     if (m == 1) {
         rc = bn_launch_miller(ctx, d_p, d_q, ctx->ws.p, n, s, true); if (rc) return rc;
     } else {
@@ -602,7 +661,7 @@ int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, voi
     rc = ctx->pow_tbl.reserve(bn254_gt_pow_table_bytes_B(step)); if (rc) return rc;
     return bn_for_parts(n, step, [&](size_t lo, size_t cnt) -> int {
         BnScope sc(ctx, s, "gt_pow");
-        return bn254_launch_gt_pow_B((const char *)d_a + lo * sizeof(bn_gt), (const char *)d_k + lo * sizeof(bn_fr), (char *)d_out + lo * sizeof(bn_gt), cnt, ctx->pow_tbl.p, s);
+        return bn254_launch_gt_pow_B((const char *)d_a + lo * sizeof(bn_gt), (const char *)d_k + lo * sizeof(bn_fr), (char *)d_out + lo * sizeof(bn_gt), cnt, ctx->pow_tbl.p, (int)bn_opt(ctx, BN254_OPT_GT_POW_MODE), s);
     });
 }
 int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, size_t n, void *stream) {
@@ -610,6 +669,13 @@ int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, siz
     return bn_for_parts(n, BN_LAUNCH_MAX, [&](size_t lo, size_t cnt) -> int {
         BnScope sc(ctx, s, "gt_inverse");
         return bn254_launch_gt_inverse_B((const char *)d_a + lo * sizeof(bn_gt), (char *)d_out + lo * sizeof(bn_gt), cnt, s);
+    });
+}
+int bn254_exp_by_neg_z_dev(bn254_ctx *ctx, const void *d_a, void *d_out, size_t n, void *stream) {
+    BN_DEV_PROLOGUE(!d_a || !d_out, BN_N_MAX);
+    return bn_for_parts(n, BN_LAUNCH_MAX, [&](size_t lo, size_t cnt) -> int {
+        BnScope sc(ctx, s, "exp_by_neg_z");
+        return bn254_launch_exp_by_neg_z_B((const char *)d_a + lo * sizeof(bn_gt), (char *)d_out + lo * sizeof(bn_gt), cnt, s);
     });
 }
 
@@ -835,18 +901,27 @@ int bn254_wave_ubench(bn254_ctx *ctx, int which, int iters, double *ms_out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     BnDeviceGuard dev_guard;
     HIP_TRY(hipSetDevice(ctx->device));
-    if ((rc = ctx->stage[0].reserve(4096))) return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    rc = bn254_launch_wave_ubench_W(which, 1, ctx->stage[0].p, ctx->stream);           // warm-up (code and tables into the caches)
-    HIP_TRY(hipEventRecord(e0, ctx->stream));
-    if (!rc) rc = bn254_launch_wave_ubench_W(which, iters, ctx->stage[0].p, ctx->stream);
-    HIP_TRY(hipEventRecord(e1, ctx->stream));
-    HIP_TRY(hipEventSynchronize(e1));
+    BnBuf out;                                        // its own buffer: ctx->stage belongs to the host-buffer entry points
+    if ((rc = out.reserve(4096))) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    *ms_out = ms;
+    auto body = [&]() -> int {
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        int r = bn254_launch_wave_ubench_W(which, 1, out.p, ctx->stream);           // warm-up (code and tables into the caches)
+        if (r) return r;
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+        if ((r = bn254_launch_wave_ubench_W(which, iters, out.p, ctx->stream))) return r;
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        return BN254_OK;
+    };
+    rc = body();
+    if (rc) (void)hipStreamSynchronize(ctx->stream);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    out.release();
+    if (!rc) *ms_out = ms;
     return rc;
 }
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {

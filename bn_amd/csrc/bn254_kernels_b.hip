@@ -68,7 +68,6 @@
 #define BN_B_FAIR_SHIFT 20          // 2^20 cycles: re-measured after the asm leaves (profiles/r03_ab_fair_policy.txt; 21 before)
 #endif
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 __device__ __forceinline__ void bn_fair_priority(int step) {
     const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_ID.wave_id: 0 / 1 for the two resident waves
     if ((step ^ slot) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
@@ -535,9 +534,28 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     Fq12<F2> r = f12_inverse(f12_load<F2>(a + 96u * pair));
     if (live) f12_store(r, out + 96u * pair);
 }
+// out[i] = a[i].exp_by_neg_z() exactly as the reference writes it (fields/fq12.rs:229-246: 62 x { cyclotomic_squared; multiply on the
+// set bits of u }, then unitary_inverse) for ANY Fq12 - off the cyclotomic subgroup the Granger-Scott "squaring" is not a square, so the
+// result is specific to this operation sequence.  The engine's own exponentiation (fe_step programs, signed digits) equals it only on
+// cyclotomic elements, which is all a pairing ever feeds it; this kernel exists so that the reference's known answer for the function
+// (fields/mod.rs:171-201, an element OFF the subgroup) runs on the device literally.
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_exp_by_neg_z_B(const uint32_t *a, uint32_t *out, uint32_t n) {
+    BN_KERNEL_PROLOGUE();
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;
+    Fq12<F2> r = exp_by_neg_z_reference_schedule(f12_load<F2>(a + 96u * pair));
+    if (live) f12_store(r, out + 96u * pair);
+}
 }  // namespace
 
 extern "C" {
+int bn254_launch_exp_by_neg_z_B(const void *a, void *out, size_t n, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_exp_by_neg_z_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (uint32_t *)out, (uint32_t)n);
+    return (int)hipGetLastError();
+}
 int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(bn254_g2_precompute_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)q, (uint32_t *)coeffs, (uint32_t)n);
@@ -558,12 +576,10 @@ size_t bn254_gt_pow_table_bytes_B(size_t n) {
     size_t grid = (2 * n + BLOCK - 1) / BLOCK;
     return grid * BLOCK * POW_TABLE_DWORDS_PER_LANE * sizeof(uint32_t);
 }
-int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, hipStream_t s) {
+// mode (BN254_OPT_GT_POW_MODE): 0 Frobenius decomposition for cyclotomic input, 2 strict (one-dimensional chain for cyclotomic input: no
+// assumption on the order), 1 the general chain for everything
+int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, int mode, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    // BN254_GT_POW_MODE: 0 (default) Frobenius decomposition for cyclotomic input, 2 strict (one-dimensional chain for cyclotomic
-    // input: no assumption on the order), 1 the general chain for everything
-    const char *e = getenv("BN254_GT_POW_MODE");
-    const int mode = e ? atoi(e) : 0;
     hipLaunchKernelGGL(bn254_gt_pow_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)a, (const uint32_t *)k, (uint32_t *)out, (uint32_t)n, (uint32_t *)table, mode < 0 || mode > 2 ? 0 : mode);
     return (int)hipGetLastError();
 }

@@ -76,28 +76,31 @@ void plan(const bn254_ctx *c, size_t n, size_t &chunk, int &nslots) {
     // as few chunks as possible with none above one round of the machine (256 pairings per CU: two waves on every SIMD), all of
     // (nearly) the same size: a ragged tail of a few pairings would cost a whole kernel latency
     size_t ch = bn_sub_launch(c, n);
-    const char *e = getenv("BN254_PIPELINE_CHUNK");                                // experiments
-    if (e && atol(e) > 0) ch = (size_t)atol(e);
+    const long forced = bn_opt(c, BN254_OPT_PIPELINE_CHUNK);                       // experiments
+    if (forced > 0) ch = (size_t)forced;
     chunk = ch;
-    int want = 2;
-    const char *s = getenv("BN254_PIPELINE_SLOTS");
-    if (s && atoi(s) > 0) want = std::min(BN_MAX_SLOTS, atoi(s));
+    const int want = std::min(BN_MAX_SLOTS, std::max(1, (int)bn_opt(c, BN254_OPT_PIPELINE_SLOTS)));
     nslots = (int)std::min<size_t>((size_t)want, (n + ch - 1) / ch);
 }
 
-// runs fn(w) for w = 0 .. count-1, workers 1.. on their own host threads.  A std::thread constructor that throws (resource
-// exhaustion) must not unwind past joinable threads (std::terminate): the workers that could not be started run inline instead.
+// runs fn(w) for w = 0 .. count-1, workers 1.. on their own host threads.  Nothing may unwind past a joinable std::thread (its
+// destructor calls std::terminate): a thread constructor that throws (resource exhaustion) makes the remaining workers run inline, and
+// an exception out of fn - bad_alloc inside a std::function or vector, say - on whichever thread is held until every started thread
+// has been joined, then rethrown on the calling thread for the entry point's bn_no_throw to translate.
 template <class Fn>
 void run_workers(int count, Fn fn) {
+    std::vector<std::exception_ptr> err((size_t)count);
+    auto guarded = [&](int w) noexcept { try { fn(w); } catch (...) { err[(size_t)w] = std::current_exception(); } };
     std::vector<std::thread> th;
     th.reserve((size_t)count);
     int started = 1;
     for (int w = 1; w < count; ++w) {
-        try { th.emplace_back(fn, w); ++started; } catch (...) { break; }
+        try { th.emplace_back(guarded, w); ++started; } catch (...) { break; }
     }
-    fn(0);
-    for (int w = started; w < count; ++w) fn(w);
+    guarded(0);
+    for (int w = started; w < count; ++w) guarded(w);
     for (auto &t : th) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
 int run_map(MapJob &j) {
@@ -193,12 +196,24 @@ struct bn254_multi {
 
 extern "C" {
 
-static int multi_create(const int *devices, int ndev, bn254_multi **out);
+static int multi_create(const int *devices, int ndev, int exchange, bn254_multi **out);
 static int pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n);
 static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out);
-int bn254_multi_create(const int *devices, int ndev, bn254_multi **out) {
+int bn254_multi_create_ex(const int *devices, int ndev, int exchange, bn254_multi **out) {
+    if (exchange != BN254_EXCHANGE_AUTO && exchange != BN254_EXCHANGE_PEER && exchange != BN254_EXCHANGE_RCCL) return BN254_E_BAD_ARG;
     BnDeviceGuard dev_guard;
-    return bn_no_throw([&] { return multi_create(devices, ndev, out); });
+    return bn_no_throw([&] { return multi_create(devices, ndev, exchange, out); });
+}
+int bn254_multi_create(const int *devices, int ndev, bn254_multi **out) {
+    return bn254_multi_create_ex(devices, ndev, bn_debug_multi_exchange(), out);          // AUTO unless the debug environment says otherwise
+}
+int bn254_multi_set_option(bn254_multi *m, int key, long value) {
+    if (!m) return BN254_E_BAD_ARG;
+    for (int g = 0; g < bn254_multi_device_count(m); ++g) {
+        const int rc = bn254_ctx_set_option(bn254_multi_ctx(m, g), key, value);
+        if (rc) return rc;
+    }
+    return BN254_OK;
 }
 int bn254_pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n) {
     BnDeviceGuard dev_guard;
@@ -208,7 +223,7 @@ int bn254_pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, 
     BnDeviceGuard dev_guard;
     return bn_no_throw([&] { return pairing_product_multi(m, p, q, n, out); });
 }
-static int multi_create(const int *devices, int ndev, bn254_multi **out) {
+static int multi_create(const int *devices, int ndev, int exchange, bn254_multi **out) {
     if (!out || ndev <= 0 || ndev > 64) return BN254_E_BAD_ARG;
     const int have = bn254_device_count();
     if (have <= 0) return BN254_E_NO_DEVICE;
@@ -233,8 +248,7 @@ static int multi_create(const int *devices, int ndev, bn254_multi **out) {
     std::vector<int> sorted = m->devices;
     std::sort(sorted.begin(), sorted.end());
     const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
-    const char *force = getenv("BN254_MULTI_EXCHANGE");
-    const bool want_rccl = distinct && !(force && !strcmp(force, "peer"));
+    const bool want_rccl = distinct && exchange != BN254_EXCHANGE_PEER;
     if (want_rccl) {
         Rccl &r = rccl();
         if (r.ok) {
@@ -242,8 +256,8 @@ static int multi_create(const int *devices, int ndev, bn254_multi **out) {
             if (r.CommInitAll(m->comms.data(), ndev, m->devices.data()) == ncclSuccess) m->exchange = BN254_EXCHANGE_RCCL;
             else m->comms.clear();
         }
-        if (m->exchange != BN254_EXCHANGE_RCCL && force && !strcmp(force, "rccl")) { bn254_multi_destroy(m); return BN254_E_COMM; }
     }
+    if (m->exchange != BN254_EXCHANGE_RCCL && exchange == BN254_EXCHANGE_RCCL) { bn254_multi_destroy(m); return BN254_E_COMM; }
     *out = m;
     return BN254_OK;
 }

@@ -40,6 +40,9 @@ int bn_no_throw(Fn &&fn) {
     try { return fn(); } catch (const std::bad_alloc &) { return BN254_E_ALLOC; } catch (...) { return BN254_E_INTERNAL; }
 }
 
+#ifndef BN254_HAVE_QUAD
+#define BN254_HAVE_QUAD 0        // the four-lanes-per-pairing kernels (bn254_kernels_q.hip) are linked in
+#endif
 constexpr int BN_MAX_SLOTS = 4;            // chunks in flight in the pipelined host-buffer path (2 used; the rest for experiments)
 
 // grow-only buffer, device or pinned host
@@ -72,6 +75,7 @@ struct bn254_ctx {
     int device = 0;
     int cus = 256;                      // compute units of the device (sizes one "round" of the lane-pair kernels: bn_round_pairs)
     std::atomic<int> mapping{1};        // 1: lane-pair mapping (default), 0: one lane per pairing; read by slot-leased callers without ctx->mu
+    std::atomic<long> opt[BN254_OPT_COUNT_];   // bn254_ctx_set_option: raw values, < 0 = "derive the default from the device" (bn_opt)
     std::mutex mu;                      // host-buffer entry points hold it for the whole call
     std::mutex scratch_mu;              // guards the scratch bookkeeping below (held only while enqueueing)
     hipStream_t stream = nullptr;       // the context's own stream (host-buffer entry points)
@@ -129,6 +133,8 @@ struct BnScope {
 };
 
 int bn_get_ctx(bn254_ctx *&ctx);                                   // NULL -> the default context of the current device
+long bn_opt(const bn254_ctx *c, int key);                          // EFFECTIVE value of a BN254_OPT_* tunable (defaults from the CU count)
+int bn_debug_multi_exchange();                                     // BN254_EXCHANGE_AUTO unless the debug environment forces one (read once)
 // scratch guard: lives across the enqueueing of work that reads/writes ctx->ws / ctx->exp_tbl on stream `s`
 struct BnScratchGuard {
     bn254_ctx *c; hipStream_t s; int rc;
@@ -144,7 +150,7 @@ int bn_launch_pairing(bn254_ctx *c, const void *p, const void *q, void *out, siz
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table);
 int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *out, hipStream_t s);   // scratch guard held by the caller
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s);
-size_t bn_product_tmp_bytes(size_t n);
+size_t bn_product_tmp_bytes(const bn254_ctx *c, size_t n);
 // table: the caller's own buffer (pipelined path: the slot's) or NULL for the context's (then under a BnScratchGuard)
 int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize, BnBuf *table = nullptr);
 
@@ -159,8 +165,9 @@ int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStrea
 int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
 int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
 size_t bn254_gt_pow_table_bytes_B(size_t n);
-int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, hipStream_t s);
+int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, int mode, hipStream_t s);
 int bn254_launch_gt_inverse_B(const void *a, void *out, size_t n, hipStream_t s);
+int bn254_launch_exp_by_neg_z_B(const void *a, void *out, size_t n, hipStream_t s);
 // bn254_kernels_w.hip: one Fq12 per wave (wave.hpp)
 int bn254_launch_wave_ubench_W(int which, int iters, void *out, hipStream_t s);
 int bn254_launch_final_exp_W(const void *f, void *out, size_t n, hipStream_t s);

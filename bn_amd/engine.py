@@ -46,6 +46,35 @@ class Engine:
             self._lib.bn254_ctx_destroy(self._ctx)
             self._ctx = None
 
+    # ---- tunables (include/bn254_hip.h BN254_OPT_*): names as in _native.OPTIONS; None / a negative value restores the default
+    def set_option(self, name, value):
+        _native.check(self._lib.bn254_ctx_set_option(self._h, _native.OPTIONS[name], -1 if value is None else int(value)))
+
+    def get_option(self, name):
+        v = C.c_long()
+        _native.check(self._lib.bn254_ctx_get_option(self._h, _native.OPTIONS[name], C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """context manager: set the given options, restore the previous RAW state (default or explicit) on exit"""
+        eng = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = {k: eng.get_option(k) for k in kw}
+                self_.dflt = {}
+                for k in kw:                       # is the current value the default?  (set -1, read, compare)
+                    eng.set_option(k, None); self_.dflt[k] = eng.get_option(k) == self_.old[k]
+                for k, v in kw.items():
+                    eng.set_option(k, v)
+                return eng
+
+            def __exit__(self_, *exc):
+                for k in kw:
+                    eng.set_option(k, None if self_.dflt[k] else self_.old[k])
+                return False
+        return _Scope()
+
     @property
     def _h(self):
         """the context handle; a closed engine raises instead of silently falling back to the C ABI's NULL = default context"""
@@ -233,6 +262,10 @@ class Engine:
     def gt_pow_dev(self, d_a, d_k, d_out, n, stream=0):
         _native.check(self._lib.bn254_gt_pow_batch_dev(self._h, d_a, d_k, d_out, n, stream))
 
+    def exp_by_neg_z_dev(self, d_in, d_out, n, stream=0):
+        """Fq12::exp_by_neg_z as the reference writes it (fq12.rs:229-246), any Fq12 in"""
+        _native.check(self._lib.bn254_exp_by_neg_z_dev(self._h, d_in, d_out, n, stream))
+
     def synthetic_scalars_dev(self, seed, lo, n, which, d_out, stream=0):
         _native.check(self._lib.bn254_synthetic_scalars_dev(self._h, seed, lo, n, which, d_out, stream))
 
@@ -269,15 +302,20 @@ class MultiEngine:
     pairings, and the multi-pairing product with its single 384-byte-per-rank exchange (RCCL all-gather when every rank has
     its own GPU, peer copies when a device is listed twice)."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, exchange="auto"):
+        """exchange: "auto" (RCCL when every rank has its own GPU and RCCL loads, else peer copies), "peer", "rccl" (fail instead of
+        falling back)"""
         self._lib = _native.lib()
         if self._lib.bn254_device_count() <= 0:
             raise _native.Bn254Error("no HIP device: bn_amd has no CPU fallback")
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         h = C.c_void_p()
-        _native.check(self._lib.bn254_multi_create(devs, len(devices), C.byref(h)))
+        _native.check(self._lib.bn254_multi_create_ex(devs, len(devices), _native.EXCHANGE[exchange], C.byref(h)))
         self._m = h
         self.devices = list(devices)
+
+    def set_option(self, name, value):
+        _native.check(self._lib.bn254_multi_set_option(self._h, _native.OPTIONS[name], -1 if value is None else int(value)))
 
     @property
     def _h(self):

@@ -47,7 +47,8 @@
  *     slot: two callers with batches of up to one machine round (256 pairings per CU: 2^16 on an MI355X) run concurrently on two
  *     streams (the number of streams the GPU overlaps without loss), further callers and multi-chunk batches queue; every other
  *     entry point serialises its callers on the context.  Use one context per thread (or bn254_multi_*) for more overlap;
- *     bn254_ctx_set_mapping is atomic, but set it before concurrent use: a call in flight keeps the mapping it started with;
+ *     bn254_ctx_set_mapping and bn254_ctx_set_option are atomic, but set them before concurrent use: a call in flight may run some
+ *     of its launches under the old and some under the new setting (same bytes either way);
  *   - the *_dev entry points are asynchronous on the caller's stream.  Context-owned scratch (the final-exponentiation table,
  *     the product workspace) is ordered across streams with events, so calls on different streams of one context are safe
  *     and serialise on that scratch; the caller still owns the ordering of its OWN buffers between streams.
@@ -92,6 +93,42 @@ const char *bn254_error_string(int code);
 /* 0: one pairing per lane (Fq2A); 1: one pairing per lane PAIR (Fq2B, the default).  Results are identical. */
 int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping);
 
+/* ---- tunables ---------------------------------------------------------------------------------------------------------
+   Every policy of the host side is a per-context option whose default is derived from the device the context is bound to (its
+   compute-unit count, `CUs` below); the call paths read nothing from the environment.  value < 0 restores the default;
+   bn254_ctx_get_option reports the EFFECTIVE value.  ctx == NULL addresses the default context of the current device.  An option
+   may be changed at any time; a call in flight may see the old or the new value between two of its launches - harmless, because
+   every option selects between kernels that return the same bytes (the one exception is stated at BN254_OPT_GT_POW_MODE).
+   For experiments only, the variables BN254_WAVE_PAIRING_MAX, BN254_WAVE_FE_MAX, BN254_QUAD_MAX, BN254_MILLER_SHARED, BN254_GT_POW_MODE,
+   BN254_PRODUCT_CHUNK / _PER_WAVE / _BFLY, BN254_ROUND_PAIRS, BN254_PIPELINE_CHUNK / _SLOTS and BN254_MULTI_EXCHANGE (rccl | peer) are
+   read ONCE per process, when the first context is created, and seed the options of every context created afterwards. */
+enum {
+    BN254_OPT_WAVE_PAIRING_MAX = 1, /* pairings (or Miller loops that only meet a final exponentiation) per call up to which ONE PER WAVE
+                                       runs (csrc/bn254_kernels_w.hip) instead of one per lane pair.  Default 20 x CUs (5120): where the
+                                       two are level on 256 CUs (profiles/r03s_wave_roles_ab.txt), 13 workgroups of 11.5 KB LDS per CU */
+    BN254_OPT_WAVE_FE_MAX = 2,      /* the same for final exponentiations.  Default 20 x CUs */
+    BN254_OPT_QUAD_MAX = 3,         /* pairings per call up to which (and above the two options before) a pairing is spread over FOUR lanes
+                                       instead of two (csrc/bn254_kernels_q.hip): the faster mapping while lane pairs would leave SIMDs
+                                       empty.  Default 64 x CUs (16384): half a machine round of lane pairs */
+    BN254_OPT_MILLER_SHARED = 4,    /* pairs per lane pair on ONE accumulator in the multi-pairing's Miller loop: 1, 2 or 4; 0 (default):
+                                       4 from four machine rounds of pairs on, 2 from two, else 1 */
+    BN254_OPT_GT_POW_MODE = 5,      /* Gt::pow chain: 0 (default) Frobenius decomposition - exact for elements whose ORDER DIVIDES r, which
+                                       is everything the reference's Gt can hold; 2 one-dimensional cyclotomic chain - exact for ANY
+                                       cyclotomic element; 1 the reference's general chain for everything.  THE ONE OPTION THAT CAN
+                                       CHANGE RESULTS: only for inputs outside the r-torsion, which the reference's typed API cannot
+                                       produce (see bn254_gt_pow_batch) */
+    BN254_OPT_PRODUCT_CHUNK = 6,    /* shape of the one-launch Fq12 product tree: values per lane pair (1..4096), */
+    BN254_OPT_PRODUCT_PER_WAVE = 7, /* live lane pairs per wave (1..32), */
+    BN254_OPT_PRODUCT_BFLY = 8,     /* butterfly levels inside a wave (0..5).  Defaults: by size, profiles/r03p_product_shape_sweep.txt */
+    BN254_OPT_ROUND_PAIRS = 9,      /* pairings per launch of the lane-pair kernels ("one machine round").  Default 256 x CUs: two waves
+                                       on every SIMD; larger batches run as equal sub-launches of at most this size */
+    BN254_OPT_PIPELINE_CHUNK = 10,  /* pairings per chunk of the pipelined host-buffer path.  Default: the sub-launch size */
+    BN254_OPT_PIPELINE_SLOTS = 11,  /* chunks in flight, 1..4.  Default 2: the number of streams the GPU overlaps without loss */
+    BN254_OPT_COUNT_ = 12
+};
+int bn254_ctx_set_option(bn254_ctx *ctx, int key, long value);
+int bn254_ctx_get_option(bn254_ctx *ctx, int key, long *value);
+
 /* ---- host-buffer entry points (what a binding of the reference's API calls) ------------------------------------------ */
 /* ctx == NULL uses a process-wide default context on the current HIP device. */
 int bn254_pairing_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n);
@@ -112,8 +149,11 @@ int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *ou
    such (the Fq12 inside Gt is private and Gt has no decoder), all of order r.  On those the device exponentiates through the
    Frobenius decomposition (k = k0 + k1 q + k2 q^2 + k3 q^3 mod r: 68 cyclotomic squarings and 72 products instead of 252 and 64),
    which needs the order to divide r.  An element that is not even cyclotomic is detected and takes the general chain
-   (fields/mod.rs:35-46 as written).  Environment BN254_GT_POW_MODE=2 selects the one-dimensional cyclotomic chain, exact for ANY
-   cyclotomic element; =1 the general chain for everything.  One window table of 7.4 KB per lane of a sub-launch lives in the context. */
+   (fields/mod.rs:35-46 as written).  bn254_ctx_set_option(ctx, BN254_OPT_GT_POW_MODE, 2) selects the one-dimensional cyclotomic
+   chain, exact for ANY cyclotomic element; 1 the general chain for everything.  One window table of 7.4 KB per lane of a sub-launch
+   lives in the context.
+   The same precondition holds for bn254_g2_mul_batch: the GLS decomposition multiplies correctly on the order-r subgroup of the twist -
+   the only G2 values the reference's API can hold (checked decode, groups/mod.rs:178-205); other twist points are outside the contract. */
 int bn254_gt_pow_batch(bn254_ctx *ctx, const bn_gt *a, const bn_fr *k, bn_gt *out, size_t n);
 /* out[i] = a[i]^-1 in Fq12 (Gt::inverse, lib.rs:172 -> fields/fq12.rs:284-292); a[i] must be non-zero, as every Gt value is */
 int bn254_gt_inverse_batch(bn254_ctx *ctx, const bn_gt *a, bn_gt *out, size_t n);
@@ -121,11 +161,16 @@ int bn254_gt_inverse_batch(bn254_ctx *ctx, const bn_gt *a, bn_gt *out, size_t n)
 /* ---- one node, several GPUs (north_star: independent batches shard across the GPUs; ONE exchange for the multi-pairing) --- */
 /* `devices[0..ndev)`: HIP device index of every rank (NULL = 0..ndev-1).  One context and one host thread per rank.  A device may
    be listed more than once (several ranks on one GPU - how the N > 1 path is exercised on a one-GPU box); the exchange of the
-   product is an RCCL all-gather when all devices are distinct and RCCL loads, peer copies otherwise (BN254_MULTI_EXCHANGE=
-   rccl|peer forces one). */
+   product is an RCCL all-gather when all devices are distinct and RCCL loads, peer copies otherwise (bn254_multi_create_ex
+   forces one). */
 typedef struct bn254_multi bn254_multi;
-enum { BN254_EXCHANGE_PEER = 0, BN254_EXCHANGE_RCCL = 1 };
-int bn254_multi_create(const int *devices, int ndev, bn254_multi **out);
+enum { BN254_EXCHANGE_AUTO = -1, BN254_EXCHANGE_PEER = 0, BN254_EXCHANGE_RCCL = 1 };
+int bn254_multi_create(const int *devices, int ndev, bn254_multi **out);                       /* = _ex(..., BN254_EXCHANGE_AUTO, ...) */
+/* exchange: BN254_EXCHANGE_AUTO (RCCL when every rank has its own GPU and RCCL loads, else peer copies), _PEER (never load RCCL),
+   _RCCL (fail with BN254_E_COMM instead of falling back) */
+int bn254_multi_create_ex(const int *devices, int ndev, int exchange, bn254_multi **out);
+/* bn254_ctx_set_option on every rank's context */
+int bn254_multi_set_option(bn254_multi *m, int key, long value);
 void bn254_multi_destroy(bn254_multi *m);
 int bn254_multi_device_count(const bn254_multi *m);
 int bn254_multi_exchange_kind(const bn254_multi *m);                 /* BN254_EXCHANGE_* */
@@ -210,8 +255,13 @@ int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uin
    `waves_per_simd` resident waves: G lane-MACs per second over the whole chip and the kernel's duration.  bench.py prints it
    as the same-run `roofline.peak`. */
 int bn254_ubench_mac32(bn254_ctx *ctx, int waves_per_simd, int iters, double *gmac_per_s, double *ms);
+/* d_out[i] = d_in[i].exp_by_neg_z() as the reference writes it (fields/fq12.rs:229-246), for ANY Fq12: the one function of the path
+   whose known answer (fields/mod.rs:171-201) lies OFF the cyclotomic subgroup, where the result depends on the operation sequence.
+   The engine's own exponentiation by u (shorter signed-digit chain, equal on every value a pairing produces) is not reachable with
+   such an input; this entry point runs the reference's sequence so that its test vector can be checked on the device. */
+int bn254_exp_by_neg_z_dev(bn254_ctx *ctx, const void *d_in, void *d_out, size_t n, void *stream);
 /* the wave-cooperative machine on one wave: milliseconds for `iters` runs of program `which` (0 cyclotomic squaring, 1 Fq12
-   product, 2 slot copy, 3 Frobenius map, 4 whole final exponentiation) - the per-phase costs quoted in DESIGN.md */
+   product, 2 slot copy, 3 Frobenius map, 4 whole final exponentiation, 5 a fused run of five squarings) - the per-phase costs quoted in DESIGN.md */
 int bn254_wave_ubench(bn254_ctx *ctx, int which, int iters, double *ms);
 
 #ifdef __cplusplus

@@ -46,3 +46,74 @@ def test_hot_loops_are_spill_free(kernel):
     hot = [b for b in blocks if b[0] >= 2500]                  # the loop bodies: squarings, line / table products (2.8k .. 14k instructions)
     assert len(hot) >= 2, blocks
     assert all(s == 0 for _, s in hot), f"scratch accesses inside the hot blocks of {kernel}: {hot}"
+
+
+# vgpr_spill_count ceilings of EVERY shipped kernel (tools/kernel_meta.py reads them from the code objects).  The ceilings are the
+# values of the build this test was written against: anything above means an edit moved a register allocation - look at
+# `tools/isa_mix.py --blocks KERNEL` before raising one.  The mapping-A kernels (bn254_*_A, *_mul_k) are the one-lane-per-pairing test
+# double, not a performance path; their spills are recorded, not guarded.
+SPILL_CEILING = {
+    "bn254_miller_B": 0, "bn254_miller_naf_B": 0, "bn254_final_exp_B": 5, "bn254_miller_shared2_B": 3, "bn254_miller_shared4_B": 4,
+    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 4, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 17, "bn254_gt_inverse_B": 4,
+    "bn254_exp_by_neg_z_B": 4,
+    "bn254_g1_mul_M": 0, "bn254_g1_mul_chain_M": 0, "bn254_g2_mul_M": 0, "bn254_g2_mul_chain_M": 0, "bn254_g1_add_M": 0, "bn254_g2_add_M": 0,
+    "bn254_final_exp_W": 0, "bn254_pairing_W": 0, "bn254_gt_tail_W": 0, "bn254_wave_ubench_W": 0, "bn254_gt_reduce_W": 2,
+    "bn254_g1_encode_k": 0, "bn254_g2_encode_k": 0, "bn254_g1_decode_k": 0, "bn254_g2_decode_k": 18, "bn254_fr_encode_k": 0, "bn254_fr_decode_k": 0,
+    "bn254_ubench_mad_k": 0, "bn254_synthetic_scalars_k": 0, "bn254_tile_k": 0,
+}
+UNGUARDED = {"bn254_miller_A", "bn254_final_exp_A", "bn254_gt_product_A", "bn254_g1_mul_k", "bn254_g2_mul_k"}
+# kernels that must fit their occupancy target without private memory beyond small call frames: the hot state of the scalar
+# multiplications used to be written to scratch on every addition (round 4: 10.7 KB per G1 multiplication) - private memory that
+# is only the window-table setup stays below these sizes
+PRIVATE_CEILING = {"bn254_g1_mul_M": 1400, "bn254_g2_mul_M": 1400, "bn254_miller_naf_B": 160, "bn254_miller_B": 160}
+
+
+def test_spill_ceilings_of_every_kernel():
+    import isa_mix
+    import kernel_meta
+    so = ROOT / "bn_amd" / "libbn254_hip.so"
+    if not so.exists() or not (isa_mix.LLVM / "llvm-readelf").exists():
+        pytest.skip("library or llvm-readelf not present")
+    meta = kernel_meta.kernel_meta(so)
+    unknown = set(meta) - set(SPILL_CEILING) - UNGUARDED
+    assert not unknown, f"kernels without a spill ceiling (add them to SPILL_CEILING): {sorted(unknown)}"
+    missing = set(SPILL_CEILING) - set(meta)
+    assert not missing, f"kernels named in SPILL_CEILING that the library no longer has: {sorted(missing)}"
+    over = {k: (meta[k]["spill"], c) for k, c in SPILL_CEILING.items() if meta[k]["spill"] > c}
+    assert not over, f"vgpr_spill_count above its ceiling (kernel: (now, ceiling)): {over}"
+    over = {k: (meta[k]["private"], c) for k, c in PRIVATE_CEILING.items() if meta[k]["private"] > c}
+    assert not over, f"private segment above its ceiling (kernel: (now, ceiling)): {over}"
+
+
+def test_scalar_multiplication_loops_do_not_store_to_scratch():
+    """the window loop of the G1 / G2 scalar multiplications (doublings + mixed additions: blocks of >= 900 instructions with
+    multiply-adds) holds the running point in registers: no scratch STORES (round 4: a by-reference cold call made the compiler
+    store the point after every addition)"""
+    import isa_mix
+    so = ROOT / "bn_amd" / "libbn254_hip.so"
+    if not so.exists() or not (isa_mix.LLVM / "llvm-objdump").exists():
+        pytest.skip("library or llvm-objdump not present")
+    for kernel in ("bn254_g1_mul_M", "bn254_g2_mul_M"):
+        blocks = []                                   # (instructions, scratch stores) of every basic block, in address order
+        for text in isa_mix.disassemble(so):
+            on = False; n = st = 0
+            for line in text.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+                if m:
+                    if on and n: blocks.append((n, st))
+                    on = kernel + "E" in m.group(1) or m.group(1).endswith(kernel); n = st = 0; continue
+                if not on: continue
+                m = re.match(r"^\s+([a-z_0-9]+)\s", line)
+                if not m: continue
+                op = m.group(1); n += 1
+                if op.startswith("scratch_store"): st += 1
+                if op.startswith(("s_cbranch", "s_branch")):
+                    blocks.append((n, st)); n = st = 0
+            if on and n: blocks.append((n, st))
+        big = [i for i, (n, _) in enumerate(blocks) if n >= 900]
+        assert len(big) >= 4, (kernel, blocks)
+        # from the doubling block of the window loop (the fourth big block from the end: doubling, two halves of the mixed addition,
+        # the normalisation that follows the loop) to the end of the function, small glue blocks included - the table construction
+        # before it may store its Jacobian table
+        region = blocks[big[-4]:]
+        assert sum(st for _, st in region) == 0, f"scratch stores inside the window loop of {kernel}: {region}"

@@ -39,6 +39,96 @@ def test_reference_kats_on_gpu(oracle, kats, eng):
     assert oracle.fq12_to_ints(gt) == [int(x) for x in kats["test_reduced_pairing"]["expected"]]
 
 
+def test_reference_miller_loop_kat_on_gpu(oracle, kats, eng):
+    """groups/mod.rs:522-547 (test_miller_loop) literally: miller_loop(precompute(k2 G2), k1 G1) through bn254_miller_batch_dev - the
+    reference-schedule kernel, whose un-exponentiated value must be the reference's twelve field elements - in both lane mappings"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    k = kats["test_miller_loop"]
+    P = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_decimal(FR, k["k1"])); Q = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, k["k2"]))
+    for mapping in (1, 0):
+        e = bn_amd.Engine(0, mapping=mapping)
+        te = D.TorchEngine(e, torch.device("cuda", 0))
+        dp = torch.from_numpy(P.reshape(1, 12).view(np.int64)).to(te.device); dq = torch.from_numpy(Q.reshape(1, 24).view(np.int64)).to(te.device)
+        f = te.empty(1, 48)
+        e.miller_batch_dev(dp.data_ptr(), dq.data_ptr(), f.data_ptr(), 1, te._stream())
+        torch.cuda.synchronize()
+        assert oracle.fq12_to_ints(f.cpu().numpy().view(np.uint64)[0]) == [int(x) for x in k["expected"]], mapping
+        # and the second half of the reference's test chain: final_exponentiation(that value) = test_reduced_pairing's answer
+        e.final_exp_batch_dev(f.data_ptr(), f.data_ptr(), 1, te._stream())
+        torch.cuda.synchronize()
+        assert oracle.fq12_to_ints(f.cpu().numpy().view(np.uint64)[0]) == [int(x) for x in kats["test_reduced_pairing"]["expected"]], mapping
+        e.close()
+
+
+def test_reference_fq12_vector_on_gpu(oracle, kats, eng):
+    """fields/mod.rs:83-169 (fq12_test_vector): every one of its 111 Fq12 products (100 x `next * start`, 10 + 1 x `squared`) runs on the
+    device through bn254_gt_mul_batch (the element is an arbitrary Fq12, not a Gt value - the kernel is the general product); the ten
+    rounds of add / sub / neg between them are not operations of the C ABI (Gt has no addition) and stay on the host"""
+    k = kats["fq12_test_vector"]
+    start = oracle.fq12_from_ints(k["start"]).reshape(1, 48)
+    nxt = start.copy()
+    for _ in range(100):
+        nxt = eng.gt_mul_batch(nxt, start)
+    cpy = nxt.copy()
+    for _ in range(10):
+        nxt = eng.gt_mul_batch(nxt, nxt)
+    for _ in range(10):
+        nxt = oracle.fq12_neg(oracle.fq12_sub(oracle.fq12_add(nxt[0], start[0]), cpy[0])).reshape(1, 48)
+    nxt = eng.gt_mul_batch(nxt, nxt)
+    assert oracle.fq12_to_ints(nxt[0]) == [int(x) for x in k["finally"]]
+    # the same 100-product prefix as ONE batch of 64 copies: every lane pair of a wave agrees
+    b = np.tile(start, (64, 1)); acc = b.copy()
+    for _ in range(100):
+        acc = eng.gt_mul_batch(acc, b)
+    assert (acc == cpy).all()
+
+
+def test_reference_cyclotomic_exp_kat_on_gpu(oracle, kats):
+    """fields/mod.rs:171-201 (test_cyclotomic_exp): orig.exp_by_neg_z() on the device, the reference's operation sequence
+    (bn254_exp_by_neg_z_dev) - the vector is OFF the cyclotomic subgroup, so only that sequence reproduces it"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    k = kats["test_cyclotomic_exp"]
+    te = D.TorchEngine(bn_amd.Engine(0), torch.device("cuda", 0))
+    n = 70                                                          # more than one wave of lane pairs, ragged
+    a = torch.from_numpy(np.tile(oracle.fq12_from_ints(k["orig"]), (n, 1)).view(np.int64)).to(te.device)
+    out = te.empty(n, 48)
+    te.e.exp_by_neg_z_dev(a.data_ptr(), out.data_ptr(), n, te._stream())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    assert oracle.fq12_to_ints(got[0]) == [int(x) for x in k["expected"]]
+    assert (got == got[0]).all()
+    # on a cyclotomic element the engine's own chain (inside the final exponentiation) and this one agree: f^(-u) both ways
+    rng = np.random.default_rng(77)
+    P, Q = _points(oracle, rng, 3)
+    g = te.e.pairing_batch(P, Q)
+    gd = torch.from_numpy(g.view(np.int64)).to(te.device); o2 = te.empty(3, 48)
+    te.e.exp_by_neg_z_dev(gd.data_ptr(), o2.data_ptr(), 3, te._stream())
+    torch.cuda.synchronize()
+    want = np.stack([oracle.fq12_exp_by_neg_z(x) for x in g])
+    assert np.array_equal(o2.cpu().numpy().view(np.uint64), want)
+
+
+def test_options_api(eng):
+    """bn254_ctx_set_option / get_option: defaults derive from the CU count, values are validated, negative restores the default"""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert eng.get_option("wave_pairing_max") == 20 * cus and eng.get_option("wave_fe_max") == 20 * cus
+    assert eng.get_option("round_pairs") == 256 * cus and eng.get_option("pipeline_slots") == 2
+    assert eng.get_option("miller_shared") == 0 and eng.get_option("gt_pow_mode") == 0
+    eng.set_option("wave_pairing_max", 7); assert eng.get_option("wave_pairing_max") == 7
+    eng.set_option("wave_pairing_max", -5); assert eng.get_option("wave_pairing_max") == 20 * cus
+    for name, bad in (("miller_shared", 3), ("gt_pow_mode", 9), ("product_per_wave", 33), ("pipeline_slots", 5), ("product_bfly", 6)):
+        with pytest.raises(Exception):
+            eng.set_option(name, bad)
+    with eng.options(product_chunk=3, pipeline_slots=1):
+        assert eng.get_option("product_chunk") == 3 and eng.get_option("pipeline_slots") == 1
+    assert eng.get_option("product_chunk") == -1 and eng.get_option("pipeline_slots") == 2
+
+
 def test_pairing_batch_matches_oracle(oracle, eng):
     rng = np.random.default_rng(101)
     n = 200                                   # ragged: not a multiple of the wave size
@@ -325,11 +415,8 @@ def test_golden_fixtures_on_gpu(eng, goldens):
     g = goldens
     n = g["k1"].shape[0]
     assert np.array_equal(eng.pairing_batch(g["g1"], g["g2"]), g["gt"])                    # a batch this small: one pairing per wave
-    os.environ["BN254_WAVE_PAIRING_MAX"] = "0"; os.environ["BN254_WAVE_FE_MAX"] = "0"
-    try:
+    with eng.options(wave_pairing_max=0, wave_fe_max=0, quad_max=0):
         assert np.array_equal(eng.pairing_batch(g["g1"], g["g2"]), g["gt"])                # and through the lane-pair kernels
-    finally:
-        os.environ.pop("BN254_WAVE_PAIRING_MAX"); os.environ.pop("BN254_WAVE_FE_MAX")
     one1 = np.tile(g["g1"][0], (n, 1)); one2 = np.tile(g["g2"][10], (n, 1))          # scalars1[0] == scalars2[10] == 1: the generators
     assert int(g["scalars1"][0]) == 1 and int(g["scalars2"][10]) == 1
     assert np.array_equal(eng.g1_mul_batch(one1, g["k1"]), g["g1"]) and np.array_equal(eng.g2_mul_batch(one2, g["k2"]), g["g2"])
@@ -881,7 +968,7 @@ def test_gt_pow_mixed_subgroup_membership(oracle, eng):
 @pytest.mark.parametrize("m", [2, 4])
 def test_shared_accumulator_miller_kernels(oracle, m):
     """bn254_miller_shared{2,4}_B (m pairs per lane pair on one accumulator; chosen by the host from two / four machine rounds of pairs
-    on, forced here by BN254_MILLER_SHARED): ragged sizes (not a multiple of m), infinite pairs, and 5000 pairs against the oracle's
+    on, forced here by BN254_OPT_MILLER_SHARED): ragged sizes (not a multiple of m), infinite pairs, and 5000 pairs against the oracle's
     fold; equal to the plain path bit for bit"""
     import os
     import bn_amd
@@ -892,17 +979,15 @@ def test_shared_accumulator_miller_kernels(oracle, m):
     P = np.tile(te_p, (reps, 1))[:n].copy(); Q = np.tile(te_q, (reps, 1))[:n].copy()       # 64 distinct pairs, repeated
     P[7] = oracle.g1_zero(); Q[4000] = oracle.g2_zero(); P[n - 1] = oracle.g1_zero()
     e = bn_amd.Engine(0)
-    os.environ["BN254_MILLER_SHARED"] = "1"
-    os.environ["BN254_WAVE_PAIRING_MAX"] = "0"                   # 5003 pairs would otherwise run one per wave (bn_wave_pairing_max)
-    try:
+    # 5003 pairs would otherwise run one per wave (BN254_OPT_WAVE_PAIRING_MAX) or four lanes per pairing (BN254_OPT_QUAD_MAX)
+    with e.options(miller_shared=1, wave_pairing_max=0, quad_max=0):
         plain = e.pairing_product(P, Q)
-        os.environ["BN254_MILLER_SHARED"] = str(m)
+        e.set_option("miller_shared", m)
         e.profile(True); e.profile_reset()
         shared = e.pairing_product(P, Q)
         assert e.kernel_stats("miller_shared")[1] >= 1 and e.kernel_stats("miller")[1] == 0
         e.profile(False)
-    finally:
-        os.environ.pop("BN254_MILLER_SHARED", None); os.environ.pop("BN254_WAVE_PAIRING_MAX", None)
+    assert e.get_option("miller_shared") == 0
     assert np.array_equal(plain, shared)
     assert np.array_equal(shared, oracle.pairing_product(P, Q))
     e.close()
@@ -927,19 +1012,13 @@ def test_rccl_exchange_between_distinct_gpus(oracle):
     want_b = oracle.pairing_batch(P, Q); want_p = oracle.pairing_product(P, Q)
     devs = list(range(min(_gpu_count(), 8)))
     for kind in ("rccl", "peer"):
-        old = os.environ.get("BN254_MULTI_EXCHANGE")
-        os.environ["BN254_MULTI_EXCHANGE"] = kind
-        try:
-            m = bn_amd.MultiEngine(devs)
-            assert m.exchange == kind
-            assert np.array_equal(m.pairing_batch(P, Q), want_b), kind
-            for _ in range(3):
-                assert np.array_equal(m.pairing_product(P, Q), want_p), kind
-            assert np.array_equal(m.pairing_product(P[:1], Q[:1]), oracle.pairing_product(P[:1], Q[:1]))
-            m.close()
-        finally:
-            if old is None: os.environ.pop("BN254_MULTI_EXCHANGE", None)
-            else: os.environ["BN254_MULTI_EXCHANGE"] = old
+        m = bn_amd.MultiEngine(devs, exchange=kind)                  # bn254_multi_create_ex: forced, no fall-back
+        assert m.exchange == kind
+        assert np.array_equal(m.pairing_batch(P, Q), want_b), kind
+        for _ in range(3):
+            assert np.array_equal(m.pairing_product(P, Q), want_p), kind
+        assert np.array_equal(m.pairing_product(P[:1], Q[:1]), oracle.pairing_product(P[:1], Q[:1]))
+        m.close()
 
 
 NCCL_WORKER = r'''
@@ -985,7 +1064,7 @@ def test_sharded_product_over_rccl_world2(oracle, tmp_path):
 
 
 def test_gt_pow_modes(oracle, eng):
-    """Gt::pow's three chains (BN254_GT_POW_MODE): the Frobenius decomposition (default; needs order r, which every value of the
+    """Gt::pow's three chains (BN254_OPT_GT_POW_MODE): the Frobenius decomposition (default; needs order r, which every value of the
     reference's Gt type has), the one-dimensional cyclotomic chain and the general chain agree with fields/mod.rs:35-46 on pairing
     values; a cyclotomic element of another order (the easy part of the final exponentiation applied to an arbitrary Fq12 - not
     constructible through the reference's API) is exact in the strict and general modes"""
@@ -998,10 +1077,10 @@ def test_gt_pow_modes(oracle, eng):
     sv = _scalars(rng, n); sv[:6] = [0, 1, M.R_ORD - 1, M.R_ORD - 2, (1 << 253) + 11, 6 * M.U * M.U % M.R_ORD]
     s = _fr(oracle, sv)
     want = np.stack([oracle.gt_pow(g[i], s[i]) for i in range(n)])
-    old = os.environ.get("BN254_GT_POW_MODE")
     try:
-        for mode in ("0", "2", "1"):
-            os.environ["BN254_GT_POW_MODE"] = mode
+        for mode in (0, 2, 1):
+            eng.set_option("gt_pow_mode", mode)
+            assert eng.get_option("gt_pow_mode") == mode
             assert np.array_equal(eng.gt_pow_batch(g, s), want), mode
         # 20 000 pairing values ^ distinct random scalars: the Frobenius chain against the one-dimensional one, all of them
         import torch
@@ -1011,18 +1090,21 @@ def test_gt_pow_modes(oracle, eng):
         Pd, Qd = D.synthetic_points(te, 777, 777 + big)
         gd = te.pairing_batch(Pd, Qd)
         kd = D.synthetic_scalars_device(te, 1 << 25, (1 << 25) + big, 0)
-        os.environ["BN254_GT_POW_MODE"] = "0"; a = te.gt_pow(gd, kd); torch.cuda.synchronize()
-        os.environ["BN254_GT_POW_MODE"] = "2"; b = te.gt_pow(gd, kd); torch.cuda.synchronize()
+        eng.set_option("gt_pow_mode", 0); a = te.gt_pow(gd, kd); torch.cuda.synchronize()
+        eng.set_option("gt_pow_mode", 2); b = te.gt_pow(gd, kd); torch.cuda.synchronize()
         assert torch.equal(a, b)
         raw = oracle.miller_only(P[0], Q[0])
         # f^(q^6 - 1) then ^(q^2 + 1): cyclotomic, but of order dividing (q^4 - q^2 + 1), not r
         cyc = oracle.fq12_final_exp_first_chunk(raw)              # fq12.rs:41-52
         batch = np.tile(cyc, (4, 1))
-        for mode in ("2", "1"):
-            os.environ["BN254_GT_POW_MODE"] = mode
+        for mode in (2, 1):
+            eng.set_option("gt_pow_mode", mode)
             got = eng.gt_pow_batch(batch, s[6:10])
             for i in range(4):
                 assert np.array_equal(got[i], oracle.gt_pow(cyc, s[6 + i])), (mode, i)
+        # the option is validated: 3 is no mode
+        with pytest.raises(Exception):
+            eng.set_option("gt_pow_mode", 3)
     finally:
-        if old is None: os.environ.pop("BN254_GT_POW_MODE", None)
-        else: os.environ["BN254_GT_POW_MODE"] = old
+        eng.set_option("gt_pow_mode", None)
+        assert eng.get_option("gt_pow_mode") == 0

@@ -2,8 +2,6 @@
 latency-bound tails of the path - the single final exponentiation of a multi-pairing, the one-launch product tree with its
 arrival tree across workgroups, the product-then-exponentiate tail of the sharded product.  Everything goes through the C ABI
 and is compared with the CPU oracle bit for bit (run with -m gpu on an MI355X)."""
-import os
-
 import numpy as np
 import pytest
 
@@ -49,17 +47,6 @@ def _fold(oracle, vals):
     return acc
 
 
-class _env:
-    def __init__(self, **kv): self.kv = kv
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update({k: str(v) for k, v in self.kv.items()})
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
-
-
 def test_wave_final_exponentiation_matches_oracle(oracle, kats, te):
     """fq12.rs:41-88 with one Fq12 per wave: arbitrary Fq12 inputs (the easy part maps anything non-zero into the cyclotomic
     subgroup), the reference's own Miller-loop known answer (groups/mod.rs:522-547 -> :773-796), one and several per launch"""
@@ -70,6 +57,11 @@ def test_wave_final_exponentiation_matches_oracle(oracle, kats, te):
         assert np.array_equal(_host(_final_exp_batch(te, _dev(te, vals[:n]))), want[:n]), n
     one = oracle.fq12_one()
     assert np.array_equal(_host(_final_exp_batch(te, _dev(te, one.reshape(1, 48))))[0], one)
+    # literal known answers on both sides, no oracle in between: the Miller value of test_miller_loop -> the Gt of test_reduced_pairing
+    kat_f = oracle.fq12_from_ints(kats["test_miller_loop"]["expected"]).reshape(1, 48)
+    assert te.e.get_option("wave_fe_max") >= 1
+    got = _host(_final_exp_batch(te, _dev(te, kat_f)))[0]
+    assert oracle.fq12_to_ints(got) == [int(x) for x in kats["test_reduced_pairing"]["expected"]]
     # in place, as pairing_batch uses it
     d = _dev(te, vals)
     te.e.final_exp_batch_dev(d.data_ptr(), d.data_ptr(), 9, te._stream())
@@ -77,19 +69,19 @@ def test_wave_final_exponentiation_matches_oracle(oracle, kats, te):
 
 
 def test_wave_and_lane_pair_final_exponentiation_agree(te):
-    """the same 600 Miller values through both kernels (the switch-over is a host-side threshold, BN254_WAVE_FE_MAX)"""
+    """the same 600 Miller values through both kernels (the switch-over is a host-side threshold, BN254_OPT_WAVE_FE_MAX)"""
     import torch
     from bn_amd import distributed as D
     n = 600
     P, Q = D.synthetic_points(te, 5000, 5000 + n)
     f = te.empty(n, 48)
     te.e.miller_batch_dev(P.data_ptr(), Q.data_ptr(), f.data_ptr(), n, te._stream())
-    with _env(BN254_WAVE_FE_MAX=0):
+    with te.e.options(wave_fe_max=0):
         a = _final_exp_batch(te, f); torch.cuda.synchronize()
-    with _env(BN254_WAVE_FE_MAX=4096):
+    with te.e.options(wave_fe_max=4096):
         b = _final_exp_batch(te, f); torch.cuda.synchronize()
     te.e.profile(True); te.e.profile_reset()
-    with _env(BN254_WAVE_FE_MAX=4096):
+    with te.e.options(wave_fe_max=4096):
         _final_exp_batch(te, f[:1].contiguous()); torch.cuda.synchronize()
     assert te.e.kernel_stats("final_exp_wave")[1] == 1 and te.e.kernel_stats("final_exp")[1] == 0
     te.e.profile(False)
@@ -116,7 +108,7 @@ def test_one_launch_product_tree_matches_fold(oracle, te):
     # every shape of the tree the host could pick (bn254_hip.hip product_shape), ragged against each of its three parameters
     want = {m: _fold(oracle, host[:m]) for m in (1, 2, 33, 1000, 4097)}
     for c, L, B in ((1, 2, 0), (3, 5, 1), (2, 32, 3), (7, 12, 2), (1, 32, 5), (4, 1, 0), (2, 3, 5)):
-        with _env(BN254_PRODUCT_CHUNK=c, BN254_PRODUCT_PER_WAVE=L, BN254_PRODUCT_BFLY=B):
+        with te.e.options(product_chunk=c, product_per_wave=L, product_bfly=B):
             for m, w in want.items():
                 assert np.array_equal(_host(te.gt_product(vals[:m].contiguous())), w), (c, L, B, m)
     # the arrival tree is a race by design (first arriver leaves, second continues): the value must not depend on who wins
@@ -137,7 +129,7 @@ def test_product_final_exp_tail(oracle, te):
 def test_wave_pairing_matches_oracle_and_lane_pair_kernels(oracle, te):
     """small batches run the WHOLE pairing per wave (bn254_pairing_W: prologue, Miller loop and final exponentiation as one program):
     against the oracle with the edge cases of groups/mod.rs:764-771 (infinity either side, z = 1), the reference's known answer,
-    and the same 300 pairs through the lane-pair kernels (BN254_WAVE_PAIRING_MAX=0) - both sides of the host's threshold"""
+    and the same 300 pairs through the lane-pair kernels (BN254_OPT_WAVE_PAIRING_MAX = 0) - both sides of the host's threshold"""
     import torch
     import bn_amd
     from bn_amd import distributed as D
@@ -161,24 +153,27 @@ def test_wave_pairing_matches_oracle_and_lane_pair_kernels(oracle, te):
     m = 300
     Pd, Qd = D.synthetic_points(te, 9000, 9000 + m)
     a = te.pairing_batch(Pd, Qd); torch.cuda.synchronize()
-    with _env(BN254_WAVE_PAIRING_MAX=0, BN254_WAVE_FE_MAX=0):
+    with te.e.options(wave_pairing_max=0, wave_fe_max=0, quad_max=0):
         b = te.pairing_batch(Pd, Qd); torch.cuda.synchronize()
     assert torch.equal(a, b)
     Pn = Pd[:8].cpu().numpy().view(np.uint64); Qn = Qd[:8].cpu().numpy().view(np.uint64)
     assert np.array_equal(a[:8].cpu().numpy().view(np.uint64), oracle.pairing_batch(Pn, Qn))
-    # either side of the host's default threshold (bn_wave_pairing_max = 5120: thirteen workgroups per CU, several waves per SIMD)
-    big = 5121
-    Pb, Qb = D.synthetic_points(te, 20000, 20000 + big)
+    # either side of the host's default threshold (BN254_OPT_WAVE_PAIRING_MAX: 20 per CU - thirteen workgroups per CU, several waves per SIMD)
     e2 = te.e
+    thr = e2.get_option("wave_pairing_max")
+    assert thr == 20 * torch.cuda.get_device_properties(0).multi_processor_count
+    big = thr + 1
+    Pb, Qb = D.synthetic_points(te, 20000, 20000 + big)
     e2.profile(True); e2.profile_reset()
-    w = te.pairing_batch(Pb[:5120].contiguous(), Qb[:5120].contiguous()); torch.cuda.synchronize()
+    w = te.pairing_batch(Pb[:thr].contiguous(), Qb[:thr].contiguous()); torch.cuda.synchronize()
     assert e2.kernel_stats("pairing_wave")[1] == 1 and e2.kernel_stats("miller")[1] == 0
     e2.profile_reset()
-    l = te.pairing_batch(Pb, Qb); torch.cuda.synchronize()
+    with e2.options(quad_max=0):                                 # (the four-lane kernels have their own test)
+        l = te.pairing_batch(Pb, Qb); torch.cuda.synchronize()
     assert e2.kernel_stats("pairing_wave")[1] == 0 and e2.kernel_stats("miller")[1] == 1
     e2.profile(False)
-    assert torch.equal(w, l[:5120])
-    with _env(BN254_WAVE_PAIRING_MAX=1 << 20, BN254_WAVE_FE_MAX=1 << 20):
+    assert torch.equal(w, l[:thr])
+    with te.e.options(wave_pairing_max=1 << 20, wave_fe_max=1 << 20):
         assert torch.equal(te.pairing_batch(Pb, Qb), l)
 
 

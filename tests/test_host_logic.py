@@ -205,4 +205,7 @@ def test_bench_relaunches_itself_for_multi_gpu():
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: covered by the gpu-marked bench test")
     assert out.returncode != 0
-    assert out.stderr.count("bench.py needs an MI355X") >= 2, out.stderr[-1500:]
+    # torchrun kills the other rank as soon as the first one exits, so only one of them is sure to print its message; that the
+    # second rank existed is in torchrun's own failure report
+    assert out.stderr.count("bench.py needs an MI355X") >= 1, out.stderr[-1500:]
+    assert out.stderr.count("bench.py needs an MI355X") >= 2 or "local_rank: 1" in out.stderr, out.stderr[-1500:]

@@ -28,7 +28,7 @@ f = te.pairing_batch(P, Q)
 one = te.empty(48); ref = te.empty(48)
 res = {}
 for n in (2, 8, 32, 256, 1024, 4096, 1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18):
-    for k in ("CHUNK", "PER_WAVE", "BFLY"): os.environ.pop("BN254_PRODUCT_" + k, None)
+    for k in ("chunk", "per_wave", "bfly"): te.e.set_option("product_" + k, None)
     te.e.gt_product_dev(f.data_ptr(), n, ref.data_ptr(), te._stream()); torch.cuda.synchronize()
     base = timed(lambda: te.e.gt_product_dev(f.data_ptr(), n, one.data_ptr(), te._stream()))
     rows = []
@@ -39,7 +39,7 @@ for n in (2, 8, 32, 256, 1024, 4096, 1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18
             if -(-groups // L) > 16384: continue
             for B in (0, 1, 2, 3):
                 if B and L < (2 << B): continue
-                os.environ["BN254_PRODUCT_CHUNK"] = str(c); os.environ["BN254_PRODUCT_PER_WAVE"] = str(L); os.environ["BN254_PRODUCT_BFLY"] = str(B)
+                te.e.set_option("product_chunk", c); te.e.set_option("product_per_wave", L); te.e.set_option("product_bfly", B)
                 t = timed(lambda: te.e.gt_product_dev(f.data_ptr(), n, one.data_ptr(), te._stream()))
                 torch.cuda.synchronize()
                 assert torch.equal(one, ref), (n, c, L, B)

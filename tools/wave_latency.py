@@ -29,10 +29,10 @@ out = te.empty(nmax, 48)
 for n in (1, 8, 64, 256, 1024, 2048, 4096, 6144, 8192):
     row = {}
     for name, thr in (("wave", 1 << 20), ("lane_pair", 0)):
-        os.environ["BN254_WAVE_FE_MAX"] = str(thr)
+        te.e.set_option("wave_fe_max", thr)
         row[name] = timed(lambda: te.e.final_exp_batch_dev(f.data_ptr(), out.data_ptr(), n, te._stream()), reps=10)
     res["final_exp_ms"][n] = row
-os.environ.pop("BN254_WAVE_FE_MAX")
+te.e.set_option("wave_fe_max", None)
 one = te.empty(48)
 for n in (32, 1024, 1 << 15, 1 << 16, 1 << 18):
     res["product_tree_ms"][n] = timed(lambda: te.e.gt_product_dev(f.data_ptr(), n, one.data_ptr(), te._stream()), reps=10)
@@ -41,9 +41,9 @@ for m in (1, 2, 8, 64):
 # whole multi-pairing on one GPU: 2^15 and 2^18 pairs (BASELINE configs[3] per-GPU shard and total)
 res["pairing_product_ms"] = {n: timed(lambda: D.pairing_product_sharded(te, P[:n], Q[:n]), reps=5, warm=2) for n in (1, 4, 1 << 15, 1 << 18)}
 for name, thr in (("wave", 1 << 20), ("lane_pair", 0)):
-    os.environ["BN254_WAVE_PAIRING_MAX"] = str(thr); os.environ["BN254_WAVE_FE_MAX"] = str(1024 if thr else 0)
+    te.e.set_option("wave_pairing_max", thr); te.e.set_option("wave_fe_max", 1024 if thr else 0); te.e.set_option("quad_max", 0)
     res.setdefault("pairing_batch_ms", {})[name] = {n: timed(lambda: te.e.pairing_batch_dev(P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 4, 64, 256, 768, 1024, 2048, 3072, 4096, 6144)}
-os.environ.pop("BN254_WAVE_PAIRING_MAX"); os.environ.pop("BN254_WAVE_FE_MAX")
+for k in ("wave_pairing_max", "wave_fe_max", "quad_max"): te.e.set_option(k, None)
 res["miller_only_ms"] = {n: timed(lambda: te.e.miller_batch_dev(P.data_ptr(), Q.data_ptr(), f.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 1 << 15, 1 << 16)}
 # by-value pairing through the host-buffer API (what `pairing(p, q)` of lib.rs:181-183 costs a caller)
 e = bn_amd.Engine(0)
