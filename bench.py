@@ -114,6 +114,25 @@ def measured_peak(eng):
     return _PEAK["v"]
 
 
+_TRAFFIC = None
+
+
+def traffic_of(kernel, units):
+    """HBM traffic of `units` units through `kernel` (a name of bn254_kernel_stats), from the rocprofv3 --pmc passes summarised in
+    profiles/pmc_traffic.json (tools/summarize_pmc_all.py: (2 x FETCH_SIZE + WRITE_SIZE) per launch / units of that launch - a SEPARATE
+    run, never this one), beside the algorithmic bytes (the reference's structs in and out) and their ratio; None if never measured"""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        tf = ROOT / "profiles" / "pmc_traffic.json"
+        _TRAFFIC = json.loads(tf.read_text()) if tf.exists() else {}
+    e = _TRAFFIC.get(kernel)
+    if not e or "hbm_bytes_per_unit" not in e:
+        return None
+    return {"traffic": e["hbm_bytes_per_unit"] * units, "algorithmic_bytes": e["algorithmic_bytes_per_unit"] * units,
+            "traffic_ratio": e["hbm_bytes_per_unit"] / e["algorithmic_bytes_per_unit"], "traffic_measured_at_units_per_launch": e["units_per_launch"],
+            "traffic_source": e["source"] + " (separate rocprofv3 --pmc run, NOT this run; per unit x the units of this line's launches)"}
+
+
 def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=None, steps=1, ref_mac32_per_unit=None):
     """roofline object for the dominant kernel among `stats` = {name: (total_ms, launches)}.  Each kernel processed `unit_count` units
     per step (a step may be several sub-launches of one machine round: bn_sub_launch in csrc/bn254_hip.hip) over `steps` recorded
@@ -125,12 +144,12 @@ def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=No
         share = shares.get(k, 1.0) if shares else 1.0
         ach = unit_count * steps * mac32_per_unit * share / (ms * 1e-3) / 1e12
         per[k] = {"avg_launch_ms": ms / cnt, "launches": cnt, "ms_per_step": ms / steps, "achieved": ach, "frac": ach / peak8}
-    traffic, src = None, None
-    tf = ROOT / "profiles" / "pmc_traffic.json"
-    if traffic_key and tf.exists():
-        ent = json.loads(tf.read_text()).get(dom, {})
-        traffic = ent.get("hbm_bytes_per_launch")
-        src = (ent.get("source", "profiles/pmc_traffic.json") + " (separate rocprofv3 --pmc run at 2^16 pairings per launch, NOT this run)") if traffic else None
+        t = traffic_of(k, unit_count * steps / cnt)                       # EVERY kernel of the line carries its traffic story, per launch
+        if t:
+            per[k].update({"traffic": t["traffic"], "algorithmic_bytes": t["algorithmic_bytes"], "traffic_ratio": t["traffic_ratio"],
+                           "hbm_GBps": t["traffic"] / (ms / cnt * 1e-3) / 1e9})
+    td = traffic_of(dom, unit_count * steps / stats[dom][1])
+    traffic, src = (td["traffic"], td["traffic_source"]) if td else (None, None)
     d = per[dom]
     out = {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": d["achieved"], "peak": peak8,
            "unit": "TMAC32/s", "frac": d["frac"],
@@ -138,6 +157,9 @@ def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=No
            "peak_source": "bn254_ubench_mac32 in this run: pure v_mad_u64_u32 stream, 8 waves/SIMD",
            "peak_at_kernel_occupancy": peak2, "kernel_occupancy_waves_per_simd": 2, "frac_of_occupancy_peak": d["achieved"] / peak2,
            "traffic": traffic, "traffic_source": src, "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"], "kernels": per}
+    if all("traffic" in v for v in per.values()):
+        # the whole step: what all kernels of the line move per step against the algorithmic bytes of the step (inputs in, results out once)
+        out["traffic_per_step_all_kernels"] = sum(v["traffic"] * v["launches"] / steps for v in per.values())
     if ref_mac32_per_unit:
         out["frac_vs_reference_chain"] = d["frac"] * ref_mac32_per_unit / mac32_per_unit
         out["frac_is"] = ("over the Fq products of the chain this kernel EXECUTES (profiles/executed_chain_lengths.json); frac_vs_reference_chain "
@@ -259,7 +281,14 @@ def run_product(eng, dev, dist, P, Q, steps, warmup):
     elapsed = timed_steps(dist, dev, step, steps, warmup)
     ks = min(steps, 3)
     st = kernel_times(eng, dev, step, PRODUCT_KERNELS, ks)
-    return elapsed, {k: v[0] / ks for k, v in st.items()}
+    n = P.shape[0]
+    tr = {}
+    for k, (ms, cnt) in st.items():                     # the Miller kernels (units = pairs) carry the traffic of a product; tree and tail are < 2 %
+        t = traffic_of(k, n) if k.startswith("miller") else None
+        if t:
+            tr[k] = {"traffic_per_step": t["traffic"], "algorithmic_bytes_per_step": t["algorithmic_bytes"], "traffic_ratio": t["traffic_ratio"],
+                     "hbm_GBps": t["traffic"] / (ms / ks * 1e-3) / 1e9}
+    return elapsed, {k: v[0] / ks for k, v in st.items()}, tr
 
 
 def bench_product(args, eng, dev, world, rank):
@@ -270,12 +299,12 @@ def bench_product(args, eng, dev, world, rank):
     from bn_amd import distributed as D
     lo, hi = D.shard_range(PRODUCT_TOTAL, rank, world)
     P, Q = D.synthetic_points(eng, lo, hi)
-    elapsed, kms = run_product(eng, dev, dist, P, Q, args.steps, args.warmup)
+    elapsed, kms, ktr = run_product(eng, dev, dist, P, Q, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps(_line("BN254 pairs/sec folded into one multi-pairing product (bit-exact vs ref)", "pairs/s",
                                PRODUCT_TOTAL * args.steps / elapsed, world, args, elapsed, "strong",
                                f"product of 2^18 pairs -> 1 Gt, {hi - lo} pairs per GPU (BASELINE.json configs[3]); all_gather of 384 B per rank",
-                               {"kernel_ms_per_step": kms}, {"process_group": (dist.get_backend() if dist.is_initialized() else None)})), flush=True)
+                               {"kernel_ms_per_step": kms, "kernel_traffic": ktr, "expected_scaling": expected_scaling("product", world)}, {"process_group": (dist.get_backend() if dist.is_initialized() else None)})), flush=True)
 
 
 def bench_prepared(args, eng, dev, world, rank):
@@ -306,12 +335,13 @@ def side_object(eng, dev, dist, P16, Q16):
     n = 1 << 20
     elapsed, rf = run_mul(eng, dev, dist, 1, n, 0, 3, 1)
     side["g1mul_2_20"] = {"config": "BASELINE.json configs[4]: 2^20 G1 scalar muls by random Fr, 1 MI355X", "value": n * 3 / elapsed, "unit": "scalar muls/s",
-                          "ms_per_step": elapsed / 3 * 1e3, "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "frac_vs_reference_chain", "avg_launch_ms")}}
+                          "ms_per_step": elapsed / 3 * 1e3, "roofline": dict({k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "frac_vs_reference_chain", "avg_launch_ms", "traffic", "traffic_source")},
+                                           **{k: rf["kernels"]["g1_mul"].get(k) for k in ("algorithmic_bytes", "traffic_ratio", "hbm_GBps")})}
     P, Q = D.synthetic_points(eng, 0, PRODUCT_TOTAL)
     for tag, m, what in (("product_2_18", PRODUCT_TOTAL, "BASELINE.json configs[3] on ONE GPU: multi-pairing product of 2^18 pairs -> 1 Gt"),
                          ("product_2_15", PRODUCT_TOTAL // 8, "the per-GPU shard of configs[3] at 8 GPUs: 2^15 pairs -> 1 Gt (Miller loops, one-launch product tree, one final exponentiation)")):
-        elapsed, kms = run_product(eng, dev, dist, P[:m], Q[:m], 3, 1)
-        side[tag] = {"config": what, "value": m * 3 / elapsed, "unit": "pairs/s", "ms_per_step": elapsed / 3 * 1e3, "kernel_ms_per_step": kms}
+        elapsed, kms, ktr = run_product(eng, dev, dist, P[:m], Q[:m], 3, 1)
+        side[tag] = {"config": what, "value": m * 3 / elapsed, "unit": "pairs/s", "ms_per_step": elapsed / 3 * 1e3, "kernel_ms_per_step": kms, "kernel_traffic": ktr}
     out1 = eng.empty(1, 48)
     step = lambda: eng.pairing_batch(P16[:1], Q16[:1], out1)
     elapsed = timed_steps(dist, dev, step, 20, 3)
@@ -319,6 +349,74 @@ def side_object(eng, dev, dist, P16, Q16):
                               "latency_ms": elapsed / 20 * 1e3,
                               "kernel_ms": {k: v[0] / 5 for k, v in kernel_times(eng, dev, step, ("pairing_wave", "miller", "final_exp_wave", "final_exp"), 5).items()}}
     return side
+
+
+def expected_scaling(workload, world):
+    """The prediction the first multi-GPU run tests, from ONE-GPU measurements only - nothing here was measured on
+    more than one GPU.  configs[2] (independent pairings) has no exchange: a per-GPU shard of 2^20/N is 16/N machine rounds of 2^16
+    pairings at the one-GPU rate, so the model is linear.  configs[3] (one product) is NOT: the per-GPU shard shrinks below what fills
+    the machine - 2^17 pairs still run two pairs per lane pair on a shared accumulator, 2^16 is one plain round, 2^15 is ONE wave per
+    SIMD (0.57 of the two-wave issue rate) - and the product tree, the 384-byte all-gather and the single final exponentiation do
+    not shrink at all."""
+    if workload == "pairing":
+        round_ms = 7.17                                          # one round of 2^16 pairings: BENCH_r03.json / profiles/r04a_bench_line.json
+        ms = (TOTAL_MULTI // world) / BATCH * round_ms
+        return {"ms_per_step": ms, "speedup_vs_1_gpu": float(world), "model": f"{TOTAL_MULTI // world // BATCH} rounds of 2^16 pairings x {round_ms} ms (one-GPU measurement), no exchange: linear",
+                "measured_on": "1 GPU only"}
+    if workload == "product":
+        # Miller part of the shard + one-launch product tree + tail (world-1 products, ONE final exponentiation); all-gather ~0.05 ms
+        parts = {1: (12.74, 0.21, 0.48), 2: (7.1, 0.20, 0.48), 4: (3.81, 0.20, 0.48), 8: (2.45, 0.16, 0.48)}.get(world)
+        if not parts:
+            return None
+        ms = sum(parts) + (0.05 if world > 1 else 0.0)
+        return {"ms_per_step": ms, "speedup_vs_1_gpu": (12.74 + 0.21 + 0.48) / ms,
+                "model": "shard Miller loops %.2f ms (2^18/N pairs: 4, 2, 1 pairs per lane pair at N = 1, 2, 4; one wave per SIMD at N = 8) + product tree %.2f + tail %.2f + all-gather 0.05 "
+                         "(profiles/r03z_side_lines.json, r03j_ab_shared_miller.txt, r04a_ab_traffic_cost.txt)" % parts, "measured_on": "1 GPU only"}
+    return None
+
+
+def bench_multi_c(args):
+    """--mode multi_c: the SAME workloads driven from ONE host process through the C ABI's multi-device entry points
+    (bn254_pairing_batch_multi / bn254_pairing_product_multi: one context, host thread and stream set per GPU, host buffers in and
+    out) - what a Rust / C++ host of north_star links.  PCIe-inclusive by construction (the entry points take host memory), so this
+    line is a different measurement from the default mode's HBM-resident `value` and says so."""
+    import numpy as np
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    if int(os.environ.get("LOCAL_RANK", "0")) != 0:
+        return                                                   # launched under torchrun: one process drives every GPU, the others have nothing to do
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: bn_amd has no CPU path")
+    n_gpus = args.gpus
+    share = os.environ.get("BN254_BENCH_SHARE_GPU") == "1"      # one-GPU box: every rank on device 0 (peer exchange)
+    devices = [0] * n_gpus if share else list(range(n_gpus))
+    dev = torch.device("cuda", 0)
+    eng = D.TorchEngine(bn_amd.Engine(0), dev)
+    product = args.workload == "product"
+    total = PRODUCT_TOTAL if product else (args.batch * n_gpus if args.batch else (BATCH if n_gpus == 1 else TOTAL_MULTI))
+    P, Q = D.synthetic_points(eng, 0, total)
+    Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
+    del P, Q
+    m = bn_amd.MultiEngine(devices)
+    out = np.zeros((total, 48), np.uint64)                       # the caller's result buffer, pages resident
+    step = (lambda: m.pairing_product(Pn, Qn)) if product else (lambda: m.pairing_batch(Pn, Qn, out))
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    exp = expected_scaling("product" if product else "pairing", n_gpus) if total in (TOTAL_MULTI, PRODUCT_TOTAL) else None
+    line = _line(("BN254 pairs/sec folded into one multi-pairing product" if product else "BN254 optimal-ate pairings/sec") + " (bit-exact vs ref)",
+                 "pairs/s" if product else "pairings/s", total * args.steps / elapsed, n_gpus, args, elapsed, "strong" if n_gpus > 1 else "weak",
+                 (f"product of 2^18 pairs -> 1 Gt (BASELINE.json configs[3])" if product else f"{total} independent pairings per step (BASELINE.json configs[{1 if n_gpus == 1 else 2}])")
+                 + f" over {n_gpus} GPU(s) from ONE host process: bn254_{'pairing_product' if product else 'pairing_batch'}_multi, pageable host buffers in and out (PCIe INCLUSIVE)",
+                 {"mode": "multi_c", "pcie_inclusive": True, "expected_scaling_kernels_only": exp},
+                 {"devices": devices, "exchange": m.exchange, "rank_numa_nodes": m.numa_nodes, "host_threads": n_gpus,
+                  "bytes_per_step": {"h2d": total * 288, "d2h": 384 if product else total * 384}})
+    m.close()
+    print(json.dumps(line), flush=True)
 
 
 def relaunch_under_torchrun(n):
@@ -343,8 +441,13 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the `side` object (configs[3], configs[4], single-pairing latency) of the default line")
     ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product"], default="pairing",
                     help="pairing: the headline metric (default); the others are side metrics with their own line")
+    ap.add_argument("--mode", choices=["dist", "multi_c"], default="dist",
+                    help="dist (default, what the driver runs): one process per GPU over torch.distributed/RCCL, inputs resident in HBM; "
+                         "multi_c: ONE host process drives all GPUs through bn254_*_multi of the C ABI (host buffers, PCIe inclusive)")
     args = ap.parse_args()
 
+    if args.mode == "multi_c":
+        return bench_multi_c(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_under_torchrun(args.gpus))
 
@@ -419,12 +522,14 @@ def main():
             rf = roofline(eng, stats, n, MAC32_PER_PAIRING, dict(KERNEL_SHARE, final_exp_wave=KERNEL_SHARE["final_exp"], pairing_wave=1.0), traffic_key=True, steps=ksteps)
             rf["algorithmic_hbm_bytes_per_launch"] = n * ALGO_BYTES_PER_PAIRING
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            if n != BATCH or cus != 256:
-                rf["traffic"] = rf["traffic_source"] = None          # the PMC figures in profiles/ were taken at 2^16 per launch on 256 CUs
+            if cus != 256:
+                rf["traffic"] = rf["traffic_source"] = None          # the PMC figures in profiles/ were taken on 256 CUs (launch shapes differ elsewhere)
             if rf["traffic"] is not None:
                 rf["hbm_GBps_of_8000"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+            if "traffic_per_step_all_kernels" in rf:
+                rf["traffic_ratio_whole_step"] = rf["traffic_per_step_all_kernels"] / (n * ALGO_BYTES_PER_PAIRING)
             line = _line("BN254 optimal-ate pairings/sec (bit-exact vs ref)", "pairings/s", total * args.steps / elapsed, world, args, elapsed,
-                         scaling, workload, {"roofline": rf},
+                         scaling, workload, {"roofline": rf, **({"expected_scaling": expected_scaling("pairing", world)} if world > 1 and args.batch is None else {})},
                          {"pairings_per_gpu": n, "inputs": "r*G1 / s*G2 (Jacobian, z != 1) resident in HBM", "parallelism": f"dp{world} (sharded, no collective)",
                           "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
                           "mapping": 1 if args.mapping is None else args.mapping,

@@ -53,6 +53,7 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_multi_destroy": [_VP],
     "bn254_multi_device_count": [_VP],
     "bn254_multi_exchange_kind": [_VP],
+    "bn254_multi_rank_numa_node": [_VP, C.c_int],
     "bn254_multi_ctx": [_VP, C.c_int],
     "bn254_pairing_batch_multi": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_pairing_product_multi": [_VP, _VP, _VP, _SZ, _VP],

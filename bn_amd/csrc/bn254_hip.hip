@@ -234,13 +234,14 @@ int bn_get_ctx(bn254_ctx *&ctx) {
 // The ONLY place this library reads its debug environment (BN254_RCCL_PATH, a file path, is read where RCCL is loaded): once per
 // process, into the seed values every new context starts from.
 namespace {
-struct DebugEnv { long opt[BN254_OPT_COUNT_]; int exchange; };
+struct DebugEnv { long opt[BN254_OPT_COUNT_]; int exchange; bool affinity; };
 const DebugEnv &bn_debug_env() {
     static DebugEnv env;
     static std::once_flag once;
     std::call_once(once, [] {
         for (long &v : env.opt) v = -1;
         env.exchange = BN254_EXCHANGE_AUTO;
+        env.affinity = true;
         static const struct { const char *name; int key; } vars[] = {
             {"BN254_WAVE_PAIRING_MAX", BN254_OPT_WAVE_PAIRING_MAX}, {"BN254_WAVE_FE_MAX", BN254_OPT_WAVE_FE_MAX}, {"BN254_QUAD_MAX", BN254_OPT_QUAD_MAX},
             {"BN254_MILLER_SHARED", BN254_OPT_MILLER_SHARED}, {"BN254_GT_POW_MODE", BN254_OPT_GT_POW_MODE}, {"BN254_PRODUCT_CHUNK", BN254_OPT_PRODUCT_CHUNK},
@@ -248,6 +249,7 @@ const DebugEnv &bn_debug_env() {
             {"BN254_PIPELINE_CHUNK", BN254_OPT_PIPELINE_CHUNK}, {"BN254_PIPELINE_SLOTS", BN254_OPT_PIPELINE_SLOTS}};
         for (const auto &v : vars)
             if (const char *e = getenv(v.name)) { const long x = atol(e); if (x >= 0) env.opt[v.key] = x; }
+        if (const char *e = getenv("BN254_MULTI_AFFINITY")) env.affinity = atoi(e) != 0;
         if (const char *e = getenv("BN254_MULTI_EXCHANGE")) env.exchange = !strcmp(e, "peer") ? BN254_EXCHANGE_PEER : !strcmp(e, "rccl") ? BN254_EXCHANGE_RCCL : BN254_EXCHANGE_AUTO;
     });
     return env;
@@ -268,6 +270,7 @@ bool bn_opt_valid(int key, long v) {
 }
 }  // namespace
 int bn_debug_multi_exchange() { return bn_debug_env().exchange; }
+bool bn_debug_multi_affinity() { return bn_debug_env().affinity; }
 long bn_opt(const bn254_ctx *c, int key) {
     const long v = c->opt[key].load(std::memory_order_relaxed);
     if (v >= 0) return v;

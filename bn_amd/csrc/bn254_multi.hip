@@ -10,10 +10,14 @@
 //     and the on-device generator of the synthetic Fr scalars (SplitMix64 -> 512 bits -> mod r -> Montgomery form).
 // RCCL is resolved with dlopen at the first multi-device call, so the library itself has no link-time dependency on it.
 #include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -185,7 +189,54 @@ Rccl &rccl() {
 
 }  // namespace
 
+// ---- host-thread placement: the thread that drives a rank (pageable H2D / D2H copies, launches) runs on the CPUs of that GPU's NUMA
+// node when the node is known (/sys/bus/pci/devices/<bus id>/numa_node) and the process may use some of its CPUs; otherwise it is
+// left alone.  Eight ranks driven from one process otherwise all stage their copies from whatever node the caller happens to run on.
+struct RankCpus { int node = -1; cpu_set_t set; bool valid = false; };
+static RankCpus rank_cpus_of_device(int dev) {
+    RankCpus r; CPU_ZERO(&r.set);
+    char bus[64] = {};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) return r;
+    for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return r;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node); fclose(f);
+    if (got != 1 || node < 0) return r;
+    r.node = node;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    if (!(f = fopen(path, "r"))) return r;
+    char list[4096] = {};
+    const bool have = fgets(list, sizeof list, f) != nullptr; fclose(f);
+    if (!have) return r;
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {                 // "0-15,128-143"
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k < 1) continue;
+        if (k == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0) CPU_SET(c, &r.set);
+    }
+    cpu_set_t cur;
+    if (sched_getaffinity(0, sizeof cur, &cur) == 0) CPU_AND(&r.set, &r.set, &cur);
+    r.valid = CPU_COUNT(&r.set) > 0;
+    return r;
+}
+// pins the CURRENT thread for the lifetime of the object (worker threads end with it; the caller's thread - rank 0 runs there -
+// gets its old mask back)
+struct BnAffinityScope {
+    cpu_set_t old; bool restore = false;
+    explicit BnAffinityScope(const RankCpus &rc) {
+        if (!rc.valid) return;
+        if (pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;
+        restore = pthread_setaffinity_np(pthread_self(), sizeof rc.set, &rc.set) == 0;
+    }
+    ~BnAffinityScope() { if (restore) pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
+};
+
 struct bn254_multi {
+    std::vector<RankCpus> cpus;             // per rank: the CPUs of its GPU's NUMA node (valid = false: no pinning)
     std::vector<int> devices;
     std::vector<bn254_ctx *> ctx;
     std::vector<ncclComm_t> comms;          // one per rank when the exchange is RCCL
@@ -236,6 +287,7 @@ static int multi_create(const int *devices, int ndev, int exchange, bn254_multi 
         if (rc) { bn254_multi_destroy(m); return rc; }
         m->devices.push_back(d);
         m->ctx.push_back(c);
+        m->cpus.push_back(bn_debug_multi_affinity() ? rank_cpus_of_device(d) : RankCpus{});
     }
     m->d_partial.resize(ndev); m->d_gather.resize(ndev);
     for (int g = 0; g < ndev; ++g) {
@@ -274,6 +326,9 @@ void bn254_multi_destroy(bn254_multi *m) {
     delete m;
 }
 int bn254_multi_device_count(const bn254_multi *m) { return m ? (int)m->devices.size() : 0; }
+int bn254_multi_rank_numa_node(const bn254_multi *m, int rank) {
+    return (m && rank >= 0 && rank < (int)m->cpus.size() && m->cpus[(size_t)rank].valid) ? m->cpus[(size_t)rank].node : -1;
+}
 int bn254_multi_exchange_kind(const bn254_multi *m) { return m ? m->exchange : BN254_E_BAD_ARG; }
 bn254_ctx *bn254_multi_ctx(bn254_multi *m, int rank) { return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[rank] : nullptr; }
 
@@ -286,6 +341,7 @@ static int pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, b
     const size_t G = m->ctx.size();
     std::vector<int> rcs(G, BN254_OK);
     run_workers((int)G, [&](int g) {
+        BnAffinityScope pin(m->cpus[(size_t)g]);
         const size_t lo = n * (size_t)g / G, hi = n * ((size_t)g + 1) / G;
         rcs[g] = bn254_pairing_batch(m->ctx[g], p + lo, q + lo, out + lo, hi - lo);
     });
@@ -315,7 +371,7 @@ static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q,
         HIP_TRY(hipStreamSynchronize(c->stream));
         return BN254_OK;
     };
-    run_workers((int)G, [&](int g) { rcs[g] = local((size_t)g); });
+    run_workers((int)G, [&](int g) { BnAffinityScope pin(m->cpus[(size_t)g]); rcs[g] = local((size_t)g); });
     for (int rc : rcs) if (rc) return rc;
     // 2. the ONE exchange step: 384 bytes per rank
     if (m->exchange == BN254_EXCHANGE_RCCL) {

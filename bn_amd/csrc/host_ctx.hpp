@@ -135,6 +135,7 @@ struct BnScope {
 int bn_get_ctx(bn254_ctx *&ctx);                                   // NULL -> the default context of the current device
 long bn_opt(const bn254_ctx *c, int key);                          // EFFECTIVE value of a BN254_OPT_* tunable (defaults from the CU count)
 int bn_debug_multi_exchange();                                     // BN254_EXCHANGE_AUTO unless the debug environment forces one (read once)
+bool bn_debug_multi_affinity();                                    // false only when the debug environment says BN254_MULTI_AFFINITY=0
 // scratch guard: lives across the enqueueing of work that reads/writes ctx->ws / ctx->exp_tbl on stream `s`
 struct BnScratchGuard {
     bn254_ctx *c; hipStream_t s; int rc;

@@ -327,6 +327,11 @@ class MultiEngine:
     def exchange(self):
         return {0: "peer", 1: "rccl"}[self._lib.bn254_multi_exchange_kind(self._h)]
 
+    @property
+    def numa_nodes(self):
+        """per rank: the NUMA node its host thread is pinned to during a call, -1 = not pinned"""
+        return [self._lib.bn254_multi_rank_numa_node(self._h, g) for g in range(len(self.devices))]
+
     def close(self):
         if getattr(self, "_m", None):
             self._lib.bn254_multi_destroy(self._m)
@@ -338,9 +343,12 @@ class MultiEngine:
         except Exception:
             pass
 
-    def pairing_batch(self, p, q):
+    def pairing_batch(self, p, q, out=None):
         p = _arr(p, G1_WORDS); q = _arr(q, G2_WORDS); _same_len(p, q)
-        out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        if out is None:
+            out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        elif out.shape != (p.shape[0], GT_WORDS) or out.dtype != np.uint64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (n,48) uint64 array")
         _native.check(self._lib.bn254_pairing_batch_multi(self._h, _p(p), _p(q), _p(out), p.shape[0]))
         return out
 

@@ -100,7 +100,8 @@ int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping);
    may be changed at any time; a call in flight may see the old or the new value between two of its launches - harmless, because
    every option selects between kernels that return the same bytes (the one exception is stated at BN254_OPT_GT_POW_MODE).
    For experiments only, the variables BN254_WAVE_PAIRING_MAX, BN254_WAVE_FE_MAX, BN254_QUAD_MAX, BN254_MILLER_SHARED, BN254_GT_POW_MODE,
-   BN254_PRODUCT_CHUNK / _PER_WAVE / _BFLY, BN254_ROUND_PAIRS, BN254_PIPELINE_CHUNK / _SLOTS and BN254_MULTI_EXCHANGE (rccl | peer) are
+   BN254_PRODUCT_CHUNK / _PER_WAVE / _BFLY, BN254_ROUND_PAIRS, BN254_PIPELINE_CHUNK / _SLOTS, BN254_MULTI_EXCHANGE (rccl | peer) and
+   BN254_MULTI_AFFINITY (0: no thread pinning) are
    read ONCE per process, when the first context is created, and seed the options of every context created afterwards. */
 enum {
     BN254_OPT_WAVE_PAIRING_MAX = 1, /* pairings (or Miller loops that only meet a final exponentiation) per call up to which ONE PER WAVE
@@ -174,6 +175,10 @@ int bn254_multi_set_option(bn254_multi *m, int key, long value);
 void bn254_multi_destroy(bn254_multi *m);
 int bn254_multi_device_count(const bn254_multi *m);
 int bn254_multi_exchange_kind(const bn254_multi *m);                 /* BN254_EXCHANGE_* */
+/* The host thread that drives a rank (its pageable H2D / D2H copies and launches) is pinned, for the duration of a call, to the CPUs
+   of that GPU's NUMA node when the node is known (/sys/bus/pci/devices/<bus id>/numa_node) and the process may run there; the
+   caller's own thread gets its mask back.  Returns that node, or -1 when the rank's thread is not pinned. */
+int bn254_multi_rank_numa_node(const bn254_multi *m, int rank);
 bn254_ctx *bn254_multi_ctx(bn254_multi *m, int rank);                /* rank's context (owned by m) */
 /* out[i] = pairing(p[i], q[i]); rank g owns the contiguous shard [n*g/G, n*(g+1)/G); no exchange (BASELINE configs[2]) */
 int bn254_pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn_gt *out, size_t n);

@@ -725,6 +725,29 @@ def test_bench_multi_rank_control_flow(tmp_path):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["peak"] > 0 and "frac" in d["roofline"]
 
 
+@pytest.mark.parametrize("workload", ["pairing", "product"])
+def test_bench_multi_c_mode(workload):
+    """`bench.py --mode multi_c`: ONE host process drives N ranks through bn254_*_multi of the C ABI (here two ranks on the one GPU);
+    the line says what it measured (PCIe inclusive), carries the prediction for the real multi-GPU run and the ranks' NUMA nodes"""
+    import json, os, pathlib, subprocess, sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = dict(os.environ, BN254_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(root / "bench.py"), "--mode", "multi_c", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload]
+    if workload == "pairing":
+        cmd += ["--batch", "4096"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["mode"] == "multi_c" and d["pcie_inclusive"] is True and d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["devices"] == [0, 0] and d["config"]["exchange"] == "peer" and len(d["config"]["rank_numa_nodes"]) == 2
+    if workload == "product":
+        assert d["expected_scaling_kernels_only"]["speedup_vs_1_gpu"] > 1.5
+
+
 def test_cpp_host_drives_multi_device_entry_points(oracle, tmp_path):
     """a compiled host program (g++, no Python in the loop) on include/bn254.hpp: bn::pairing, Gt::inverse, and bn::MultiGpu with two
     ranks on device 0 - pairing_batch and pairing_product equal the oracle's fold of shootout/main.rs:11-16"""
