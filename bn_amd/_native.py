@@ -7,7 +7,7 @@ import subprocess
 
 HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("BN254_LIB_PATH", HERE / "libbn254_hip.so"))     # override: kernel experiments only
-SOURCES = [HERE / "csrc" / f for f in ("bn254_hip.hip", "bn254_kernels_b.hip", "bn254_kernels_mul.hip", "bn254_kernels_w.hip", "bn254_multi.hip")]
+SOURCES = [HERE / "csrc" / f for f in ("bn254_hip.hip", "bn254_kernels_b.hip", "bn254_kernels_mul.hip", "bn254_kernels_w.hip", "bn254_kernels_q.hip", "bn254_multi.hip")]
 OBJ_DIR = HERE / "csrc" / "build"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -454,7 +454,15 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // lines each) beat the entry-major rows (every lane's 16 bytes from a different 1 KB row: 4x the traffic, profiles/r03m_pmc_side.txt)
 struct PowTableLane {
     uint4 *base;             // this lane's 33 x 2 x 7 vectors
-    __device__ __forceinline__ void st6(int slot, int half, const Fq6<F2> &v) const {
+#ifdef BN_AB_ALIAS_SCRATCH
+    // TIMING EXPERIMENT ONLY (wrong results): the 33 entries of a lane alias entries 0 / 1 of the SAME lane - no lane writes another
+    // lane's lines (aliasing whole tables made thousands of waves fight over the same lines: 3.8 -> 6.9 ms), the footprint is 1/16
+    static __device__ __forceinline__ int alias(int slot) { return slot & 1; }
+#else
+    static __device__ __forceinline__ int alias(int slot) { return slot; }
+#endif
+    __device__ __forceinline__ void st6(int slot_, int half, const Fq6<F2> &v) const {
+        const int slot = alias(slot_);
         uint4 *p = base + (uint32_t)(slot * 2 + half) * 7u;
         uint32_t w[28];
 #pragma unroll
@@ -463,7 +471,8 @@ struct PowTableLane {
 #pragma unroll
         for (int g = 0; g < 7; ++g) p[g] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
     }
-    __device__ __forceinline__ Fq6<F2> ld6(int slot, int half) const {
+    __device__ __forceinline__ Fq6<F2> ld6(int slot_, int half) const {
+        const int slot = alias(slot_);
         const uint4 *p = base + (uint32_t)(slot * 2 + half) * 7u;
         uint32_t w[28];
 #pragma unroll
@@ -507,11 +516,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 #ifdef BN_POW_TABLE_ENTRY_MAJOR
     PowTable tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
 #else
-#ifdef BN_AB_ALIAS_SCRATCH
-    PowTable tbl = {(uint4 *)table + (size_t)(t & 63u) * (POW_TABLE_DWORDS_PER_LANE / 4)};       // timing experiment: 64 lanes' tables (475 KB) for everybody
-#else
     PowTable tbl = {(uint4 *)table + (size_t)t * (POW_TABLE_DWORDS_PER_LANE / 4)};
-#endif
 #endif
     const Fq12<F2> base = f12_load<F2>(a + 96u * pair);
     Fq12<F2> res;

@@ -41,7 +41,7 @@ int bn_no_throw(Fn &&fn) {
 }
 
 #ifndef BN254_HAVE_QUAD
-#define BN254_HAVE_QUAD 0        // the four-lanes-per-pairing kernels (bn254_kernels_q.hip) are linked in
+#define BN254_HAVE_QUAD 1        // the four-lanes-per-pairing kernels (bn254_kernels_q.hip) are linked in
 #endif
 constexpr int BN_MAX_SLOTS = 4;            // chunks in flight in the pipelined host-buffer path (2 used; the rest for experiments)
 
@@ -176,6 +176,10 @@ int bn254_launch_pairing_W(const void *p, const void *q, void *out, size_t n, in
 int bn254_launch_gt_tail_W(const void *in, size_t groups, unsigned m, void *out, int final_exp, hipStream_t s);
 void bn254_gt_reduce_sizes_W(size_t n, unsigned chunk, unsigned per_wave, size_t *grid, size_t *scratch_bytes, size_t *counter_words);
 int bn254_launch_gt_reduce_W(const void *in, size_t n, unsigned chunk, unsigned per_wave, unsigned bfly, void *scratch, void *counters, void *out, hipStream_t s);
+// bn254_kernels_q.hip: one pairing per quad of lanes (quad.hpp)
+int bn254_launch_miller_Q(const void *p, const void *q, void *f, size_t n, hipStream_t s);
+size_t bn254_final_exp_table_bytes_Q(size_t n);
+int bn254_launch_final_exp_Q(const void *f, void *out, size_t n, void *table, hipStream_t s);
 // bn254_kernels_mul.hip
 size_t bn254_mul_table_bytes_M(int g, size_t n);
 int bn254_launch_g1_mul_M(const void *p, const void *k, void *out, size_t n, int normalize, void *table, hipStream_t s);

@@ -253,7 +253,7 @@ int bn254_tile_dev(bn254_ctx *ctx, const void *d_record, size_t record_bytes, si
    accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
 int bn254_profile_enable(bn254_ctx *ctx, int on);
 int bn254_profile_reset(bn254_ctx *ctx);
-/* kernel: "miller", "miller_shared", "miller_wave", "pairing_wave", "final_exp", "final_exp_wave", "gt_product", "gt_tail", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
+/* kernel: "miller", "miller_shared", "miller_wave", "miller_quad", "pairing_wave", "final_exp", "final_exp_wave", "final_exp_quad", "exp_by_neg_z", "gt_product", "gt_tail", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
    Synchronises and consumes the recorded events (totals accumulate until bn254_profile_reset). */
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 /* issue-rate ceiling of v_mad_u64_u32 (the 32x32+64 multiply-accumulate every field product is built from) at

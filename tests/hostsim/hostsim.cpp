@@ -5,9 +5,11 @@
 // This library is never loaded by the product (bn_amd/); it is not a CPU fallback.
 #define BN_HOSTSIM 1
 #include "lanepair.hpp"
+#include "lanequad.hpp"
 #include "../../bn_amd/csrc/io.hpp"
 #include "../../bn_amd/csrc/curve.hpp"
 #include "../../bn_amd/csrc/io_wire.hpp"
+#include "../../bn_amd/csrc/quad.hpp"
 #include <cstring>
 
 using namespace bn254;
@@ -161,6 +163,36 @@ static void hs_add_generic(const uint32_t *a, const uint32_t *b, int negate_b, u
 }
 EXPORT void hs_g1_add(const uint32_t *a, const uint32_t *b, int negate_b, uint32_t *o) { hs_add_generic<FqField, 8>(a, b, negate_b, o, ld1, st1); }
 EXPORT void hsb_g2_add(const uint32_t *a, const uint32_t *b, int negate_b, uint32_t *o) { hs_add_generic<Fq2Field<F2B>, 16>(a, b, negate_b, o, ld2b, st2b); }
+// ---------------------------------------------------------------- four lanes per pairing (quad.hpp) on a simulated quad
+typedef Fq2B<FeQ> F2Q;
+EXPORT void hsq_fq12_sqr(const uint32_t *a, uint32_t *o) { q12_store(q12_sqr(q12_load<F2Q>(a)), o); }
+EXPORT void hsq_fq12_mul(const uint32_t *a, const uint32_t *b, int conj_b, uint32_t *o) { q12_store(q12_mul_half(q12_load<F2Q>(a), q12_load<F2Q>(b).h, conj_b != 0), o); }
+EXPORT void hsq_fq12_cyclotomic_sqr(const uint32_t *a, uint32_t *o) { q12_store(q12_cyclotomic_sqr(q12_load<F2Q>(a)), o); }
+EXPORT void hsq_fq12_inverse(const uint32_t *a, uint32_t *o) { q12_store(q12_inverse(q12_load<F2Q>(a)), o); }
+EXPORT void hsq_fq12_conj(const uint32_t *a, uint32_t *o) { q12_store(q12_conj(q12_load<F2Q>(a)), o); }
+EXPORT void hsq_fq12_frobenius(const uint32_t *a, int p, uint32_t *o) {
+    QFq12<F2Q> f = q12_load<F2Q>(a);
+    q12_store(p == 1 ? q12_frobenius<1>(f) : p == 2 ? q12_frobenius<2>(f) : q12_frobenius<3>(f), o);
+}
+EXPORT void hsq_fq12_mul_by_024(const uint32_t *a, const uint32_t *l0, const uint32_t *lvw, const uint32_t *lvv, uint32_t *o) {
+    q12_store(q12_mul_by_024(q12_load<F2Q>(a), f2_load((F2Q *)0, l0), f2_load((F2Q *)0, lvw), f2_load((F2Q *)0, lvv)), o);
+}
+EXPORT void hsq_final_exponentiation(const uint32_t *a, uint32_t *o) {
+    QuadTableVars<F2Q> tbl;
+    q12_store(q_final_exponentiation(q12_load<F2Q>(a), tbl), o);
+}
+// the whole pairing as the quad kernels run it: prologue on both pairs, NAF Miller loop, final exponentiation
+EXPORT void hsq_pairing(const uint32_t *g1, const uint32_t *g2, int final_exp, uint32_t *o) {
+    bool inf = words_all_zero(g1 + 16, 8) || words_all_zero(g2 + 32, 16);
+    G1Aff<FeQ> p; G2Aff<F2Q> q;
+    pair_prologue<FeQ>(f2_scalar_load((F2Q *)0, g1), f2_scalar_load((F2Q *)0, g1 + 8), f2_scalar_load((F2Q *)0, g1 + 16),
+                       f2_load((F2Q *)0, g2), f2_load((F2Q *)0, g2 + 16), f2_load((F2Q *)0, g2 + 32), p, q);
+    MillerStateVars<F2Q, FeQ> st;
+    QFq12<F2Q> f = q_miller_loop_naf(p, q, st);
+    if (final_exp) { QuadTableVars<F2Q> tbl; f = q_final_exponentiation(f, tbl); }
+    if (inf) f = q12_one<F2Q>();
+    q12_store(f, o);
+}
 // pairing through the NAF Miller schedule (what the pairing kernels run): only the exponentiated value is comparable
 EXPORT void hsb_pairing_naf(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
     bool inf = words_all_zero(g1 + 16, 8) || words_all_zero(g2 + 32, 16);

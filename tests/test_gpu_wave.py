@@ -177,6 +177,62 @@ def test_wave_pairing_matches_oracle_and_lane_pair_kernels(oracle, te):
         assert torch.equal(te.pairing_batch(Pb, Qb), l)
 
 
+def test_quad_kernels_match_oracle_and_lane_pair_kernels(oracle, te, goldens):
+    """four lanes per pairing (bn_amd/csrc/quad.hpp, bn254_kernels_q.hip: Miller loop + final exponentiation, picked by the host between
+    BN254_OPT_WAVE_PAIRING_MAX and BN254_OPT_QUAD_MAX pairings per call): against the oracle with the edge cases of groups/mod.rs:764-771,
+    the committed goldens, and bit for bit against the lane-pair kernels on both sides of both thresholds; the multi-pairing too"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    from bn_oracle import FR
+    e = bn_amd.Engine(0)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert e.get_option("quad_max") == 64 * cus
+    # (1) a ragged small batch forced onto the quad kernels (70 quads: 4.4 waves), edge cases included
+    rng = np.random.default_rng(306)
+    n = 70
+    ks = [oracle.fp_from_int(FR, int.from_bytes(rng.bytes(40), "little") % M.R_ORD) for _ in range(2 * n)]
+    P = oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (n, 1)), np.stack(ks[:n]))
+    Q = oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (n, 1)), np.stack(ks[n:]))
+    P[1] = oracle.g1_zero(); Q[2] = oracle.g2_zero(); P[3] = oracle.g1_zero(); Q[3] = oracle.g2_zero()
+    P[4] = oracle.g1_one(); Q[4] = oracle.g2_one()
+    P[69] = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, M.R_ORD - 1))
+    with e.options(wave_pairing_max=0, wave_fe_max=0):
+        e.profile(True); e.profile_reset()
+        got = e.pairing_batch(P, Q)
+        assert e.kernel_stats("miller_quad")[1] == 1 and e.kernel_stats("final_exp_quad")[1] == 1 and e.kernel_stats("miller")[1] == 0
+        e.profile(False)
+        assert np.array_equal(got, oracle.pairing_batch(P, Q))
+        assert np.array_equal(e.pairing_product(P, Q), oracle.pairing_product(P, Q))      # Miller per quad -> product tree -> one exponentiation
+        g = goldens
+        assert np.array_equal(e.pairing_batch(g["g1"], g["g2"]), g["gt"])                  # the committed fixtures, no oracle involved
+        assert np.array_equal(e.pairing_batch(P[:1], Q[:1]), got[:1])                      # one quad: a quarter... a sixteenth of a wave
+    e.close()
+    # (2) both sides of both thresholds on device-resident inputs: thr_w (wave | quad) and thr_q (quad | lane pair)
+    e2 = te.e
+    thr_w, thr_q = e2.get_option("wave_pairing_max"), e2.get_option("quad_max")
+    Pd, Qd = D.synthetic_points(te, 40000, 40000 + thr_q + 1)
+    with e2.options(quad_max=0):
+        ref = te.pairing_batch(Pd, Qd); torch.cuda.synchronize()                           # lane-pair kernels (n > thr_w)
+    e2.profile(True)
+    for m, want_quad in ((thr_w + 1, True), (thr_q, True), (thr_q + 1, False)):
+        e2.profile_reset()
+        out = te.pairing_batch(Pd[:m].contiguous(), Qd[:m].contiguous()); torch.cuda.synchronize()
+        assert (e2.kernel_stats("miller_quad")[1], e2.kernel_stats("final_exp_quad")[1]) == ((1, 1) if want_quad else (0, 0)), m
+        assert e2.kernel_stats("miller")[1] == (0 if want_quad else 1), m
+        assert torch.equal(out, ref[:m]), m
+    e2.profile(False)
+    Pn = Pd[:6].cpu().numpy().view(np.uint64); Qn = Qd[:6].cpu().numpy().view(np.uint64)
+    assert np.array_equal(ref[:6].cpu().numpy().view(np.uint64), oracle.pairing_batch(Pn, Qn))
+    # (3) the halves separately: Miller values of the quad kernel through the lane-pair exponentiation and vice versa
+    m = thr_w + 77
+    with e2.options(quad_max=0):
+        a = te.miller_product(Pd[:m].contiguous(), Qd[:m].contiguous()); torch.cuda.synchronize()
+    b = te.miller_product(Pd[:m].contiguous(), Qd[:m].contiguous()); torch.cuda.synchronize()
+    # un-exponentiated products differ by nothing: both run the NAF schedule on the isomorphic curve with the same lines
+    assert torch.equal(te.product_final_exp(a.reshape(1, 48)), te.product_final_exp(b.reshape(1, 48)))
+
+
 def test_single_pairing_latency_path(oracle, te):
     """n = 1 through every entry point: the by-value `pairing(p, q)` of lib.rs:181-183"""
     import bn_amd

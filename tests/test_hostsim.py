@@ -407,3 +407,39 @@ def test_shared_accumulator_miller_loop(oracle, hs):
         assert np.array_equal(hs.call("hsb_pairing_product_shared", m, P, Q, out_words=96), oracle.pairing_product(P, Q))
         P[m - 1] = oracle.g1_zero(); Q[0] = oracle.g2_zero()
         assert np.array_equal(hs.call("hsb_pairing_product_shared", m, P, Q, out_words=96), oracle.pairing_product(P, Q))
+
+
+def test_quad_mapping_on_simulated_quad(oracle, hs, kats):
+    """bn_amd/csrc/quad.hpp (one pairing on FOUR lanes: lower lane pair c0, upper c1) on the 4-lane value type of
+    tests/hostsim/lanequad.hpp, every limb / value bound enforced: each split operation against the oracle or its lane-pair twin,
+    the final exponentiation, and whole pairings - random, the reference's known answer (groups/mod.rs:773-796), infinity"""
+    rng = np.random.default_rng(405)
+    def fq12(): return np.concatenate([oracle.fp_from_int(FQ, int.from_bytes(rng.bytes(40), "little") % M.Q) for _ in range(12)])
+    def fq2(): return np.concatenate([oracle.fp_from_int(FQ, int.from_bytes(rng.bytes(40), "little") % M.Q) for _ in range(2)])
+    for _ in range(3):
+        a, b = fq12(), fq12()
+        assert np.array_equal(hs.call("hsq_fq12_sqr", a, out_words=96), oracle.fq12_sqr(a))                      # fq12.rs:275-282
+        assert np.array_equal(hs.call("hsq_fq12_mul", a, b, 0, out_words=96), oracle.fq12_mul(a, b))             # fq12.rs:295-307
+        bc = hs.call("hsq_fq12_conj", b, out_words=96)
+        assert np.array_equal(hs.call("hsq_fq12_mul", a, b, 1, out_words=96), oracle.fq12_mul(a, bc))            # by the conjugate
+        assert np.array_equal(hs.call("hsq_fq12_inverse", a, out_words=96), oracle.fq12_inverse(a))              # fq12.rs:284-292
+        for pw in (1, 2, 3):
+            assert np.array_equal(hs.call("hsq_fq12_frobenius", a, pw, out_words=96), hs.call("hsb_fq12_frobenius", a, pw, out_words=96))
+        l0, lvw, lvv = fq2(), fq2(), fq2()
+        assert np.array_equal(hs.call("hsq_fq12_mul_by_024", a, l0, lvw, lvv, out_words=96), hs.call("hsb_fq12_mul_by_024", a, l0, lvw, lvv, out_words=96))
+    for v, z in ((oracle.fq12_one(), None), (np.zeros(48, np.uint64), None)):
+        assert np.array_equal(hs.call("hsq_fq12_sqr", v, out_words=96), oracle.fq12_sqr(v))
+    P = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)); Q = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng))
+    g = oracle.pairing(P, Q)
+    assert np.array_equal(hs.call("hsq_fq12_cyclotomic_sqr", g, out_words=96), oracle.fq12_sqr(g))               # fq12.rs:178-227 on a Gt value
+    assert np.array_equal(hs.call("hsq_final_exponentiation", oracle.miller_only(P, Q), out_words=96), g)        # fq12.rs:41-88
+    assert np.array_equal(hs.call("hsq_pairing", P, Q, 1, out_words=96), g)
+    # the Miller value of the NAF schedule differs from the reference's, its exponentiation does not
+    assert np.array_equal(oracle.fq12_final_exponentiation(hs.call("hsq_pairing", P, Q, 0, out_words=96)), g)
+    k = kats["test_reduced_pairing"]
+    Pk = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_decimal(FR, k["k1"])); Qk = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, k["k2"]))
+    assert oracle.fq12_to_ints(hs.call("hsq_pairing", Pk, Qk, 1, out_words=96)) == [int(x) for x in k["expected"]]
+    one = oracle.fq12_one()
+    assert np.array_equal(hs.call("hsq_pairing", oracle.g1_zero(), Q, 1, out_words=96), one)
+    assert np.array_equal(hs.call("hsq_pairing", P, oracle.g2_zero(), 1, out_words=96), one)
+    assert np.array_equal(hs.call("hsq_pairing", oracle.g1_one(), oracle.g2_one(), 1, out_words=96), oracle.pairing(oracle.g1_one(), oracle.g2_one()))

@@ -44,6 +44,15 @@ for name, thr in (("wave", 1 << 20), ("lane_pair", 0)):
     te.e.set_option("wave_pairing_max", thr); te.e.set_option("wave_fe_max", 1024 if thr else 0); te.e.set_option("quad_max", 0)
     res.setdefault("pairing_batch_ms", {})[name] = {n: timed(lambda: te.e.pairing_batch_dev(P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 4, 64, 256, 768, 1024, 2048, 3072, 4096, 6144)}
 for k in ("wave_pairing_max", "wave_fe_max", "quad_max"): te.e.set_option(k, None)
+# the mid-size window: four lanes per pairing (bn254_kernels_q.hip) against the lane-pair kernels and the library's own choice
+mid = {}
+for name, opts in (("default", {}), ("quad", {"wave_pairing_max": 0, "wave_fe_max": 0, "quad_max": 1 << 20}), ("lane_pair", {"wave_pairing_max": 0, "wave_fe_max": 0, "quad_max": 0}),
+                   ("wave", {"wave_pairing_max": 1 << 20, "wave_fe_max": 1 << 20})):
+    for k, v in opts.items(): te.e.set_option(k, v)
+    mid[name] = {n: timed(lambda: te.e.pairing_batch_dev(P.data_ptr(), Q.data_ptr(), out.data_ptr(), n, te._stream()), reps=5, warm=1)
+                 for n in (1024, 4096, 5120, 5121, 6144, 8192, 12288, 16384, 16385, 24576, 32768, 65536) if not (name == "wave" and n > 8192)}
+    for k in opts: te.e.set_option(k, None)
+res["pairing_batch_ms_mid_size"] = mid
 res["miller_only_ms"] = {n: timed(lambda: te.e.miller_batch_dev(P.data_ptr(), Q.data_ptr(), f.data_ptr(), n, te._stream()), reps=5, warm=1) for n in (1, 1 << 15, 1 << 16)}
 # by-value pairing through the host-buffer API (what `pairing(p, q)` of lib.rs:181-183 costs a caller)
 e = bn_amd.Engine(0)
