@@ -272,7 +272,7 @@ def bench_gtpow(args, eng, dev, world, rank):
                                "weak", f"{n} Gt values ^ distinct random Fr per GPU per step", {"roofline": rf})), flush=True)
 
 
-PRODUCT_KERNELS = ("miller", "miller_shared", "miller_wave", "gt_product", "gt_tail", "final_exp_wave", "final_exp")
+PRODUCT_KERNELS = ("miller", "miller_shared", "miller_wave", "miller_quad", "gt_product", "gt_tail", "final_exp_wave", "final_exp_quad", "final_exp")
 
 
 def run_product(eng, dev, dist, P, Q, steps, warmup):
@@ -518,8 +518,10 @@ def main():
         if rank == 0:
             ksteps = min(args.steps, 10)
             # (--batch below the wave-machine thresholds of csrc/bn254_hip.hip: the whole pairing is ONE kernel, "pairing_wave")
-            stats = kernel_times(eng, dev, step, ("miller", "final_exp", "final_exp_wave", "pairing_wave"), ksteps)
-            rf = roofline(eng, stats, n, MAC32_PER_PAIRING, dict(KERNEL_SHARE, final_exp_wave=KERNEL_SHARE["final_exp"], pairing_wave=1.0), traffic_key=True, steps=ksteps)
+            # (--batch in the small / mid-size windows of csrc/bn254_hip.hip: one kernel "pairing_wave", or the four-lane kernels "*_quad")
+            stats = kernel_times(eng, dev, step, ("miller", "final_exp", "final_exp_wave", "pairing_wave", "miller_quad", "final_exp_quad"), ksteps)
+            rf = roofline(eng, stats, n, MAC32_PER_PAIRING, dict(KERNEL_SHARE, final_exp_wave=KERNEL_SHARE["final_exp"], pairing_wave=1.0,
+                                                                 miller_quad=KERNEL_SHARE["miller"], final_exp_quad=KERNEL_SHARE["final_exp"]), traffic_key=True, steps=ksteps)
             rf["algorithmic_hbm_bytes_per_launch"] = n * ALGO_BYTES_PER_PAIRING
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             if cus != 256:

@@ -27,7 +27,10 @@ typedef Fq2B<Fe> F2;
 
 // The affine window table of a lane in global memory: [lane][entry 1..8][18 dwords padded to 80 bytes] - a lane reads the entry of
 // ITS digit as five 16-byte loads from one or two cache lines (curve.hpp AffTableVars explains why not a private array).
-constexpr uint32_t AFF_ENTRY_U4 = 5, AFF_LANE_U4 = 8 * AFF_ENTRY_U4;                 // 80 B per entry, 640 B per lane
+#ifndef BN_AFF_ENTRY_U4
+#define BN_AFF_ENTRY_U4 5           // 16-byte groups per entry: 5 = packed (80 B, an entry may straddle two 128-byte lines), 8 = one line per entry
+#endif
+constexpr uint32_t AFF_ENTRY_U4 = BN_AFF_ENTRY_U4, AFF_LANE_U4 = 8 * AFF_ENTRY_U4;   // 80 B per entry, 640 B per lane
 template <class F>
 struct AffTableMem {
     uint4 *base;             // this lane's 8 entries
@@ -51,6 +54,10 @@ struct AffTableMem {
 #pragma unroll
         for (int i2 = 0; i2 < 9; ++i2) { x.l[i2] = w[i2]; y.l[i2] = w[9 + i2]; }
     }
+    // touch(i): start fetching entry i towards the caches (one dword; the value only keeps the load alive until consume());
+    // used a window ahead, when the digit is known but the four doublings still have to run (-DBN_MUL_PREFETCH)
+    __device__ __forceinline__ uint32_t touch(int i) const { return ((const volatile uint32_t *)(base + (uint32_t)(i - 1) * AFF_ENTRY_U4))[0]; }
+    static __device__ __forceinline__ void consume(uint32_t token) { asm volatile("" ::"v"(token)); }
     // G1: (x, y) are Fe; G2 in the lane-pair mapping: this lane's components of (x, y)
     __device__ __forceinline__ void put(int i, const Aff<FqField> &v) const { put_fe(i, v.x, v.y); }
     __device__ __forceinline__ void put(int i, const Aff<Fq2Field<Fq2B<Fe>>> &v) const { put_fe(i, v.x.v, v.y.v); }

@@ -27,7 +27,7 @@ KERNELS = {
     "bn254_final_exp_W": ("final_exp_wave", lambda g: g // 64, 384 + 384),
     "bn254_gt_tail_W": ("gt_tail", lambda g: g // 64, 2 * 384),
     "bn254_gt_reduce_W": ("gt_product", None, 384),                      # units = values in: not visible in the grid (see --values)
-    "bn254_miller_Q": ("miller_quad", lambda g: g // 4, 96 + 192 + 384),
+    "bn254_miller_naf_Q": ("miller_quad", lambda g: g // 4, 96 + 192 + 384),
     "bn254_final_exp_Q": ("final_exp_quad", lambda g: g // 4, 384 + 384),
 }
 
