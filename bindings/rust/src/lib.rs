@@ -7,7 +7,7 @@
 extern crate bn;
 
 use bn::{Fr, G1, G2, Gt};
-use std::os::raw::{c_int, c_void};
+use std::os::raw::{c_int, c_long, c_void};
 
 extern "C" {
     fn bn254_pairing_batch(ctx: *mut c_void, p: *const G1, q: *const G2, out: *mut Gt, n: usize) -> c_int;
@@ -23,6 +23,12 @@ extern "C" {
     fn bn254_gt_inverse_batch(ctx: *mut c_void, a: *const Gt, out: *mut Gt, n: usize) -> c_int;
     // one node, several GPUs (include/bn254_hip.h "bn254_multi"): one context + host thread per device inside the library
     fn bn254_multi_create(devices: *const c_int, ndev: c_int, out: *mut *mut c_void) -> c_int;
+    fn bn254_multi_create_ex(devices: *const c_int, ndev: c_int, exchange: c_int, out: *mut *mut c_void) -> c_int;     // -1 auto, 0 peer copies, 1 RCCL
+    fn bn254_multi_set_option(m: *mut c_void, key: c_int, value: c_long) -> c_int;
+    fn bn254_multi_rank_numa_node(m: *const c_void, rank: c_int) -> c_int;
+    // tunables of a context (NULL = the default context of the current device): BN254_OPT_* of include/bn254_hip.h; value < 0 = default
+    fn bn254_ctx_set_option(ctx: *mut c_void, key: c_int, value: c_long) -> c_int;
+    fn bn254_ctx_get_option(ctx: *mut c_void, key: c_int, value: *mut c_long) -> c_int;
     fn bn254_multi_destroy(m: *mut c_void);
     fn bn254_pairing_batch_multi(m: *mut c_void, p: *const G1, q: *const G2, out: *mut Gt, n: usize) -> c_int;
     fn bn254_pairing_product_multi(m: *mut c_void, p: *const G1, q: *const G2, n: usize, out: *mut Gt) -> c_int;
@@ -32,6 +38,24 @@ extern "C" {
 // process-wide default context behind a NULL ctx), like the crate's own `pairing` (its types are `Send + Sync`,
 // src/lib.rs:55-61): the batch entry points lease one of two pipeline slots per call (two callers overlap on the GPU, more queue),
 // the others lock the context for the call.
+
+/// `BN254_OPT_*` of include/bn254_hip.h: per-context policies whose defaults derive from the device's CU count
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+#[repr(i32)]
+pub enum GpuOption {
+    WavePairingMax = 1, WaveFeMax = 2, QuadMax = 3, MillerShared = 4, GtPowMode = 5, ProductChunk = 6, ProductPerWave = 7,
+    ProductBfly = 8, RoundPairs = 9, PipelineChunk = 10, PipelineSlots = 11,
+}
+/// sets an option of the process-wide default context of the current HIP device; `None` restores the default
+pub fn set_option(key: GpuOption, value: Option<i64>) -> Result<(), GpuError> {
+    check(unsafe { bn254_ctx_set_option(std::ptr::null_mut(), key as c_int, value.unwrap_or(-1) as c_long) })
+}
+/// the effective value of an option of the default context
+pub fn get_option(key: GpuOption) -> Result<i64, GpuError> {
+    let mut v: c_long = 0;
+    check(unsafe { bn254_ctx_get_option(std::ptr::null_mut(), key as c_int, &mut v) })?;
+    Ok(v as i64)
+}
 
 /// Error code of the HIP engine: negative `BN254_E_*`, positive `hipError_t`.  There is no CPU fallback.
 #[derive(Debug, Clone, Copy, PartialEq, Eq)]
@@ -160,6 +184,22 @@ impl MultiGpu {
         let mut h = std::ptr::null_mut();
         check(unsafe { bn254_multi_create(devices.as_ptr(), devices.len() as c_int, &mut h) })?;
         Ok(MultiGpu(h))
+    }
+    /// the same with the exchange of the product forced: `Some(false)` peer copies, `Some(true)` RCCL (error instead of a fall-back)
+    pub fn with_exchange(devices: &[i32], rccl: Option<bool>) -> Result<MultiGpu, GpuError> {
+        let mut h = std::ptr::null_mut();
+        let kind = match rccl { None => -1, Some(false) => 0, Some(true) => 1 };
+        check(unsafe { bn254_multi_create_ex(devices.as_ptr(), devices.len() as c_int, kind, &mut h) })?;
+        Ok(MultiGpu(h))
+    }
+    /// an option on every rank's context
+    pub fn set_option(&self, key: GpuOption, value: Option<i64>) -> Result<(), GpuError> {
+        check(unsafe { bn254_multi_set_option(self.0, key as c_int, value.unwrap_or(-1) as c_long) })
+    }
+    /// NUMA node the host thread of `rank` is pinned to during a call (None: not pinned)
+    pub fn rank_numa_node(&self, rank: usize) -> Option<i32> {
+        let n = unsafe { bn254_multi_rank_numa_node(self.0, rank as c_int) };
+        if n < 0 { None } else { Some(n) }
     }
     /// `out[i] = bn::pairing(p[i], q[i])`, 2^20 pairings over 8 GPUs = BASELINE configs[2]
     pub fn pairing_batch(&self, p: &[G1], q: &[G2]) -> Result<Vec<Gt>, GpuError> {

@@ -55,7 +55,7 @@ struct AffTableMem {
         for (int i2 = 0; i2 < 9; ++i2) { x.l[i2] = w[i2]; y.l[i2] = w[9 + i2]; }
     }
     // touch(i): start fetching entry i towards the caches (one dword; the value only keeps the load alive until consume());
-    // used a window ahead, when the digit is known but the four doublings still have to run (-DBN_MUL_PREFETCH)
+    // used a window ahead, when the digit is known but the four doublings still have to run (-DBN_MUL_PREFETCH; measured: -2 %, profiles/r04c_ab_g1mul.txt)
     __device__ __forceinline__ uint32_t touch(int i) const { return ((const volatile uint32_t *)(base + (uint32_t)(i - 1) * AFF_ENTRY_U4))[0]; }
     static __device__ __forceinline__ void consume(uint32_t token) { asm volatile("" ::"v"(token)); }
     // G1: (x, y) are Fe; G2 in the lane-pair mapping: this lane's components of (x, y)

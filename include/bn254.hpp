@@ -93,12 +93,19 @@ inline Gt pairing_product(const std::vector<G1> &p, const std::vector<G2> &q) {
     return r;
 }
 
+// tunables of the default context (BN254_OPT_* of bn254_hip.h; value < 0 restores the default derived from the device)
+inline void set_option(int key, long value) { check(bn254_ctx_set_option(nullptr, key, value)); }
+inline long get_option(int key) { long v = 0; check(bn254_ctx_get_option(nullptr, key, &v)); return v; }
+
 // several GPUs of one node behind one handle (bn254_multi_*): shards of independent pairings, and the multi-pairing product with
 // its single 384-byte-per-GPU exchange (RCCL all-gather over xGMI) and ONE final exponentiation
 class MultiGpu {
     bn254_multi *m_ = nullptr;
 public:
-    explicit MultiGpu(const std::vector<int> &devices) { check(bn254_multi_create(devices.data(), (int)devices.size(), &m_)); }
+    // exchange: BN254_EXCHANGE_AUTO (RCCL when every rank has its own GPU), _PEER, _RCCL (throws instead of falling back)
+    explicit MultiGpu(const std::vector<int> &devices, int exchange = BN254_EXCHANGE_AUTO) { check(bn254_multi_create_ex(devices.data(), (int)devices.size(), exchange, &m_)); }
+    void set_option(int key, long value) { check(bn254_multi_set_option(m_, key, value)); }           // BN254_OPT_*, every rank's context
+    int rank_numa_node(int rank) const { return bn254_multi_rank_numa_node(m_, rank); }
     ~MultiGpu() { bn254_multi_destroy(m_); }
     MultiGpu(const MultiGpu &) = delete;
     MultiGpu &operator=(const MultiGpu &) = delete;
