@@ -9,9 +9,9 @@
 //   f * line (fq12.rs:107-176, sparse)                 each pair: own half * (x0 + x2 v^2) + other half * x4    8 Fq2 products instead of 13
 //   f * g (fq12.rs:295-307)                            own halves, then the Karatsuba cross term 3 + 3          9 instead of 18
 //   Granger-Scott squaring (fq12.rs:178-227)           per Fp4: lower a b, upper (a + b)(a + xi b)              3 instead of 6
-// What is NOT split: the G2 point arithmetic of the Miller loop (doubling / addition step, the line coefficients) and the inversions
-// run on both pairs redundantly - they hold the same values, so no exchange is needed for them.  Per doubling step a pair executes
-// 23 instead of 34 Fq2-product units, per addition step 21.7 instead of 26.7.
+// The G2 point arithmetic of the Miller loop is needed by both pairs; its independent same-shape products are dealt out two at a time
+// (q_doubling_step: 5 product slots instead of 9, q_addition_step: 7 instead of 13), the linear parts and the inversions run on both
+// pairs redundantly.  Per doubling step a pair executes ~20 instead of 34 Fq2-product units, per addition step ~17 instead of 27.
 // Every formula below is the lane-pair formula of tower.hpp with its operands picked per role; operand forms (standard / lazy sums)
 // are those of the originals, and the host simulation (tests/hostsim/lanequad.hpp) runs this header on a 4-lane value type with
 // every bound enforced.  Same field elements, hence the same bytes as the other mappings.
@@ -92,9 +92,14 @@ BN_COARSE QFq12<F2> q12_mul_by_024(const QFq12<F2> &f, const F2 &ell_0, const F2
     r.h.c2 = f2_lc3<1, -1, -1>(f2_add(pk, f2_qpick(s0, s1)), p00, p22);                        // a0 x2 + a2 x0 + [s0 | s1]
     return r;
 }
+// f <- f * line(P).  The two scalings of the line by P's coordinates (groups/mod.rs:502: ell_vw * P.y, ell_vv * P.x) are the one piece of
+// the otherwise redundant point arithmetic that splits for free: the lower pair scales ell_vw, the upper pair ell_vv - ONE Fq product
+// per lane instead of two -, and each fetches the other's result.
 template <class F2, class S>
 BN_FN QFq12<F2> q12_apply_line(const QFq12<F2> &f, const Line<F2> &l, const G1Aff<S> &p) {
-    return q12_mul_by_024(f, l.ell_0, f2_scale(l.ell_vw, p.y), f2_scale(l.ell_vv, p.x));
+    const F2 mine = f2_scale(f2_qpick(l.ell_vw, l.ell_vv), quad_pick(p.y, p.x));
+    const F2 other = f2_xq(mine);
+    return q12_mul_by_024(f, l.ell_0, f2_qpick(mine, other), f2_qpick(other, mine));
 }
 
 // fq12.rs:295-307 (Karatsuba over Fq6): `b` hands out THIS pair's half of the multiplier (from the table, or a register copy);
@@ -171,8 +176,70 @@ BN_OUTER QFq12<F2> q12_frobenius(const QFq12<F2> &a) {
     return {f6_qpick(m, f6_scale(m, f2_const(F2P, k::FROB12_C1[P])))};
 }
 
+// ---- the G2 point arithmetic of the Miller loop.  Both pairs need R, the lines and P, so the steps run on both - but wherever a step
+// holds TWO independent Fq2 products (or squares) of the same shape, the lower pair computes one, the upper pair the other, and each
+// fetches the other's result (36 selects + 9 DPP moves instead of a ~330-instruction product).  Same formulas, operand forms and
+// results as pairing.hpp doubling_step<true> / addition_step (groups/mod.rs:612-634, 592-610).
+template <class F2>
+BN_FN void f2_mul_split(const F2 &a_lo, const F2 &b_lo, const F2 &a_up, const F2 &b_up, F2 &r_lo, F2 &r_up) {
+    const F2 m = f2_mul(f2_qpick(a_lo, a_up), f2_qpick(b_lo, b_up)), o = f2_xq(m);
+    r_lo = f2_qpick(m, o); r_up = f2_qpick(o, m);
+}
+template <class F2>
+BN_FN void f2_sqr_split(const F2 &a_lo, const F2 &a_up, F2 &r_lo, F2 &r_up) {
+    const F2 m = f2_sqr(f2_qpick(a_lo, a_up)), o = f2_xq(m);
+    r_lo = f2_qpick(m, o); r_up = f2_qpick(o, m);
+}
+// 2 + 3 product slots per pair instead of 3 products + 6 squares
+template <class F2>
+BN_COARSE Line<F2> q_doubling_step(G2Proj<F2> &r) {
+    F2 b, c, j, yz2;
+    f2_sqr_split(r.y, r.z, b, c);                                        // b = y^2 | c = z^2
+    f2_sqr_split(r.x, f2_sum_for_mul(r.y, r.z), j, yz2);                 // j = x^2 | (y + z)^2
+    const F2 a = f2_half(f2_mul(r.x, r.y));
+    const F2 e = f2_mul_iso3b(c);                                        // 3 b' t^6 z^2 on the isomorphic curve
+    const F2 f3 = f2_add(f2_add(e, e), e);
+    const F2 g = f2_half_for_sqr(f2_add(b, f3));
+    const F2 h = f2_lc3<1, -1, -1>(yz2, b, c);
+    F2 g2, e_sq;
+    f2_sqr_split(g, e, g2, e_sq);                                        // g^2 | e^2
+    Line<F2> l;
+    l.ell_0 = f2_mul_xi(f2_ssub(e, b));
+    l.ell_vw = f2_neg_lazy(h);
+    l.ell_vv = f2_add(f2_add(j, j), j);
+    f2_mul_split(a, f2_lc3<1, -3, 0>(b, e, e), b, h, r.x, r.z);          // x' = a (b - f) | z' = b h
+    r.y = f2_lc3<1, -3, 0>(g2, e_sq, e_sq);
+    return l;
+}
+// 6 + 1 product slots per pair instead of 11 products + 2 squares
+template <class F2>
+BN_COARSE Line<F2> q_addition_step(G2Proj<F2> &r, const G2Aff<F2> &base) {
+    F2 zx, zy;
+    f2_mul_split(r.z, base.x, r.z, base.y, zx, zy);                      // z bx | z by
+    const F2 d = f2_lc3<1, -1, 0>(r.x, zx, r.x), e = f2_lc3<1, -1, 0>(r.y, zy, r.y);
+    F2 f, g;
+    f2_sqr_split(d, e, f, g);                                            // d^2 | e^2
+    F2 h, i;
+    f2_mul_split(d, f, r.x, f, h, i);                                    // d f | x f
+    F2 zg, ebx;
+    f2_mul_split(r.z, g, e, base.x, zg, ebx);                            // z g | e bx
+    F2 dby, hy;
+    f2_mul_split(d, base.y, h, r.y, dby, hy);                            // d by | h y
+    const F2 j = f2_lc3<1, -2, 0>(f2_add(zg, h), i, i);
+    Line<F2> l;
+    l.ell_0 = f2_mul_xi(f2_ssub(ebx, dby));
+    l.ell_vv = f2_neg_lazy(e);
+    l.ell_vw = d;
+    F2 eij, dj;
+    f2_mul_split(e, f2_lc3<1, -1, 0>(i, j, j), d, j, eij, dj);           // e (i - j) | d j
+    r.y = f2_lc3<1, -1, 0>(eij, hy, h);
+    r.x = dj;
+    r.z = f2_mul(r.z, h);
+    return l;
+}
+
 // ---- Miller loop: miller_loop_sched<true> (NAF schedule on the isomorphic curve) with f split over the quad; R, the point being
-// added and P live in `st` (LDS in the kernel) on BOTH pairs, which run the point arithmetic redundantly
+// added and P live in `st` (LDS in the kernel) on BOTH pairs
 template <class F2, class S, class Store>
 BN_FN QFq12<F2> q_miller_loop_naf(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, Store &st) {
     {
@@ -199,13 +266,13 @@ BN_FN QFq12<F2> q_miller_loop_naf(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, S
                 if (j != 0) f = q12_sqr(f);
                 BN_COMPILER_FENCE();
                 G2Proj<F2> r = st.get_r();
-                l = doubling_step<true>(r);
+                l = q_doubling_step(r);
                 st.put_r(r);
             } else {
                 G2Proj<F2> r = st.get_r();
                 G2Aff<F2> b = st.get_base();
                 if (digit < 0) b.y = f2_neg(b.y);
-                l = addition_step(r, b);
+                l = q_addition_step(r, b);
                 st.put_r(r);
             }
             f = q12_apply_line(f, l, st.get_p());
