@@ -277,10 +277,11 @@ long bn_opt(const bn254_ctx *c, int key) {
     const long cus = c->cus > 0 ? c->cus : 256;
     switch (key) {
         // one pairing / exponentiation per WAVE: a workgroup needs 11.5 KB of LDS, thirteen fit a CU; a pairing takes 1.05 ms up to 4 per CU
-        // (one wave per SIMD), 1.5 ms at 8, 2.05 ms at 12, 3.2 ms at 16 per CU - and 3.0 ms on four lanes (bn254_kernels_q.hip) whatever
-        // the count up to 64 per CU; a final exponentiation 0.5 / 0.7 / 1.46 ms at 4 / 8 / 16 per CU against 1.36 ms on four lanes
-        // (profiles/r04_wave_latency.json, 256 CUs).  Both cross at ~15 per CU.
-        case BN254_OPT_WAVE_PAIRING_MAX: case BN254_OPT_WAVE_FE_MAX: return (BN254_HAVE_QUAD ? 15 : 20) * cus;
+        // (one wave per SIMD), 1.5 ms at 8, 2.05 ms at 12, 3.2 ms at 16 per CU - and 2.8 ms on four lanes (bn254_kernels_q.hip) whatever
+        // the count up to 64 per CU; a final exponentiation 0.5 / 0.7 / 1.46 ms at 4 / 8 / 16 per CU against 1.37 ms on four lanes
+        // (profiles/r04_wave_latency.json, 256 CUs).  They cross at ~14 and ~15 per CU.
+        case BN254_OPT_WAVE_PAIRING_MAX: return (BN254_HAVE_QUAD ? 14 : 20) * cus;
+        case BN254_OPT_WAVE_FE_MAX: return (BN254_HAVE_QUAD ? 15 : 20) * cus;
         case BN254_OPT_QUAD_MAX: return BN254_HAVE_QUAD ? 64 * cus : 0;
         case BN254_OPT_MILLER_SHARED: case BN254_OPT_GT_POW_MODE: return 0;
         case BN254_OPT_ROUND_PAIRS: return 256 * cus;

@@ -171,7 +171,7 @@ BN_OUTER QFq12<F2> q12_inverse(const QFq12<F2> &a) {
 }
 // fq12.rs:90-95: the Fq6 map on the own half, the upper pair scales its half by FROB12_C1[P]
 template <int P, class F2>
-BN_OUTER QFq12<F2> q12_frobenius(const QFq12<F2> &a) {
+BN_FN QFq12<F2> q12_frobenius(const QFq12<F2> &a) {
     const Fq6<F2> m = f6_frobenius<P>(a.h);
     return {f6_qpick(m, f6_scale(m, f2_const(F2P, k::FROB12_C1[P])))};
 }
@@ -238,6 +238,25 @@ BN_COARSE Line<F2> q_addition_step(G2Proj<F2> &r, const G2Aff<F2> &base) {
     return l;
 }
 
+// The maps as the exponentiation machine calls them: out of line (they are rare), but with the operand BY VALUE in <9 x i32> vectors
+// on the GPU - the running value of the machine handed over by reference has its address escape, lives in a stack slot from then on and
+// is loaded and stored (27 dwords) in EVERY step (fe.hpp "leaf calling convention"; the same pathology as curve.hpp jac_double_cold)
+#if defined(BN_HOSTSIM)
+template <int P, class F2> BN_FN QFq12<F2> q12_frobenius_call(const QFq12<F2> &a) { return q12_frobenius<P>(a); }
+#else
+template <int P, class F2>
+BN_OUTER void q12_frobenius_vec(u32x9 c0, u32x9 c1, u32x9 c2, QFq12<F2> *out) {
+    QFq12<F2> a;
+    a.h.c0.v = bn_unv(c0); a.h.c1.v = bn_unv(c1); a.h.c2.v = bn_unv(c2);
+    *out = q12_frobenius<P>(a);
+}
+template <int P, class F2> BN_FN QFq12<F2> q12_frobenius_call(const QFq12<F2> &a) {
+    QFq12<F2> t;
+    q12_frobenius_vec<P, F2>(bn_tov(a.h.c0.v), bn_tov(a.h.c1.v), bn_tov(a.h.c2.v), &t);
+    return t;
+}
+#endif
+
 // ---- Miller loop: miller_loop_sched<true> (NAF schedule on the isomorphic curve) with f split over the quad; R, the point being
 // added and P live in `st` (LDS in the kernel) on BOTH pairs
 template <class F2, class S, class Store>
@@ -297,8 +316,7 @@ BN_FN void q_fe_step(QFq12<F2> &res, const int w, Tbl &tbl) {
     if (post == 1) {
         res = q12_conj(res);
     } else if (post) {
-        const QFq12<F2> cur = res;
-        res = post == 2 ? q12_frobenius<1>(cur) : post == 3 ? q12_frobenius<2>(cur) : q12_frobenius<3>(cur);
+        res = post == 2 ? q12_frobenius_call<1>(res) : post == 3 ? q12_frobenius_call<2>(res) : q12_frobenius_call<3>(res);
     }
     if (put) tbl.put(put - 1, res.h);
 }
@@ -306,7 +324,10 @@ template <class F2, class Tbl>
 BN_FN QFq12<F2> q_final_exponentiation(const QFq12<F2> &f, Tbl &tbl) {
     const QFq12<F2> b = q12_inverse(f);
     const QFq12<F2> c = q12_mul_o(q12_conj(f), b);
-    QFq12<F2> res = q12_mul_o(q12_frobenius<2>(c), c);
+    // (a separate variable for the loop: the out-of-line product writes its result through a pointer, and a loop-carried value whose
+    //  address has escaped stays in memory for the whole program)
+    const QFq12<F2> start = q12_mul_o(q12_frobenius_call<2>(c), c);
+    QFq12<F2> res = {start.h};
 #pragma unroll 1
     for (int i = 0; i < k::FE_STEPS; ++i) q_fe_step(res, k::FE_PROG[i], tbl);
     return res;

@@ -34,9 +34,9 @@
  *
  * Sizes: n is limited by device memory only.  Batches are cut internally into sub-launches of at most one machine round, and the
  * context-owned tables (final exponentiation: 4 KB, Gt::pow: 14.8 KB per pairing) are sized for ONE round - 264 MB / 970 MB on an
- * MI355X whatever n is.  Up to 3840 pairings or final exponentiations per call (the tail of every multi-pairing: exactly one) run one per
+ * MI355X whatever n is.  Up to 3584 pairings (3840 final exponentiations) per call (the tail of every multi-pairing: exactly one) run one per
  * WAVE instead of one per lane pair: a pairing in 1.0 ms instead of 4.2 ms, a final exponentiation in 0.5 ms instead of 2.0 ms; from
- * there up to 16384 per call a pairing runs on FOUR lanes (3.0 ms); above, on lane pairs (BN254_OPT_* below move the thresholds).
+ * there up to 16384 per call a pairing runs on FOUR lanes (2.8-2.9 ms); above, on lane pairs (BN254_OPT_* below move the thresholds).
  *
  * Ownership: the caller owns every buffer passed in; the library owns device memory and streams inside a context and keeps
  * no pointer after a call returns.  A context is bound to one GPU.  There is NO CPU fallback: without a usable MI355X the
@@ -106,7 +106,7 @@ int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping);
    read ONCE per process, when the first context is created, and seed the options of every context created afterwards. */
 enum {
     BN254_OPT_WAVE_PAIRING_MAX = 1, /* pairings (or Miller loops that only meet a final exponentiation) per call up to which ONE PER WAVE
-                                       runs (csrc/bn254_kernels_w.hip).  Default 15 x CUs (3840): where it is level with the four-lane
+                                       runs (csrc/bn254_kernels_w.hip).  Default 14 x CUs (3584): where it is level with the four-lane
                                        kernels on 256 CUs (profiles/r04_wave_latency.json), 13 workgroups of 11.5 KB LDS per CU */
     BN254_OPT_WAVE_FE_MAX = 2,      /* the same for final exponentiations.  Default 15 x CUs */
     BN254_OPT_QUAD_MAX = 3,         /* pairings per call up to which (and above the two options before) a pairing is spread over FOUR lanes

@@ -116,11 +116,11 @@ def test_options_api(eng):
     """bn254_ctx_set_option / get_option: defaults derive from the CU count, values are validated, negative restores the default"""
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    assert eng.get_option("wave_pairing_max") == 15 * cus and eng.get_option("wave_fe_max") == 15 * cus
+    assert eng.get_option("wave_pairing_max") == 14 * cus and eng.get_option("wave_fe_max") == 15 * cus
     assert eng.get_option("round_pairs") == 256 * cus and eng.get_option("pipeline_slots") == 2
     assert eng.get_option("miller_shared") == 0 and eng.get_option("gt_pow_mode") == 0
     eng.set_option("wave_pairing_max", 7); assert eng.get_option("wave_pairing_max") == 7
-    eng.set_option("wave_pairing_max", -5); assert eng.get_option("wave_pairing_max") == 15 * cus
+    eng.set_option("wave_pairing_max", -5); assert eng.get_option("wave_pairing_max") == 14 * cus
     for name, bad in (("miller_shared", 3), ("gt_pow_mode", 9), ("product_per_wave", 33), ("pipeline_slots", 5), ("product_bfly", 6)):
         with pytest.raises(Exception):
             eng.set_option(name, bad)

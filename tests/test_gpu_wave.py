@@ -158,10 +158,10 @@ def test_wave_pairing_matches_oracle_and_lane_pair_kernels(oracle, te):
     assert torch.equal(a, b)
     Pn = Pd[:8].cpu().numpy().view(np.uint64); Qn = Qd[:8].cpu().numpy().view(np.uint64)
     assert np.array_equal(a[:8].cpu().numpy().view(np.uint64), oracle.pairing_batch(Pn, Qn))
-    # either side of the host's default threshold (BN254_OPT_WAVE_PAIRING_MAX: 15 per CU - thirteen workgroups per CU, several waves per SIMD)
+    # either side of the host's default threshold (BN254_OPT_WAVE_PAIRING_MAX: 14 per CU - thirteen workgroups per CU, several waves per SIMD)
     e2 = te.e
     thr = e2.get_option("wave_pairing_max")
-    assert thr == 15 * torch.cuda.get_device_properties(0).multi_processor_count
+    assert thr == 14 * torch.cuda.get_device_properties(0).multi_processor_count
     big = thr + 1
     Pb, Qb = D.synthetic_points(te, 20000, 20000 + big)
     e2.profile(True); e2.profile_reset()
