@@ -46,7 +46,8 @@ def test_hot_loops_are_spill_free(kernel):
     if not so.exists() or not (isa_mix.LLVM / "llvm-objdump").exists():
         pytest.skip("library or llvm-objdump not present")
     blocks = [b for text in isa_mix.disassemble(so) for b in _blocks(text, kernel)]
-    hot = [b for b in blocks if b[0] >= 2500]                  # the loop bodies: squarings, line / table products (2.8k .. 14k instructions)
+    # the loop bodies: squarings, line / table products (2.8k .. 14k instructions; on four lanes a Granger-Scott squaring is 2.1k)
+    hot = [b for b in blocks if b[0] >= (2000 if kernel.endswith("_Q") else 2500)]
     assert len(hot) >= 2, blocks
     assert all(s == 0 for _, s in hot), f"scratch accesses inside the hot blocks of {kernel}: {hot}"
 
