@@ -302,11 +302,15 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // State of the M pairs in global memory: per lane and pair 17 x 16 bytes - R (27 dwords in 7 groups of 4), the base point (18 in 5),
 // P (18 in 5) -, group-major, then the lane: every access of a wave is one coalesced dwordx4 instruction over 1 KB (ExpTableMem's
 // layout).  Both lanes of a pair hold P (an Fq point) replicated.
+#ifndef BN_SHARED_P_GLOBAL
+#define BN_SHARED_P_LDS 1    // the M affine P_i live in LDS ([pair][dword][lane]: 72 B per lane and pair, 18 KB per workgroup at M = 4, eight
+#endif                       // workgroups per CU = 147 of the 160 KB) instead of global memory: they are read in EVERY step of every pair
 template <int M>
 struct MillerStateMem {
     uint4 *base;             // wave-uniform
     uint32_t lane, stride;   // this lane's column, lanes in the launch
     uint32_t infmask;        // bit i: pair i is (treated as) infinite
+    uint32_t *plds;          // this lane's column of the workgroup's P store (BN_SHARED_P_LDS)
 #ifdef BN_AB_ALIAS_SCRATCH
     __device__ __forceinline__ uint32_t row(int, int g) const { return (uint32_t)g * stride + (lane & 8191u); }      // timing experiment, see ExpTableMem
 #else
@@ -341,8 +345,21 @@ struct MillerStateMem {
     __device__ __forceinline__ G2Proj<F2> get_r(int i) const { Fe t[3]; ld_n<3, 0>(i, t); return {{t[0]}, {t[1]}, {t[2]}}; }
     __device__ __forceinline__ void put_base(int i, const G2Aff<F2> &v) const { Fe t[2] = {v.x.v, v.y.v}; st_n<2, 7>(i, t); }
     __device__ __forceinline__ G2Aff<F2> get_base(int i) const { Fe t[2]; ld_n<2, 7>(i, t); return {{t[0]}, {t[1]}}; }
+#ifdef BN_SHARED_P_LDS
+    __device__ __forceinline__ void put_p(int i, const G1Aff<Fe> &v) const {
+#pragma unroll
+        for (int l = 0; l < 9; ++l) { plds[((i * 18) + l) * BLOCK] = v.x.l[l]; plds[((i * 18) + 9 + l) * BLOCK] = v.y.l[l]; }
+    }
+    __device__ __forceinline__ G1Aff<Fe> get_p(int i) const {
+        G1Aff<Fe> v;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) { v.x.l[l] = plds[((i * 18) + l) * BLOCK]; v.y.l[l] = plds[((i * 18) + 9 + l) * BLOCK]; }
+        return v;
+    }
+#else
     __device__ __forceinline__ void put_p(int i, const G1Aff<Fe> &v) const { Fe t[2] = {v.x, v.y}; st_n<2, 12>(i, t); }
     __device__ __forceinline__ G1Aff<Fe> get_p(int i) const { Fe t[2]; ld_n<2, 12>(i, t); return {t[0], t[1]}; }
+#endif
     __device__ __forceinline__ bool is_inf(int i) const { return (infmask >> i) & 1u; }
 };
 constexpr size_t MILLER_STATE_BYTES_PER_LANE_AND_PAIR = 17 * 16;
@@ -353,7 +370,12 @@ __device__ __forceinline__ void miller_shared_body(const uint32_t *g1, const uin
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t lp = t >> 1, groups = (n + M - 1) / M;
     const bool live = lp < groups;
-    MillerStateMem<M> st = {state, t, gridDim.x * BLOCK, 0u};
+#ifdef BN_SHARED_P_LDS
+    __shared__ uint32_t p_store[M * 18 * BLOCK];
+    MillerStateMem<M> st = {state, t, gridDim.x * BLOCK, 0u, p_store + threadIdx.x};
+#else
+    MillerStateMem<M> st = {state, t, gridDim.x * BLOCK, 0u, nullptr};
+#endif
 #pragma unroll 1
     for (int i = 0; i < M; ++i) {
         uint32_t pair = (live ? lp : groups - 1) * M + (uint32_t)i;

@@ -210,7 +210,8 @@ def test_quad_kernels_match_oracle_and_lane_pair_kernels(oracle, te, goldens):
     e.close()
     # (2) both sides of both thresholds on device-resident inputs: thr_w (wave | quad) and thr_q (quad | lane pair)
     e2 = te.e
-    thr_w, thr_q = e2.get_option("wave_pairing_max"), e2.get_option("quad_max")
+    # (the Miller loop and the exponentiation have their own wave thresholds: above BOTH the whole pairing runs on four lanes)
+    thr_w, thr_q = max(e2.get_option("wave_pairing_max"), e2.get_option("wave_fe_max")), e2.get_option("quad_max")
     Pd, Qd = D.synthetic_points(te, 40000, 40000 + thr_q + 1)
     with e2.options(quad_max=0):
         ref = te.pairing_batch(Pd, Qd); torch.cuda.synchronize()                           # lane-pair kernels (n > thr_w)
