@@ -350,14 +350,16 @@ BN_FN Fe fe_reduce(const Fe &a) {
 // conditional add/subtract per Fq add instead (arith.rs:238-253).  Result: normalized limbs, value < 3q.
 // core: the middle term's sign is a per-lane run-time flag (needed by the lane-pair Fq2 mapping, where the even lane
 // subtracts and the odd lane adds the partner's limb in xi-multiplications)
-template <int C1, int C2, int C3, int C4>
+// WIDE: every term enters the 64-bit chain on its own (no 32-bit pre-combination), which lifts the bound on the SUM of the inputs' limb
+// bounds - each input still has to fit int32 (lb <= 4).  Used where one reduction takes the place of several (quad.hpp).
+template <int C1, int C2, int C3, int C4, bool WIDE = false>
 BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool neg2) {
     BN_COUNT(lc3);
     constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3, A4 = C4 < 0 ? -C4 : C4;
     // Every input limb is read as a SIGNED 32-bit integer (so inputs may be signed lazy differences, fe_ssub): |limb| < 2^31,
     // i.e. lb <= 4.  Terms with a small coefficient are first combined in 32-bit arithmetic ("narrow"); the others enter the
     // 64-bit chain on their own.
-    constexpr bool N1 = C1 != 0 && A1 <= 2, N2 = C2 != 0 && A2 <= 2, N3 = C3 != 0 && A3 <= 2, N4 = C4 != 0 && A4 <= 2;
+    constexpr bool N1 = !WIDE && C1 != 0 && A1 <= 2, N2 = !WIDE && C2 != 0 && A2 <= 2, N3 = !WIDE && C3 != 0 && A3 <= 2, N4 = !WIDE && C4 != 0 && A4 <= 2;
     BN_IFB(if (!((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4) && (C4 == 0 || w.lb <= 4)))
                std::fprintf(stderr, "fe_lc<%d,%d,%d,%d> lbs %u %u %u %u\n", C1, C2, C3, C4, x.lb, y.lb, z.lb, w.lb);)
     BN_REQUIRE((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4) && (C4 == 0 || w.lb <= 4), "fe_lc: input limbs must fit int32");

@@ -141,6 +141,10 @@ BN_FN Fe fe_lc3_par_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_
 BN_LEAF3T(fe_lc3_par, fe_lc3_par_body)
 template <int C1, int C2, int C3, int C4>
 BN_FN Fe fe_lc4_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4>(x, y, z, w, !lane_is_odd()); }
+template <int C1, int C2, int C3, int C4>      // all terms in the 64-bit chain (fe.hpp WIDE)
+BN_FN Fe fe_lc4w_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4, true>(x, y, z, w, !lane_is_odd()); }
+template <int C1, int C2, int C3>
+BN_FN Fe fe_lc3sw(const Fe &x, const Fe &y, const Fe &z) { return fe_lc4_core<C1, C2, C3, 0, true>(x, y, z, z, false); }
 #endif
 
 template <class T>
@@ -207,6 +211,11 @@ template <int CX, int CY, class T>
 BN_FN Fq2B<T> f2_lc_xi(const Fq2B<T> &x, const Fq2B<T> &y) { return {fe_lc3_par<9 * CX, CX, CY>(x.v, lane_partner(x.v), y.v)}; }
 template <int CX, int CY, int CZ, class T>
 BN_FN Fq2B<T> f2_lc_xi2(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc4_par<9 * CX, CX, CY, CZ>(x.v, lane_partner(x.v), y.v, z.v)}; }
+// the same with every term in the 64-bit chain, and the plain three-term combination likewise: signed lazy inputs of any limb bound <= 4 each
+template <int CX, int CY, int CZ, class T>
+BN_FN Fq2B<T> f2_lc_xi2w(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc4w_par<9 * CX, CX, CY, CZ>(x.v, lane_partner(x.v), y.v, z.v)}; }
+template <int C1, int C2, int C3, class T>
+BN_FN Fq2B<T> f2_lc3sw(const Fq2B<T> &x, const Fq2B<T> &y, const Fq2B<T> &z) { return {fe_lc3sw<C1, C2, C3>(x.v, y.v, z.v)}; }
 template <class T> BN_FN Fq2B<T> f2_mul_xi(const Fq2B<T> &x) { return f2_lc_xi<1, 0>(x, x); }
 // (27 - 3i) * x: even lane 27 x0 + 3 x1, odd lane 27 x1 - 3 x0  (fe_lc3_par negates its middle term on the even lane)
 template <class T> BN_FN Fq2B<T> f2_mul_iso3b(const Fq2B<T> &x) { return {fe_lc3_par<27, -3, 0>(x.v, lane_partner(x.v), x.v)}; }

@@ -120,14 +120,18 @@ BN_FN QFq12<F2> q12_mul_half(const QFq12<F2> &a, Fq6<F2> b, bool conj_b) {
     const F2 k12 = f2_qpick(qa, pa), k01 = f2_qpick(qb, pb), k02 = f2_qpick(qc, pc);            // (s1+s2)(t1+t2), (s0+s1)(t0+t1), (s0+s2)(t0+t2)
     const Fq6<F2> other = f6_xq(mine);
     const Fq6<F2> aa = f6_qpick(mine, other), bb = f6_qpick(other, mine);
-    Fq6<F2> lo, st;
-    lo.c0 = f2_lc_xi<1, 1>(bb.c2, aa.c0);                                    // aa + v bb
-    lo.c1 = f2_lc3<1, 1, 0>(aa.c1, bb.c0, bb.c0);
-    lo.c2 = f2_lc3<1, 1, 0>(aa.c2, bb.c1, bb.c1);
-    st.c0 = f2_lc_xi<1, 1>(f2_ssub(f2_ssub(k12, v1), v2), v0);               // f6_mul's recombination of the cross product
-    st.c1 = f2_lc_xi<1, 1>(v2, f2_ssub(f2_ssub(k01, v0), v1));
-    st.c2 = f2_lc3<1, -1, -1>(f2_add(k02, v1), v0, v2);
-    return {f6_qpick(lo, f6_lc3<1, -1, -1>(st, aa, bb))};
+    // ONE fused reduction  xi X + Y - Z  per coefficient for both roles (lane-uniform stream: separate reductions - three for the lower
+    // pair, three for the cross product and three for the Karatsuba difference of the upper pair - would all run on both pairs):
+    //   lower  c0 = aa + v bb:   (xi bb2 + aa0,  aa1 + bb0,  aa2 + bb1)
+    //   upper  c1 = s t - aa - bb with f6_mul's recombination of s t inlined:
+    //          (xi (k12 - v1 - v2) + v0 - aa0 - bb0,   xi v2 + (k01 - v0 - v1) - aa1 - bb1,   (k02 + v1 - v0 - v2) - aa2 - bb2)
+    // Signed lazy operands of up to four terms each: all terms go through the 64-bit chain (f2_lc_xi2w / f2_lc3sw).
+    const F2 zero = f2_zero(F2P);
+    Fq6<F2> r;
+    r.c0 = f2_lc_xi2w<1, 1, -1>(f2_qpick(bb.c2, f2_ssub(f2_ssub(k12, v1), v2)), f2_qpick(aa.c0, f2_ssub(v0, aa.c0)), f2_qpick(zero, bb.c0));
+    r.c1 = f2_lc_xi2w<1, 1, -1>(f2_qpick(zero, v2), f2_qpick(aa.c1, f2_ssub(f2_ssub(k01, v0), v1)), f2_qpick(f2_neg_lazy(bb.c0), f2_add(aa.c1, bb.c1)));
+    r.c2 = f2_lc3sw<1, -1, 0>(f2_qpick(aa.c2, f2_ssub(f2_ssub(f2_add(k02, v1), v0), v2)), f2_qpick(f2_neg_lazy(bb.c1), f2_add(aa.c2, bb.c2)), zero);
+    return {r};
 }
 template <class F2> BN_COARSE QFq12<F2> q12_mul(const QFq12<F2> &a, const QFq12<F2> &b) { return q12_mul_half(a, b.h, false); }
 template <class F2> BN_OUTER QFq12<F2> q12_mul_o(const QFq12<F2> &a, const QFq12<F2> &b) { return q12_mul_half(a, b.h, false); }
@@ -146,14 +150,17 @@ BN_COARSE QFq12<F2> q12_cyclotomic_sqr(const QFq12<F2> &f) {
     };
     F2 t01, m01, t23, m23, t45, m45;
     fp4(z0, z1, t01, m01); fp4(z2, z3, t23, m23); fp4(z4, z5, t45, m45);
-    Fq6<F2> lo, up;
-    lo.c0 = f2_lc_xi2<-3, 3, -2>(t01, f2_ssub(m01, t01), z0);
-    lo.c1 = f2_lc_xi2<-3, 3, -2>(t23, f2_ssub(m23, t23), z4);
-    lo.c2 = f2_lc_xi2<-3, 3, -2>(t45, f2_ssub(m45, t45), z3);
-    up.c0 = f2_lc_xi<6, 2>(t45, z2);
-    up.c1 = f2_lc3<6, 2, 0>(t01, z1, z1);
-    up.c2 = f2_lc3<6, 2, 0>(t23, z5, z5);
-    return {f6_qpick(lo, up)};
+    // ONE fused reduction  -3 xi X + 3 Y - 2 Z  per coefficient serves both roles (the instruction stream is lane-uniform: two
+    // role-specific reductions would both be executed by both pairs):
+    //   lower  z0' = 3 (m01 - t01 - xi t01) - 2 z0 ...      (X, Y, Z) = (t, m - t, z_even)
+    //   upper  z2' = 6 xi t45 + 2 z2                         (X, Y, Z) = (-2 t45, 0, -z2)
+    //          z1' = 6 t01 + 2 z1,  z5' = 6 t23 + 2 z5       (X, Y, Z) = (0, 2 t, -z_odd)
+    const F2 zero = f2_zero(F2P);
+    Fq6<F2> r;
+    r.c0 = f2_lc_xi2<-3, 3, -2>(f2_qpick(t01, f2_dbl(f2_neg_lazy(t45))), f2_qpick(f2_ssub(m01, t01), zero), f2_qpick(z0, f2_neg_lazy(z2)));
+    r.c1 = f2_lc_xi2<-3, 3, -2>(f2_qpick(t23, zero), f2_qpick(f2_ssub(m23, t23), f2_dbl(t01)), f2_qpick(z4, f2_neg_lazy(z1)));
+    r.c2 = f2_lc_xi2<-3, 3, -2>(f2_qpick(t45, zero), f2_qpick(f2_ssub(m45, t45), f2_dbl(t23)), f2_qpick(z3, f2_neg_lazy(z5)));
+    return {r};
 }
 
 // fq12.rs:284-292: the two Fq6 squares in parallel, d = c0^2 - v c1^2 and its inverse (one Fq inversion) on both pairs, own half * t

@@ -30,6 +30,14 @@ template <int C1, int C2, int C3, int C4>
 BN_FN FeP fe_lc4_par(const FeP &x, const FeP &y, const FeP &z, const FeP &w) {
     return {{fe_lc4_core<C1, C2, C3, C4>(x.v[0], y.v[0], z.v[0], w.v[0], true), fe_lc4_core<C1, C2, C3, C4>(x.v[1], y.v[1], z.v[1], w.v[1], false)}};
 }
+template <int C1, int C2, int C3, int C4>
+BN_FN FeP fe_lc4w_par(const FeP &x, const FeP &y, const FeP &z, const FeP &w) {
+    return {{fe_lc4_core<C1, C2, C3, C4, true>(x.v[0], y.v[0], z.v[0], w.v[0], true), fe_lc4_core<C1, C2, C3, C4, true>(x.v[1], y.v[1], z.v[1], w.v[1], false)}};
+}
+template <int C1, int C2, int C3>
+BN_FN FeP fe_lc3sw(const FeP &x, const FeP &y, const FeP &z) {
+    return {{fe_lc4_core<C1, C2, C3, 0, true>(x.v[0], y.v[0], z.v[0], z.v[0], false), fe_lc4_core<C1, C2, C3, 0, true>(x.v[1], y.v[1], z.v[1], z.v[1], false)}};
+}
 BN_FN FeP fe_mul(const FeP &a, const FeP &b) { return {{fe_mul(a.v[0], b.v[0]), fe_mul(a.v[1], b.v[1])}}; }
 BN_FN FeP fe_mul_body(const FeP &a, const FeP &b) { return fe_mul(a, b); }
 BN_FN FeP fe_sqr(const FeP &a) { return fe_mul(a, a); }

@@ -24,6 +24,9 @@ template <int C1, int C2, int C3> BN_FN FeQ fe_lc3(const FeQ &x, const FeQ &y, c
 template <int C1, int C2, int C3> BN_FN FeQ fe_lc3_par(const FeQ &x, const FeQ &y, const FeQ &z) { return {{fe_lc3_par<C1, C2, C3>(x.p[0], y.p[0], z.p[0]), fe_lc3_par<C1, C2, C3>(x.p[1], y.p[1], z.p[1])}}; }
 template <int C1, int C2, int C3, int C4>
 BN_FN FeQ fe_lc4_par(const FeQ &x, const FeQ &y, const FeQ &z, const FeQ &w) { return {{fe_lc4_par<C1, C2, C3, C4>(x.p[0], y.p[0], z.p[0], w.p[0]), fe_lc4_par<C1, C2, C3, C4>(x.p[1], y.p[1], z.p[1], w.p[1])}}; }
+template <int C1, int C2, int C3, int C4>
+BN_FN FeQ fe_lc4w_par(const FeQ &x, const FeQ &y, const FeQ &z, const FeQ &w) { return {{fe_lc4w_par<C1, C2, C3, C4>(x.p[0], y.p[0], z.p[0], w.p[0]), fe_lc4w_par<C1, C2, C3, C4>(x.p[1], y.p[1], z.p[1], w.p[1])}}; }
+template <int C1, int C2, int C3> BN_FN FeQ fe_lc3sw(const FeQ &x, const FeQ &y, const FeQ &z) { return {{fe_lc3sw<C1, C2, C3>(x.p[0], y.p[0], z.p[0]), fe_lc3sw<C1, C2, C3>(x.p[1], y.p[1], z.p[1])}}; }
 BN_FN FeQ fe_mul2(const FeQ &a, const FeQ &u, const FeQ &c, const FeQ &v) { return {{fe_mul2(a.p[0], u.p[0], c.p[0], v.p[0]), fe_mul2(a.p[1], u.p[1], c.p[1], v.p[1])}}; }
 BN_FN FeQ fe_select(bool take_b, const FeQ &a, const FeQ &b) { return {{fe_select(take_b, a.p[0], b.p[0]), fe_select(take_b, a.p[1], b.p[1])}}; }
 // both pairs of a quad read the same inputs (G1 / G2 points) ...
