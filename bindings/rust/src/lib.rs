@@ -44,7 +44,7 @@ extern "C" {
 #[repr(i32)]
 pub enum GpuOption {
     WavePairingMax = 1, WaveFeMax = 2, QuadMax = 3, MillerShared = 4, GtPowMode = 5, ProductChunk = 6, ProductPerWave = 7,
-    ProductBfly = 8, RoundPairs = 9, PipelineChunk = 10, PipelineSlots = 11,
+    ProductBfly = 8, RoundPairs = 9, PipelineChunk = 10, PipelineSlots = 11, StreamStopAtError = 12,
 }
 /// sets an option of the process-wide default context of the current HIP device; `None` restores the default
 pub fn set_option(key: GpuOption, value: Option<i64>) -> Result<(), GpuError> {

@@ -164,7 +164,7 @@ def lib():
 
 # BN254_OPT_* of include/bn254_hip.h
 OPTIONS = {"wave_pairing_max": 1, "wave_fe_max": 2, "quad_max": 3, "miller_shared": 4, "gt_pow_mode": 5, "product_chunk": 6,
-           "product_per_wave": 7, "product_bfly": 8, "round_pairs": 9, "pipeline_chunk": 10, "pipeline_slots": 11}
+           "product_per_wave": 7, "product_bfly": 8, "round_pairs": 9, "pipeline_chunk": 10, "pipeline_slots": 11, "stream_stop_at_error": 12}
 EXCHANGE = {"auto": -1, "peer": 0, "rccl": 1}
 
 

@@ -246,7 +246,8 @@ const DebugEnv &bn_debug_env() {
             {"BN254_WAVE_PAIRING_MAX", BN254_OPT_WAVE_PAIRING_MAX}, {"BN254_WAVE_FE_MAX", BN254_OPT_WAVE_FE_MAX}, {"BN254_QUAD_MAX", BN254_OPT_QUAD_MAX},
             {"BN254_MILLER_SHARED", BN254_OPT_MILLER_SHARED}, {"BN254_GT_POW_MODE", BN254_OPT_GT_POW_MODE}, {"BN254_PRODUCT_CHUNK", BN254_OPT_PRODUCT_CHUNK},
             {"BN254_PRODUCT_PER_WAVE", BN254_OPT_PRODUCT_PER_WAVE}, {"BN254_PRODUCT_BFLY", BN254_OPT_PRODUCT_BFLY}, {"BN254_ROUND_PAIRS", BN254_OPT_ROUND_PAIRS},
-            {"BN254_PIPELINE_CHUNK", BN254_OPT_PIPELINE_CHUNK}, {"BN254_PIPELINE_SLOTS", BN254_OPT_PIPELINE_SLOTS}};
+            {"BN254_PIPELINE_CHUNK", BN254_OPT_PIPELINE_CHUNK}, {"BN254_PIPELINE_SLOTS", BN254_OPT_PIPELINE_SLOTS},
+            {"BN254_STREAM_STOP_AT_ERROR", BN254_OPT_STREAM_STOP_AT_ERROR}};
         for (const auto &v : vars)
             if (const char *e = getenv(v.name)) { const long x = atol(e); if (x >= 0) env.opt[v.key] = x; }
         if (const char *e = getenv("BN254_MULTI_AFFINITY")) env.affinity = atoi(e) != 0;
@@ -265,6 +266,7 @@ bool bn_opt_valid(int key, long v) {
         case BN254_OPT_PRODUCT_BFLY: return v <= 5;
         case BN254_OPT_ROUND_PAIRS: case BN254_OPT_PIPELINE_CHUNK: return v >= 1;
         case BN254_OPT_PIPELINE_SLOTS: return v >= 1 && v <= BN_MAX_SLOTS;
+        case BN254_OPT_STREAM_STOP_AT_ERROR: return v <= 1;
         default: return false;
     }
 }
@@ -277,13 +279,13 @@ long bn_opt(const bn254_ctx *c, int key) {
     const long cus = c->cus > 0 ? c->cus : 256;
     switch (key) {
         // one pairing / exponentiation per WAVE: a workgroup needs 11.5 KB of LDS, thirteen fit a CU; a pairing takes 1.05 ms up to 4 per CU
-        // (one wave per SIMD), 1.5 ms at 8, 2.05 ms at 12, 3.2 ms at 16 per CU - and 2.8 ms on four lanes (bn254_kernels_q.hip) whatever
-        // the count up to 64 per CU; a final exponentiation 0.5 / 0.7 / 1.46 ms at 4 / 8 / 16 per CU against 1.37 ms on four lanes
-        // (profiles/r04_wave_latency.json, 256 CUs).  They cross at ~14 and ~15 per CU.
+        // (one wave per SIMD), 1.5 ms at 8, 2.05 ms at 12, 3.2 ms at 16 per CU - and 2.7 ms on four lanes (bn254_kernels_q.hip) whatever
+        // the count up to 64 per CU; a final exponentiation 0.5 / 0.74 / 1.48 ms at 4 / 8 / 16 per CU against 1.24 ms on four lanes
+        // (profiles/r04_wave_latency.json, 256 CUs).  They cross at ~14 and ~13 per CU.
         case BN254_OPT_WAVE_PAIRING_MAX: return (BN254_HAVE_QUAD ? 14 : 20) * cus;
-        case BN254_OPT_WAVE_FE_MAX: return (BN254_HAVE_QUAD ? 15 : 20) * cus;
+        case BN254_OPT_WAVE_FE_MAX: return (BN254_HAVE_QUAD ? 13 : 20) * cus;
         case BN254_OPT_QUAD_MAX: return BN254_HAVE_QUAD ? 64 * cus : 0;
-        case BN254_OPT_MILLER_SHARED: case BN254_OPT_GT_POW_MODE: return 0;
+        case BN254_OPT_MILLER_SHARED: case BN254_OPT_GT_POW_MODE: case BN254_OPT_STREAM_STOP_AT_ERROR: return 0;
         case BN254_OPT_ROUND_PAIRS: return 256 * cus;
         case BN254_OPT_PIPELINE_SLOTS: return 2;
         default: return -1;                  // product shape, pipeline chunk: decided per call from the size
@@ -830,8 +832,10 @@ static int stream_encode(bn254_ctx *ctx, int g, const void *p, size_t n, uint8_t
 static int stream_decode(bn254_ctx *ctx, int g, const uint8_t *in, size_t len, void *out, int32_t *status, size_t max_points, size_t *count, size_t *consumed) {
     if (!count || !consumed || (len && !in) || (max_points && (!out || !status))) return BN254_E_BAD_ARG;
     const size_t rs = g == 1 ? BN254_G1_WIRE_BYTES : BN254_G2_WIRE_BYTES;
+    { int rc0 = bn_get_ctx(ctx); if (rc0) return rc0; }
     return bn_no_throw([&]() -> int {
         std::vector<uint8_t> fixed;
+        std::vector<size_t> ends;                                   // stream position behind every record
         size_t pos = 0, n = 0;
         while (pos < len && n < max_points) {
             // tag 0: one byte; tag 4: a full record; any other tag is the crate's "invalid leading byte" - it consumes the byte it read
@@ -840,9 +844,13 @@ static int stream_decode(bn254_ctx *ctx, int g, const uint8_t *in, size_t len, v
             fixed.resize((n + 1) * rs, 0);
             memcpy(fixed.data() + n * rs, in + pos, rec);
             pos += rec; ++n;
+            ends.push_back(pos);
         }
         int rc = g == 1 ? bn254_g1_decode_batch(ctx, fixed.data(), (bn_g1 *)out, status, n) : bn254_g2_decode_batch(ctx, fixed.data(), (bn_g2 *)out, status, n);
         if (rc) return rc;
+        if (bn_opt(ctx, BN254_OPT_STREAM_STOP_AT_ERROR) == 1)      // the crate's own behaviour: Decodable returns Err at the first bad record
+            for (size_t i = 0; i < n; ++i)
+                if (status[i] != 0) { n = i + 1; pos = ends[i]; break; }
         *count = n; *consumed = pos;
         return BN254_OK;
     });

@@ -34,9 +34,9 @@
  *
  * Sizes: n is limited by device memory only.  Batches are cut internally into sub-launches of at most one machine round, and the
  * context-owned tables (final exponentiation: 4 KB, Gt::pow: 14.8 KB per pairing) are sized for ONE round - 264 MB / 970 MB on an
- * MI355X whatever n is.  Up to 3584 pairings (3840 final exponentiations) per call (the tail of every multi-pairing: exactly one) run one per
+ * MI355X whatever n is.  Up to 3584 pairings (3328 final exponentiations) per call (the tail of every multi-pairing: exactly one) run one per
  * WAVE instead of one per lane pair: a pairing in 1.0 ms instead of 4.2 ms, a final exponentiation in 0.5 ms instead of 2.0 ms; from
- * there up to 16384 per call a pairing runs on FOUR lanes (2.8-2.9 ms); above, on lane pairs (BN254_OPT_* below move the thresholds).
+ * there up to 16384 per call a pairing runs on FOUR lanes (2.7 ms); above, on lane pairs (BN254_OPT_* below move the thresholds).
  *
  * Ownership: the caller owns every buffer passed in; the library owns device memory and streams inside a context and keeps
  * no pointer after a call returns.  A context is bound to one GPU.  There is NO CPU fallback: without a usable MI355X the
@@ -101,14 +101,14 @@ int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping);
    may be changed at any time; a call in flight may see the old or the new value between two of its launches - harmless, because
    every option selects between kernels that return the same bytes (the one exception is stated at BN254_OPT_GT_POW_MODE).
    For experiments only, the variables BN254_WAVE_PAIRING_MAX, BN254_WAVE_FE_MAX, BN254_QUAD_MAX, BN254_MILLER_SHARED, BN254_GT_POW_MODE,
-   BN254_PRODUCT_CHUNK / _PER_WAVE / _BFLY, BN254_ROUND_PAIRS, BN254_PIPELINE_CHUNK / _SLOTS, BN254_MULTI_EXCHANGE (rccl | peer) and
+   BN254_PRODUCT_CHUNK / _PER_WAVE / _BFLY, BN254_ROUND_PAIRS, BN254_PIPELINE_CHUNK / _SLOTS, BN254_STREAM_STOP_AT_ERROR, BN254_MULTI_EXCHANGE (rccl | peer) and
    BN254_MULTI_AFFINITY (0: no thread pinning) are
    read ONCE per process, when the first context is created, and seed the options of every context created afterwards. */
 enum {
     BN254_OPT_WAVE_PAIRING_MAX = 1, /* pairings (or Miller loops that only meet a final exponentiation) per call up to which ONE PER WAVE
                                        runs (csrc/bn254_kernels_w.hip).  Default 14 x CUs (3584): where it is level with the four-lane
                                        kernels on 256 CUs (profiles/r04_wave_latency.json), 13 workgroups of 11.5 KB LDS per CU */
-    BN254_OPT_WAVE_FE_MAX = 2,      /* the same for final exponentiations.  Default 15 x CUs */
+    BN254_OPT_WAVE_FE_MAX = 2,      /* the same for final exponentiations.  Default 13 x CUs */
     BN254_OPT_QUAD_MAX = 3,         /* pairings per call up to which (and above the two options before) a pairing is spread over FOUR lanes
                                        instead of two (csrc/bn254_kernels_q.hip): the faster mapping while lane pairs would leave SIMDs
                                        empty.  Default 64 x CUs (16384): half a machine round of lane pairs */
@@ -126,7 +126,10 @@ enum {
                                        on every SIMD; larger batches run as equal sub-launches of at most this size */
     BN254_OPT_PIPELINE_CHUNK = 10,  /* pairings per chunk of the pipelined host-buffer path.  Default: the sub-launch size */
     BN254_OPT_PIPELINE_SLOTS = 11,  /* chunks in flight, 1..4.  Default 2: the number of streams the GPU overlaps without loss */
-    BN254_OPT_COUNT_ = 12
+    BN254_OPT_STREAM_STOP_AT_ERROR = 12, /* bn254_g{1,2}_decode_stream: 1 = the crate's own behaviour - its Decodable returns Err at the first bad
+                                       record (groups/mod.rs:165-175) -: `count` ends WITH the first record whose status is non-zero and
+                                       `consumed` behind it; 0 (default): decode every record, report every status */
+    BN254_OPT_COUNT_ = 13
 };
 int bn254_ctx_set_option(bn254_ctx *ctx, int key, long value);
 int bn254_ctx_get_option(bn254_ctx *ctx, int key, long *value);
@@ -209,8 +212,8 @@ int bn254_g2_decode_batch(bn254_ctx *ctx, const uint8_t *in, bn_g2 *out, int32_t
    and `consumed` bytes are reported (a truncated trailing record is left unconsumed); status[i] as for the batch decoders.
    DIFFERENCE from the crate: its Decodable returns Err at the first bad record and the caller's stream stops there
    (groups/mod.rs:165-175); this decoder records the status (a bad tag consumes its one byte, a record that fails a check consumes
-   its full length), decodes the record to G::zero() and CONTINUES with the next one - a caller that wants the crate's behaviour
-   stops at the first non-zero status[i]. */
+   its full length), decodes the record to G::zero() and CONTINUES with the next one.  bn254_ctx_set_option(ctx,
+   BN254_OPT_STREAM_STOP_AT_ERROR, 1) selects the crate's behaviour: the call stops with the first bad record (count includes it). */
 int bn254_g1_encode_stream(bn254_ctx *ctx, const bn_g1 *p, size_t n, uint8_t *out, size_t cap, size_t *written);
 int bn254_g2_encode_stream(bn254_ctx *ctx, const bn_g2 *p, size_t n, uint8_t *out, size_t cap, size_t *written);
 int bn254_g1_decode_stream(bn254_ctx *ctx, const uint8_t *in, size_t len, bn_g1 *out, int32_t *status, size_t max_points, size_t *count, size_t *consumed);

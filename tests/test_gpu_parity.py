@@ -116,7 +116,7 @@ def test_options_api(eng):
     """bn254_ctx_set_option / get_option: defaults derive from the CU count, values are validated, negative restores the default"""
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    assert eng.get_option("wave_pairing_max") == 14 * cus and eng.get_option("wave_fe_max") == 15 * cus
+    assert eng.get_option("wave_pairing_max") == 14 * cus and eng.get_option("wave_fe_max") == 13 * cus
     assert eng.get_option("round_pairs") == 256 * cus and eng.get_option("pipeline_slots") == 2
     assert eng.get_option("miller_shared") == 0 and eng.get_option("gt_pow_mode") == 0
     eng.set_option("wave_pairing_max", 7); assert eng.get_option("wave_pairing_max") == 7
@@ -858,6 +858,15 @@ def test_wire_stream_format_on_gpu(oracle, eng):
         assert np.array_equal(out2[1:], out[:out2.shape[0] - 1])
         out3, st3, used3 = decs(got, max_points=5)
         assert out3.shape[0] == 5 and np.array_equal(out3, out[:5])
+        # the crate's own behaviour on request (BN254_OPT_STREAM_STOP_AT_ERROR): its Decodable returns Err at the first bad record
+        # (groups/mod.rs:165-175) - a good record, then a bad tag: the call stops WITH the bad record, the rest stays unconsumed
+        first = got[:1] if got[0] == 0 else got[:len(enc1(pts[1]))]
+        bad = np.concatenate([first, np.array([9], np.uint8), got[first.size:first.size + 300]])
+        with eng.options(stream_stop_at_error=1):
+            out4, st4, used4 = decs(bad)
+        assert out4.shape[0] == 2 and st4[0] == 0 and st4[1] == 3 and used4 == first.size + 1
+        out5, st5, used5 = decs(bad)                                   # default: every record, every status
+        assert out5.shape[0] > 2 and st5[1] == 3 and not st5[2:].any() and used5 > used4
 
 
 @pytest.mark.parametrize("workload", ["pairing", "product"])
