@@ -211,7 +211,8 @@ static RankCpus rank_cpus_of_device(int dev) {
     char list[4096] = {};
     const bool have = fgets(list, sizeof list, f) != nullptr; fclose(f);
     if (!have) return r;
-    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {                 // "0-15,128-143"
+    char *save = nullptr;
+    for (char *tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {     // "0-15,128-143"
         int a = 0, b = 0;
         const int k = sscanf(tok, "%d-%d", &a, &b);
         if (k < 1) continue;
