@@ -81,6 +81,15 @@ template <int CX, int CY, int CZ>
 BN_FN Fq2A f2_lc_xi2(const Fq2A &x, const Fq2A &y, const Fq2A &z) {
     return {fe_lc4_core<9 * CX, -CX, CY, CZ>(x.c0, x.c1, y.c0, z.c0, false), fe_lc4_core<9 * CX, CX, CY, CZ>(x.c1, x.c0, y.c1, z.c1, false)};
 }
+// every term in the 64-bit chain (fe.hpp WIDE): signed lazy inputs of any limb bound <= 4 each
+template <int CX, int CY, int CZ>
+BN_FN Fq2A f2_lc_xi2w(const Fq2A &x, const Fq2A &y, const Fq2A &z) {
+    return {fe_lc4_core<9 * CX, -CX, CY, CZ, true>(x.c0, x.c1, y.c0, z.c0, false), fe_lc4_core<9 * CX, CX, CY, CZ, true>(x.c1, x.c0, y.c1, z.c1, false)};
+}
+template <int C1, int C2, int C3>
+BN_FN Fq2A f2_lc3sw(const Fq2A &x, const Fq2A &y, const Fq2A &z) {
+    return {fe_lc4_core<C1, C2, C3, 0, true>(x.c0, y.c0, z.c0, z.c0, false), fe_lc4_core<C1, C2, C3, 0, true>(x.c1, y.c1, z.c1, z.c1, false)};
+}
 BN_FN Fq2A f2_mul_xi(const Fq2A &x) { return f2_lc_xi<1, 0>(x, x); }
 // (27 - 3i) * x = (27 x0 + 3 x1) + (27 x1 - 3 x0) i: the curve constant 3 b' t^6 of the isomorphic curve (pairing.hpp)
 BN_FN Fq2A f2_mul_iso3b(const Fq2A &x) { return {fe_lc3<27, 3, 0>(x.c0, x.c1, x.c1), fe_lc3<27, -3, 0>(x.c1, x.c0, x.c0)}; }
