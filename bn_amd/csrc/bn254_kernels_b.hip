@@ -525,16 +525,25 @@ __device__ __noinline__ void gt_pow_strict_cold(const Fq12<F2> *base, const uint
     PowTable t = *tbl;
     *res = gt_pow_cyclotomic(*base, raw, t);
 }
+__device__ __noinline__ void gt_pow_gls_table_cold(const Fq12<F2> *base, const PowTable *tbl) {
+    PowTable t = *tbl;
+    gt_pow_gls_table(*base, t);
+}
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table, int mode) {
     BN_KERNEL_PROLOGUE();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
-    uint32_t kw[8], raw[8];
+    // the scalar is fetched and taken out of Montgomery form where it is first needed - AFTER the table construction on the main path:
+    // live across it, its eight words (and the address they came from) were spilled
+    auto load_scalar = [&](uint32_t *raw) {
+        uint32_t kw[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kw[i] = k[8u * pair + i];
-    fr_from_mont(kw, raw);
+        for (int i = 0; i < 8; ++i) kw[i] = k[8u * pair + i];
+        fr_from_mont(kw, raw);
+    };
+    uint32_t raw[8];
 #ifdef BN_POW_TABLE_ENTRY_MAJOR
     PowTable tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
 #else
@@ -546,9 +555,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     // r - all the reference's Gt can hold), 2: the one-dimensional signed-window chain (exact for ANY cyclotomic element), 1 or a
     // non-cyclotomic element in the wave: the general chain (exact for any Fq12)
     const bool cyc = mode != 1 && __all(gt_is_cyclotomic(base));
-    if (cyc && mode == 0) res = gt_pow_gls(base, raw, tbl);
-    else if (cyc) gt_pow_strict_cold(&base, raw, &tbl, &res);
-    else gt_pow_general_cold(&base, raw, &tbl, &res);
+    if (cyc && mode == 0) { gt_pow_gls_table_cold(&base, &tbl); load_scalar(raw); res = gt_pow_gls_loop<F2>(raw, tbl); }
+    else if (cyc) { load_scalar(raw); gt_pow_strict_cold(&base, raw, &tbl, &res); }
+    else { load_scalar(raw); gt_pow_general_cold(&base, raw, &tbl, &res); }
     if (live) f12_store(res, out + 96u * pair);
 }
 // out[i] = a[i]^-1   (Gt::inverse, lib.rs:172 -> fq12.rs:284-292; one Fq inversion per element, constant-time divsteps)

@@ -590,9 +590,10 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
 // cyclotomic, which every such value is; order r itself would cost an exponentiation to check - the strict mode of the kernel
 // (gt_pow_cyclotomic) is exact for ANY cyclotomic element instead.
 constexpr int GT_GLS_ENTRIES = 1 + 4 * 8;
+// the table: one, a^1 .. a^8 and their three Frobenius images (33 entries).  A function of its own so that a kernel can keep it OUT of
+// line: inlined, its values stayed live into the window loop's register allocation (17-22 spilled VGPRs in bn254_gt_pow_B)
 template <class F2, class Tbl>
-BN_FN Fq12<F2> gt_pow_gls(const Fq12<F2> &base, const uint32_t *k_raw, Tbl &tbl) {
-    const GlsSplit g = gls_decompose(k_raw);
+BN_FN void gt_pow_gls_table(const Fq12<F2> &base, Tbl &tbl) {
     tbl.put(0, f12_one<F2>());
     tbl.put(1, base);
 #pragma unroll 1
@@ -609,6 +610,11 @@ BN_FN Fq12<F2> gt_pow_gls(const Fq12<F2> &base, const uint32_t *k_raw, Tbl &tbl)
         tbl.put(16 + e, f12_frobenius_one<2>(v));
         tbl.put(24 + e, f12_frobenius_one<3>(v));
     }
+}
+// the window loop over a table built by gt_pow_gls_table
+template <class F2, class Tbl>
+BN_FN Fq12<F2> gt_pow_gls_loop(const uint32_t *k_raw, Tbl &tbl) {
+    const GlsSplit g = gls_decompose(k_raw);
     Fq12<F2> res = f12_one<F2>();
 #pragma unroll 1
     for (int w = GLS_WINDOWS - 1; w >= 0; --w) {
@@ -628,6 +634,11 @@ BN_FN Fq12<F2> gt_pow_gls(const Fq12<F2> &base, const uint32_t *k_raw, Tbl &tbl)
         }
     }
     return res;
+}
+template <class F2, class Tbl>
+BN_FN Fq12<F2> gt_pow_gls(const Fq12<F2> &base, const uint32_t *k_raw, Tbl &tbl) {
+    gt_pow_gls_table(base, tbl);
+    return gt_pow_gls_loop<F2>(k_raw, tbl);
 }
 
 // the same chains with the table in a local array (host simulation)

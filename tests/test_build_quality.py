@@ -36,9 +36,9 @@ def _blocks(text, pat):
     return out
 
 
-# bn254_gt_pow_B: its 17 spilled VGPRs are loop-invariant per-lane scalars (pair index, the input / output / table addresses, flags) stored
-# once in the prologue and reloaded in the epilogue and once per window OUTSIDE the squaring / product blocks (llvm's "Folded Spill" /
-# "Folded Reload" annotations: 8 stores at the top, single-dword reloads between the blocks) - what matters is checked here
+# bn254_gt_pow_B: its 13 spilled VGPRs (round 3: 17; the table construction is out of line and the scalar is fetched after it since round 4)
+# are loop-invariant per-lane scalars - pair index, the input / output / table addresses - stored in the prologue and reloaded in the
+# epilogue and between the blocks (llvm's "Folded Spill" / "Folded Reload" annotations); what matters is checked here
 @pytest.mark.parametrize("kernel", ["bn254_miller_naf_B", "bn254_final_exp_B", "bn254_gt_pow_B", "bn254_miller_naf_Q", "bn254_final_exp_Q"])
 def test_hot_loops_are_spill_free(kernel):
     import isa_mix
@@ -60,7 +60,7 @@ def test_hot_loops_are_spill_free(kernel):
 # double, not a performance path; their spills are recorded, not guarded.
 SPILL_CEILING = {
     "bn254_miller_B": 0, "bn254_miller_naf_B": 0, "bn254_final_exp_B": 5, "bn254_miller_shared2_B": 6, "bn254_miller_shared4_B": 20,
-    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 7, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 22, "bn254_gt_inverse_B": 4,
+    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 7, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 13, "bn254_gt_inverse_B": 4,
     "bn254_exp_by_neg_z_B": 4, "bn254_miller_naf_Q": 0, "bn254_final_exp_Q": 0,
     "bn254_g1_mul_M": 5, "bn254_g1_mul_chain_M": 10,      # (outside the window loop: test_scalar_multiplication_loops_do_not_store_to_scratch)
     "bn254_g2_mul_M": 0, "bn254_g2_mul_chain_M": 0, "bn254_g1_add_M": 0, "bn254_g2_add_M": 0,
