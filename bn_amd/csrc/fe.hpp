@@ -613,6 +613,58 @@ BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
     return r;
 }
 
+// (a1 u1 + c1 v1 + a2 u2 + c2 v2 + a3 u3 + c3 v3) / R with ONE reduction: 486 + 81 mads.  Three Fq2 products of the lane-pair mapping summed
+// before they are reduced (tower.hpp f12_mul_by_024: every output coefficient of the sparse line product is such a sum).
+// Column bound: 6 * 9 + 9 = 63 terms of (2^29 - 1)^2 plus a carry stay below 2^64 ONLY for normalized limbs - every operand must have lb = 1.
+// Value: sum of the vb products <= 338 gives a result below 3q.
+BN_FN Fe fe_mul6(const Fe &a1, const Fe &u1, const Fe &c1, const Fe &v1, const Fe &a2, const Fe &u2, const Fe &c2, const Fe &v2,
+                 const Fe &a3, const Fe &u3, const Fe &c3, const Fe &v3) {
+#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+    return fe_mul6_asm(a1, u1, c1, v1, a2, u2, c2, v2, a3, u3, c3, v3);
+#endif
+    BN_COUNT(mul2); BN_COUNT(mul2); BN_COUNT(mul2);           // (counted as three dual products: the executed-chain figures stay comparable)
+    const Fe *x[6] = {&a1, &c1, &a2, &c2, &a3, &c3}, *y[6] = {&u1, &v1, &u2, &v2, &u3, &v3};
+#if defined(BN_BOUNDS)
+    unsigned vsum = 0;
+    for (int k = 0; k < 6; ++k) {
+        BN_REQUIRE(!x[k]->sg && !y[k]->sg, "fe_mul6 on a signed lazy value");
+        BN_REQUIRE(x[k]->lb == 1 && y[k]->lb == 1, "fe_mul6 needs normalized limbs in every operand (63 column terms)");
+        vsum += x[k]->vb * y[k]->vb;
+    }
+    BN_REQUIRE(vsum <= 338, "fe_mul6 value bound");                       // <= 169: result < 2q;  <= 338: result < 3q
+#endif
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fe r;
+#pragma unroll
+    for (int col = 0; col < 9; ++col) {
+#pragma unroll
+        for (int i = 0; i <= col; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc += (uint64_t)x[k]->l[i] * y[k]->l[col - i];
+#pragma unroll
+        for (int i = 0; i < col; ++i) acc += (uint64_t)m[i] * k::Q[col - i];
+        m[col] = ((uint32_t)acc * k::QINV) & MASK29;
+        acc += (uint64_t)m[col] * k::Q[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int col = 9; col < 17; ++col) {
+#pragma unroll
+        for (int i = col - 8; i <= 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc += (uint64_t)x[k]->l[i] * y[k]->l[col - i];
+#pragma unroll
+        for (int i = col - 8; i <= 8; ++i) acc += (uint64_t)m[i] * k::Q[col - i];
+        r.l[col - 9] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    BN_SETB(r, 1, (vsum <= 169 ? 2 : 3));
+    BN_VERIFY(r, "fe_mul6");
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // boundary conversions: the C ABI speaks the reference's format (8 x u32 = [u64;4] little endian, a*2^256 mod q, < q)
 BN_FN Fe fe_unpack_u32x8(const uint32_t *w) {     // raw 256-bit integer -> 29-bit limbs (no Montgomery change)

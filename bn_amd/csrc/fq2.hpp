@@ -189,6 +189,20 @@ BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a
 BN_FN Fe f2b_sqr(const Fe &a) { return bn_unv(f2b_sqr_leaf(bn_tov(a))); }
 #endif
 
+// A multiplier PREPARED for the lane-pair product: (u, v) such that this lane's component of a * b is own_a * u + partner_a * v.  With
+// every limb normalized (the negated component too), three products can share one reduction (fe_mul6):
+//     reduce(a1 b1 + a2 b2 + a3 b3)     inputs: normalized limbs (standard form, or carry-propagated sums below 4q for the a_i)
+// which is how the sparse line product forms each of its six output coefficients (tower.hpp f12_mul_by_024).
+template <class T> struct Fq2BPrep { T u, v; };
+template <class T>
+BN_FN Fq2BPrep<T> f2b_prepare(const Fq2B<T> &b) {
+    const T pb = lane_partner(b.v);
+    return {lane_pick(b.v, pb), lane_pick(fe_norm(fe_neg<1, 9>(pb)), b.v)};
+}
+template <class T>
+BN_FN Fq2B<T> f2b_mul3(const Fq2B<T> &a1, const Fq2BPrep<T> &b1, const Fq2B<T> &a2, const Fq2BPrep<T> &b2, const Fq2B<T> &a3, const Fq2BPrep<T> &b3) {
+    return {fe_mul6(a1.v, b1.u, lane_partner(a1.v), b1.v, a2.v, b2.u, lane_partner(a2.v), b2.v, a3.v, b3.u, lane_partner(a3.v), b3.v)};
+}
 template <class T> BN_FN Fq2B<T> f2_add(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_add(a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_dbl(const Fq2B<T> &a) { return {fe_dbl(a.v)}; }
 template <int LB, int K, class T> BN_FN Fq2B<T> f2_sub(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_sub<LB, K>(a.v, b.v)}; }

