@@ -77,19 +77,17 @@ BN_COARSE QFq12<F2> q12_sqr(const QFq12<F2> &a) {
 //   S = other * x4 coefficient-wise;   v^2 S = (xi s1, xi s2, s0),   v S = (xi s2, s0, s1)
 template <class F2>
 BN_COARSE QFq12<F2> q12_mul_by_024(const QFq12<F2> &f, const F2 &ell_0, const F2 &ell_vw, const F2 &ell_vv) {
-    const F2 &x0 = ell_0, &x2 = ell_vv, &x4 = ell_vw;
+    // by lazy reduction like tower.hpp f12_mul_by_024: every output coefficient is ONE chain of three Fq2 products (fe_mul6) over
+    // multipliers prepared once - 9 products, 3 reductions and no recombination per pair instead of 8 products, 8 reductions and 3 fused ones
     const Fq6<F2> o = f6_xq(f.h);
     const F2 &a0 = f.h.c0, &a1 = f.h.c1, &a2 = f.h.c2;
-    const F2 a02 = f2_add(a0, a2);
-    BN_COMPILER_FENCE();
-    const F2 p00 = f2_mul(a0, x0), p22 = f2_mul(a2, x2);
-    const F2 p12 = f2_mul(a1, x2), p10 = f2_mul(a1, x0);
-    const F2 s0 = f2_mul(o.c0, x4), s1 = f2_mul(o.c1, x4), s2 = f2_mul(o.c2, x4);
+    const auto x0 = f2b_prepare(ell_0), xx2 = f2b_prepare(f2_mul_xi(ell_vv)), x4 = f2b_prepare(ell_vw), xx4 = f2b_prepare(f2_mul_xi(ell_vw));
+    decltype(x4) x4m = {quad_pick(xx4.u, x4.u), quad_pick(xx4.v, x4.v)};                       // lower: xi x4, upper: x4
     QFq12<F2> r;
-    r.h.c0 = f2_lc_xi<1, 1>(f2_add(p12, f2_qpick(s1, s2)), p00);                               // a0 x0 + xi (a1 x2 + [s1 | s2])
-    r.h.c1 = f2_lc_xi<1, 1>(f2_qpick(f2_add(p22, s2), p22), f2_qpick(p10, f2_add(p10, s0)));    // a1 x0 + xi a2 x2 + [xi s2 | s0]
-    const F2 pk = f2_mul(a02, f2_norm(f2_add(x0, x2)));
-    r.h.c2 = f2_lc3<1, -1, -1>(f2_add(pk, f2_qpick(s0, s1)), p00, p22);                        // a0 x2 + a2 x0 + [s0 | s1]
+    r.h.c0 = f2b_mul3(a0, x0, a1, xx2, f2_qpick(o.c1, o.c2), xx4);                              // a0 x0 + xi a1 x2 + xi [o1 | o2] x4
+    r.h.c1 = f2b_mul3(a1, x0, a2, xx2, f2_qpick(o.c2, o.c0), x4m);                              // a1 x0 + xi a2 x2 + [xi o2 | o0] x4
+    const auto x2 = f2b_prepare(ell_vv);
+    r.h.c2 = f2b_mul3(a2, x0, a0, x2, f2_qpick(o.c0, o.c1), x4);                                // a2 x0 + a0 x2 + [o0 | o1] x4
     return r;
 }
 // f <- f * line(P).  The two scalings of the line by P's coordinates (groups/mod.rs:502: ell_vw * P.y, ell_vv * P.x) are the one piece of
