@@ -352,18 +352,29 @@ BN_FN Fe fe_reduce(const Fe &a) {
 // subtracts and the odd lane adds the partner's limb in xi-multiplications)
 // WIDE: every term enters the 64-bit chain on its own (no 32-bit pre-combination), which lifts the bound on the SUM of the inputs' limb
 // bounds - each input still has to fit int32 (lb <= 4).  Used where one reduction takes the place of several (quad.hpp).
-template <int C1, int C2, int C3, int C4, bool WIDE = false>
+#if defined(BN_NO_PAR_SIGN2)     // experiment switch: the role-signed term of the _par reductions through negate-and-select (rounds 1-3)
+#define BN_PAR_SIGN2 false
+#else
+#define BN_PAR_SIGN2 true
+#endif
+// SIGN2: the middle term's sign really is a per-lane value (the _par callers): the term then enters the 64-bit chain with a per-lane
+// coefficient register (one multiply-add per limb) instead of a negate-and-select before the narrow sum (two to three instructions).
+template <int C1, int C2, int C3, int C4, bool WIDE = false, bool SIGN2 = false>
 BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool neg2) {
     BN_COUNT(lc3);
     constexpr int A1 = C1 < 0 ? -C1 : C1, A2 = C2 < 0 ? -C2 : C2, A3 = C3 < 0 ? -C3 : C3, A4 = C4 < 0 ? -C4 : C4;
     // Every input limb is read as a SIGNED 32-bit integer (so inputs may be signed lazy differences, fe_ssub): |limb| < 2^31,
     // i.e. lb <= 4.  Terms with a small coefficient are first combined in 32-bit arithmetic ("narrow"); the others enter the
     // 64-bit chain on their own.
-    constexpr bool N1 = !WIDE && C1 != 0 && A1 <= 2, N2 = !WIDE && C2 != 0 && A2 <= 2, N3 = !WIDE && C3 != 0 && A3 <= 2, N4 = !WIDE && C4 != 0 && A4 <= 2;
+    // A LONE small term with a coefficient other than +1 would cost a shift or a negation AND the multiply-add that takes the narrow
+    // sum into the chain: it goes into the chain directly instead (one multiply-add).
+    constexpr bool K1 = !WIDE && C1 != 0 && A1 <= 2, K2 = !WIDE && !SIGN2 && C2 != 0 && A2 <= 2, K3 = !WIDE && C3 != 0 && A3 <= 2, K4 = !WIDE && C4 != 0 && A4 <= 2;
+    constexpr bool LONE = (int)K1 + (int)K2 + (int)K3 + (int)K4 == 1;
+    constexpr bool N1 = K1 && !(LONE && C1 != 1), N2 = K2 && !(LONE && C2 != 1), N3 = K3 && !(LONE && C3 != 1), N4 = K4 && !(LONE && C4 != 1);
     BN_IFB(if (!((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4) && (C4 == 0 || w.lb <= 4)))
                std::fprintf(stderr, "fe_lc<%d,%d,%d,%d> lbs %u %u %u %u\n", C1, C2, C3, C4, x.lb, y.lb, z.lb, w.lb);)
     BN_REQUIRE((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4) && (C4 == 0 || w.lb <= 4), "fe_lc: input limbs must fit int32");
-    BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb + (uint64_t)A4 * w.vb <= 1000, "fe_lc vb");
+    BN_REQUIRE((uint64_t)A1 * x.vb + (uint64_t)A2 * y.vb + (uint64_t)A3 * z.vb + (uint64_t)A4 * w.vb <= 500, "fe_lc vb");     // keeps the quotient estimate below in 32 bits: |te| < 500 * 2^21.6 + 1000 < 2^31
     BN_IFB(if ((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) + (N4 ? A4 * w.lb : 0) > 4)
                std::fprintf(stderr, "fe_lc<%d,%d,%d,%d> lbs %u %u %u %u\n", C1, C2, C3, C4, x.lb, y.lb, z.lb, w.lb);)
     BN_REQUIRE((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) + (N4 ? A4 * w.lb : 0) <= 4, "fe_lc narrow part exceeds 32 bits");
@@ -371,21 +382,43 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
     // at most 9 per unit coefficient, and the truncation of FE_MU24, < 2^9 units)
     auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8] + ((int32_t)f.l[7] >> 29); };
     const int32_t c2 = neg2 ? -C2 : C2;
-    int64_t te = -600 - 9 * (int64_t)(A1 + A2 + A3 + A4);
-    if (C1 != 0) te += (int64_t)C1 * top(x);
-    if (C2 != 0) te += (int64_t)c2 * top(y);
-    if (C3 != 0) te += (int64_t)C3 * top(z);
-    if (C4 != 0) te += (int64_t)C4 * top(w);
-    const int64_t kq = (te * (int64_t)k::FE_MU24) >> 45;     // floor; kq <= floor(value/q), kq >= value/q - 2
+    // 32-bit arithmetic (a value below vb q has a top limb below vb * 2^21.6, and the sum of |C| vb is at most 500: checked above):
+    // one v_mul_hi_i32 and a shift on the GPU instead of a 64 x 32-bit product
+    int32_t te = -600 - 9 * (A1 + A2 + A3 + A4);
+    if (C1 != 0) te += C1 * top(x);
+    if (C2 != 0) te += c2 * top(y);
+    if (C3 != 0) te += C3 * top(z);
+    if (C4 != 0) te += C4 * top(w);
+    const int64_t kq = ((int64_t)te * (int64_t)k::FE_MU24) >> 45;     // floor; kq <= floor(value/q), kq >= value/q - 2
     Fe r;
     int64_t carry = 0;
 #if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM) && !defined(BN_NO_ASM_REDUCE)
     // GPU: the 64-bit chain of a limb as ONE asm statement of v_mad_i64_i32 (carry - kq q_i + narrow sum + the wide terms), like the
     // multiplier leaves (fe_asm.hpp): the compiler otherwise builds it from sign extensions, 64-bit adds and - in some contexts -
     // v_mul_lo / v_mul_hi pairs.  Same arithmetic, limb for limb.
-    const int32_t nkq = (int32_t)(0 - kq);
+    // kq * (-q_i): the quotient estimate itself against the NEGATED modulus limb (a signed 32-bit scalar operand), so no negation of kq;
+    // limb 0 starts its chain from the inline constant 0 (no accumulator to clear).
+    const int32_t kq32 = (int32_t)kq;
     constexpr int NWIDE = (C1 != 0 && !N1) + (C2 != 0 && !N2) + (C3 != 0 && !N3) + (C4 != 0 && !N4);
     constexpr bool ANY_NARROW = N1 || N2 || N3 || N4;
+#define BN_LC_NARROW "\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0"
+#define BN_LC_CHAIN(OUT, ACC0)                                                                                                                        \
+    if constexpr (NWIDE == 0) {                                                                                                                       \
+        if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 BN_LC_NARROW : OUT(t) : "v"(kq32), "s"(nqi), "v"(nsum) : "vcc");        \
+        else asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 : OUT(t) : "v"(kq32), "s"(nqi) : "vcc");                                                      \
+    } else if constexpr (NWIDE == 1) {                                                                                                                \
+        if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 BN_LC_NARROW "\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0" : OUT(t) : "v"(kq32), "s"(nqi), "v"(nsum), "v"(wc[0]), "v"(wv[0]) : "vcc"); \
+        else asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 "\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0" : OUT(t) : "v"(kq32), "s"(nqi), "v"(wc[0]), "v"(wv[0]) : "vcc"); \
+    } else if constexpr (NWIDE == 2) {                                                                                                                \
+        if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 BN_LC_NARROW "\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0\n\tv_mad_i64_i32 %0, vcc, %6, %7, %0" : OUT(t) : "v"(kq32), "s"(nqi), "v"(nsum), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]) : "vcc"); \
+        else asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 "\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0" : OUT(t) : "v"(kq32), "s"(nqi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]) : "vcc"); \
+    } else if constexpr (NWIDE == 3) {                                                                                                                \
+        if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 BN_LC_NARROW "\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0\n\tv_mad_i64_i32 %0, vcc, %6, %7, %0\n\tv_mad_i64_i32 %0, vcc, %8, %9, %0" : OUT(t) : "v"(kq32), "s"(nqi), "v"(nsum), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]) : "vcc"); \
+        else asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 "\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0" : OUT(t) : "v"(kq32), "s"(nqi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]) : "vcc"); \
+    } else {                                                                                                                                          \
+        asm("v_mad_i64_i32 %0, vcc, %1, %2, " ACC0 "\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0" : OUT(t) : "v"(kq32), "s"(nqi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]), "v"(wc[3]), "v"(wv[3]) : "vcc"); \
+        if constexpr (ANY_NARROW) t += (int64_t)nsum;                                                                                                 \
+    }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         int32_t nsum = 0;
@@ -393,7 +426,7 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
         if (N2) { int32_t yy = C2 * (int32_t)y.l[i]; nsum += neg2 ? -yy : yy; }
         if (N3) nsum += C3 * (int32_t)z.l[i];
         if (N4) nsum += C4 * (int32_t)w.l[i];
-        // the wide terms in order; a term that is absent multiplies by the inline constant 0 (never emitted: see the switch on NWIDE)
+        // the wide terms in order
         int32_t wc[4], wv[4];
         int nw = 0;
         if (C1 != 0 && !N1) { wc[nw] = C1; wv[nw] = (int32_t)x.l[i]; ++nw; }
@@ -401,25 +434,12 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
         if (C3 != 0 && !N3) { wc[nw] = C3; wv[nw] = (int32_t)z.l[i]; ++nw; }
         if (C4 != 0 && !N4) { wc[nw] = C4; wv[nw] = (int32_t)w.l[i]; ++nw; }
         int64_t t = carry;
-        const uint32_t qi = k::Q[i];
-        if constexpr (NWIDE == 0) {
-            if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(nsum) : "vcc");
-            else asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(t) : "v"(nkq), "s"(qi) : "vcc");
-        } else if constexpr (NWIDE == 1) {
-            if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(nsum), "v"(wc[0]), "v"(wv[0]) : "vcc");
-            else asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(wc[0]), "v"(wv[0]) : "vcc");
-        } else if constexpr (NWIDE == 2) {
-            if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0\n\tv_mad_i64_i32 %0, vcc, %6, %7, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(nsum), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]) : "vcc");
-            else asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]) : "vcc");
-        } else if constexpr (NWIDE == 3) {
-            if constexpr (ANY_NARROW) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, 1, %3, %0\n\tv_mad_i64_i32 %0, vcc, %4, %5, %0\n\tv_mad_i64_i32 %0, vcc, %6, %7, %0\n\tv_mad_i64_i32 %0, vcc, %8, %9, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(nsum), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]) : "vcc");
-            else asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]) : "vcc");
-        } else {
-            asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0" : "+v"(t) : "v"(nkq), "s"(qi), "v"(wc[0]), "v"(wv[0]), "v"(wc[1]), "v"(wv[1]), "v"(wc[2]), "v"(wv[2]), "v"(wc[3]), "v"(wv[3]) : "vcc");
-            if constexpr (ANY_NARROW) t += (int64_t)nsum;
-        }
+        const int32_t nqi = -(int32_t)k::Q[i];
+        if (i == 0) { BN_LC_CHAIN("=&v", "0") } else { BN_LC_CHAIN("+v", "%0") }
         if (i < 8) { r.l[i] = (uint32_t)t & MASK29; carry = t >> 29; } else { r.l[i] = (uint32_t)t; }
     }
+#undef BN_LC_CHAIN
+#undef BN_LC_NARROW
 #else
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -441,8 +461,8 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
     BN_VERIFY(r, "fe_lc4_core");
     return r;
 }
-template <int C1, int C2, int C3>
-BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) { return fe_lc4_core<C1, C2, C3, 0>(x, y, z, z, neg2); }
+template <int C1, int C2, int C3, bool SIGN2 = false>
+BN_FN Fe fe_lc3_core(const Fe &x, const Fe &y, const Fe &z, bool neg2) { return fe_lc4_core<C1, C2, C3, 0, false, SIGN2>(x, y, z, z, neg2); }
 // all-64-bit variant for UNSIGNED lazy inputs with limbs beyond 31 bits (lb up to 8); rare call sites only
 template <int C1, int C2, int C3>
 BN_FN Fe fe_lc3w_body(const Fe &x, const Fe &y, const Fe &z) {

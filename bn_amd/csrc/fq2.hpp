@@ -146,10 +146,10 @@ BN_FN bool lane_pair_all_zero(const Fe &a) { bool z = fe_is_zero(a); return z &&
 BN_FN bool lane_pair_all_zero_std(const Fe &a) { bool z = fe_is_zero_std(a); return z && lane_partner_flag(z); }
 // reduce(C1*x + s*C2*y + C3*z), s = -1 on even lanes, +1 on odd lanes
 template <int C1, int C2, int C3>
-BN_FN Fe fe_lc3_par_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3>(x, y, z, !lane_is_odd()); }
+BN_FN Fe fe_lc3_par_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3, BN_PAR_SIGN2>(x, y, z, !lane_is_odd()); }
 BN_LEAF3T(fe_lc3_par, fe_lc3_par_body)
 template <int C1, int C2, int C3, int C4>
-BN_FN Fe fe_lc4_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4>(x, y, z, w, !lane_is_odd()); }
+BN_FN Fe fe_lc4_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4, false, BN_PAR_SIGN2>(x, y, z, w, !lane_is_odd()); }
 template <int C1, int C2, int C3, int C4>      // all terms in the 64-bit chain (fe.hpp WIDE)
 BN_FN Fe fe_lc4w_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4, true>(x, y, z, w, !lane_is_odd()); }
 template <int C1, int C2, int C3>
@@ -179,7 +179,71 @@ BN_FN T f2b_sqr_body(const T &a) {
     T t = lane_pick(fe_sub<1, 7>(a, pa), a);
     return fe_mul_body(s, t);
 }
-#if defined(BN_HOSTSIM)
+#if !defined(BN_HOSTSIM) && !defined(BN_NO_EXEC_GLUE)
+// The GPU's operand set-up for the two leaves above, nine instructions per role decision instead of eighteen: where only the EVEN lane
+// of a pair differs from the odd one, the difference is applied IN PLACE to a register the exchange just produced, with the odd lanes
+// switched off in EXEC for those instructions (one asm statement: save, mask, nine limbs, restore) - not computed in all lanes and then
+// selected.  Same values limb for limb as f2b_mul_body / f2b_sqr_body (which the host simulation keeps running):
+//   product: this lane's component = a0 * (own b) + a1 * X,   a0 / a1 = the pair's components of a in BOTH lanes (quad_perm [0,0,2,2] /
+//            [1,1,3,3]),  X = the partner's b, negated on the even lane          (45 -> 36 instructions around the 243 multiply-adds)
+//   square:  S = own a doubled, T = the partner's a;  even lane: S = a + T, T = a - T  (63 -> 45 around the 162 multiply-adds)
+BN_FN Fe lane_dpp_even(const Fe &x) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], 0xA0, 0xF, 0xF, true);
+    return r;
+}
+BN_FN Fe lane_dpp_odd(const Fe &x) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], 0xF5, 0xF, 0xF, true);
+    return r;
+}
+#define BN_EVEN_LANES 0x5555555555555555ull
+template <int LB, int K>
+BN_FN void fe_neg_on_even_lanes(Fe &x) {            // x <- fe_neg<LB, K>(x) on the even lanes, untouched on the odd ones
+    constexpr Bias<LB, K> B{};
+    uint64_t saved;
+    asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
+        "v_sub_u32 %[x0], %[b0], %[x0]\n\tv_sub_u32 %[x1], %[b1], %[x1]\n\tv_sub_u32 %[x2], %[b2], %[x2]\n\t"
+        "v_sub_u32 %[x3], %[b3], %[x3]\n\tv_sub_u32 %[x4], %[b4], %[x4]\n\tv_sub_u32 %[x5], %[b5], %[x5]\n\t"
+        "v_sub_u32 %[x6], %[b6], %[x6]\n\tv_sub_u32 %[x7], %[b7], %[x7]\n\tv_sub_u32 %[x8], %[b8], %[x8]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [x0] "+v"(x.l[0]), [x1] "+v"(x.l[1]), [x2] "+v"(x.l[2]), [x3] "+v"(x.l[3]), [x4] "+v"(x.l[4]), [x5] "+v"(x.l[5]), [x6] "+v"(x.l[6]),
+          [x7] "+v"(x.l[7]), [x8] "+v"(x.l[8]), [sv] "=&s"(saved)
+        : [b0] "s"(B.c[0]), [b1] "s"(B.c[1]), [b2] "s"(B.c[2]), [b3] "s"(B.c[3]), [b4] "s"(B.c[4]), [b5] "s"(B.c[5]), [b6] "s"(B.c[6]),
+          [b7] "s"(B.c[7]), [b8] "s"(B.c[8]), [m] "s"(BN_EVEN_LANES)
+        : "scc");
+}
+BN_FN Fe f2b_mul_gpu(const Fe &a, const Fe &b) {
+    const Fe a0 = lane_dpp_even(a), a1 = lane_dpp_odd(a);
+    Fe x = lane_partner(b);
+    fe_neg_on_even_lanes<1, 9>(x);
+    return fe_mul2(a0, b, a1, x);
+}
+BN_FN Fe f2b_sqr_gpu(const Fe &a) {
+    constexpr Bias<1, 7> B{};
+    Fe t = lane_partner(a), s = fe_dbl(a);
+    uint64_t saved;
+#define BN_SQ(i) "v_add_u32 %[s" #i "], %[a" #i "], %[t" #i "]\n\tv_sub_u32 %[t" #i "], %[a" #i "], %[t" #i "]\n\tv_add_u32 %[t" #i "], %[b" #i "], %[t" #i "]\n\t"
+    asm("s_and_saveexec_b64 %[sv], %[m]\n\t" BN_SQ(0) BN_SQ(1) BN_SQ(2) BN_SQ(3) BN_SQ(4) BN_SQ(5) BN_SQ(6) BN_SQ(7) BN_SQ(8) "s_mov_b64 exec, %[sv]"
+        : [s0] "+v"(s.l[0]), [s1] "+v"(s.l[1]), [s2] "+v"(s.l[2]), [s3] "+v"(s.l[3]), [s4] "+v"(s.l[4]), [s5] "+v"(s.l[5]), [s6] "+v"(s.l[6]),
+          [s7] "+v"(s.l[7]), [s8] "+v"(s.l[8]),
+          [t0] "+v"(t.l[0]), [t1] "+v"(t.l[1]), [t2] "+v"(t.l[2]), [t3] "+v"(t.l[3]), [t4] "+v"(t.l[4]), [t5] "+v"(t.l[5]), [t6] "+v"(t.l[6]),
+          [t7] "+v"(t.l[7]), [t8] "+v"(t.l[8]), [sv] "=&s"(saved)
+        : [a0] "v"(a.l[0]), [a1] "v"(a.l[1]), [a2] "v"(a.l[2]), [a3] "v"(a.l[3]), [a4] "v"(a.l[4]), [a5] "v"(a.l[5]), [a6] "v"(a.l[6]),
+          [a7] "v"(a.l[7]), [a8] "v"(a.l[8]),
+          [b0] "s"(B.c[0]), [b1] "s"(B.c[1]), [b2] "s"(B.c[2]), [b3] "s"(B.c[3]), [b4] "s"(B.c[4]), [b5] "s"(B.c[5]), [b6] "s"(B.c[6]),
+          [b7] "s"(B.c[7]), [b8] "s"(B.c[8]), [m] "s"(BN_EVEN_LANES)
+        : "scc");
+#undef BN_SQ
+    return fe_mul_body(s, t);
+}
+BN_LEAF_MUL u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_gpu(bn_unv(a), bn_unv(b))); }
+BN_LEAF_MUL u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_gpu(bn_unv(a))); }
+BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a), bn_tov(b))); }
+BN_FN Fe f2b_sqr(const Fe &a) { return bn_unv(f2b_sqr_leaf(bn_tov(a))); }
+#elif defined(BN_HOSTSIM)
 template <class T> BN_FN T f2b_mul(const T &a, const T &b) { return f2b_mul_body(a, b); }
 template <class T> BN_FN T f2b_sqr(const T &a) { return f2b_sqr_body(a); }
 #else

@@ -46,8 +46,8 @@ def test_hot_loops_are_spill_free(kernel):
     if not so.exists() or not (isa_mix.LLVM / "llvm-objdump").exists():
         pytest.skip("library or llvm-objdump not present")
     blocks = [b for text in isa_mix.disassemble(so) for b in _blocks(text, kernel)]
-    # the loop bodies: squarings, line / table products (2.8k .. 14k instructions; on four lanes a Granger-Scott squaring is 2.1k)
-    hot = [b for b in blocks if b[0] >= (2000 if kernel.endswith("_Q") else 2500)]
+    # the loop bodies: squarings, line / table products (2.7k .. 13k instructions; on four lanes a Granger-Scott squaring is 1.9k)
+    hot = [b for b in blocks if b[0] >= (1500 if kernel.endswith("_Q") else 2500)]
     assert len(hot) >= 2, blocks
     if kernel == "bn254_miller_naf_B":
         hot = hot[1:]               # the first big block is the prologue (both affine conversions around the inversion call), run once
@@ -61,12 +61,12 @@ def test_hot_loops_are_spill_free(kernel):
 # `tools/isa_mix.py --blocks KERNEL` before raising one.  The mapping-A kernels (bn254_*_A, *_mul_k) are the one-lane-per-pairing test
 # double, not a performance path; their spills are recorded, not guarded.
 SPILL_CEILING = {
-    "bn254_miller_B": 2, "bn254_miller_naf_B": 2, "bn254_final_exp_B": 5, "bn254_miller_shared2_B": 10, "bn254_miller_shared4_B": 30,
-    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 18, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 13, "bn254_gt_inverse_B": 4,
+    "bn254_miller_B": 4, "bn254_miller_naf_B": 0, "bn254_final_exp_B": 7, "bn254_miller_shared2_B": 19, "bn254_miller_shared4_B": 19,
+    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 10, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 14, "bn254_gt_inverse_B": 4,
     "bn254_exp_by_neg_z_B": 4, "bn254_miller_naf_Q": 0, "bn254_final_exp_Q": 0,
-    "bn254_g1_mul_M": 5, "bn254_g1_mul_chain_M": 10,      # (outside the window loop: test_scalar_multiplication_loops_do_not_store_to_scratch)
+    "bn254_g1_mul_M": 0, "bn254_g1_mul_chain_M": 0,      # (outside the window loop: test_scalar_multiplication_loops_do_not_store_to_scratch)
     "bn254_g2_mul_M": 0, "bn254_g2_mul_chain_M": 0, "bn254_g1_add_M": 0, "bn254_g2_add_M": 0,
-    "bn254_final_exp_W": 0, "bn254_pairing_W": 0, "bn254_gt_tail_W": 0, "bn254_wave_ubench_W": 0, "bn254_gt_reduce_W": 6,
+    "bn254_final_exp_W": 0, "bn254_pairing_W": 0, "bn254_gt_tail_W": 0, "bn254_wave_ubench_W": 0, "bn254_gt_reduce_W": 2,
     "bn254_g1_encode_k": 0, "bn254_g2_encode_k": 0, "bn254_g1_decode_k": 0, "bn254_g2_decode_k": 18, "bn254_fr_encode_k": 0, "bn254_fr_decode_k": 0,
     "bn254_ubench_mad_k": 0, "bn254_synthetic_scalars_k": 0, "bn254_tile_k": 0,
 }
@@ -74,7 +74,7 @@ UNGUARDED = {"bn254_miller_A", "bn254_final_exp_A", "bn254_gt_product_A", "bn254
 # kernels that must fit their occupancy target without private memory beyond small call frames: the hot state of the scalar
 # multiplications used to be written to scratch on every addition (round 4: 10.7 KB per G1 multiplication) - private memory that
 # is only the window-table setup stays below these sizes
-PRIVATE_CEILING = {"bn254_g1_mul_M": 1400, "bn254_g2_mul_M": 1400, "bn254_miller_naf_B": 160, "bn254_miller_B": 160}
+PRIVATE_CEILING = {"bn254_g1_mul_M": 1400, "bn254_g2_mul_M": 1400, "bn254_miller_naf_B": 160, "bn254_miller_B": 176}
 
 
 def test_spill_ceilings_of_every_kernel():
