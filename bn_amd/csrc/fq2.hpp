@@ -239,6 +239,8 @@ BN_FN Fe f2b_sqr_gpu(const Fe &a) {
 #undef BN_SQ
     return fe_mul_body(s, t);
 }
+BN_FN Fe f2b_mul_inl(const Fe &a, const Fe &b) { return f2b_mul_gpu(a, b); }      // for callers that inline the leaf themselves (wave.hpp)
+BN_FN Fe f2b_sqr_inl(const Fe &a) { return f2b_sqr_gpu(a); }
 BN_LEAF_MUL u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_gpu(bn_unv(a), bn_unv(b))); }
 BN_LEAF_MUL u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_gpu(bn_unv(a))); }
 BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a), bn_tov(b))); }
@@ -246,7 +248,11 @@ BN_FN Fe f2b_sqr(const Fe &a) { return bn_unv(f2b_sqr_leaf(bn_tov(a))); }
 #elif defined(BN_HOSTSIM)
 template <class T> BN_FN T f2b_mul(const T &a, const T &b) { return f2b_mul_body(a, b); }
 template <class T> BN_FN T f2b_sqr(const T &a) { return f2b_sqr_body(a); }
+template <class T> BN_FN T f2b_mul_inl(const T &a, const T &b) { return f2b_mul_body(a, b); }
+template <class T> BN_FN T f2b_sqr_inl(const T &a) { return f2b_sqr_body(a); }
 #else
+template <class T> BN_FN T f2b_mul_inl(const T &a, const T &b) { return f2b_mul_body(a, b); }
+template <class T> BN_FN T f2b_sqr_inl(const T &a) { return f2b_sqr_body(a); }
 BN_LEAF_MUL u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_body(bn_unv(a), bn_unv(b))); }
 BN_LEAF_MUL u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_body(bn_unv(a))); }
 BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a), bn_tov(b))); }

@@ -27,6 +27,20 @@ BN_FN Fe quad_xchg(const Fe &x) {                 // the same limb of the OTHER 
     for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], 0x4E, 0xF, 0xF, true);
     return r;
 }
+// the lower / the upper pair's value of a register on BOTH pairs: one DPP move per limb where an exchange and two selects used to build
+// "mine on my side, the other's on the other side" (quad_perm [0,1,0,1] / [2,3,2,3])
+BN_FN Fe quad_lo(const Fe &x) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], 0x44, 0xF, 0xF, true);
+    return r;
+}
+BN_FN Fe quad_up(const Fe &x) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], 0xEE, 0xF, 0xF, true);
+    return r;
+}
 BN_FN bool quad_is_upper() { return (threadIdx.x & 2u) != 0; }
 BN_FN Fe quad_pick(const Fe &lower_choice, const Fe &upper_choice) { return fe_select(quad_is_upper(), lower_choice, upper_choice); }
 // an Fq2 of the reference image at w (lower pair) or w + off (upper pair)
@@ -37,6 +51,10 @@ BN_FN void quad_store_f2(const Fq2B<Fe> &a, uint32_t *w, int off) { f2_store(a, 
 #define F2P ((const F2 *)nullptr)
 template <class F2> BN_FN F2 f2_xq(const F2 &a) { return {quad_xchg(a.v)}; }
 template <class F2> BN_FN F2 f2_qpick(const F2 &lo, const F2 &up) { return {quad_pick(lo.v, up.v)}; }
+template <class F2> BN_FN F2 f2_qlo(const F2 &a) { return {quad_lo(a.v)}; }
+template <class F2> BN_FN F2 f2_qup(const F2 &a) { return {quad_up(a.v)}; }
+template <class F2> BN_FN Fq6<F2> f6_qlo(const Fq6<F2> &a) { return {f2_qlo(a.c0), f2_qlo(a.c1), f2_qlo(a.c2)}; }
+template <class F2> BN_FN Fq6<F2> f6_qup(const Fq6<F2> &a) { return {f2_qup(a.c0), f2_qup(a.c1), f2_qup(a.c2)}; }
 template <class F2> BN_FN Fq6<F2> f6_xq(const Fq6<F2> &a) { return {f2_xq(a.c0), f2_xq(a.c1), f2_xq(a.c2)}; }
 template <class F2> BN_FN Fq6<F2> f6_qpick(const Fq6<F2> &lo, const Fq6<F2> &up) { return {f2_qpick(lo.c0, up.c0), f2_qpick(lo.c1, up.c1), f2_qpick(lo.c2, up.c2)}; }
 
@@ -54,16 +72,14 @@ template <class F2> BN_FN QFq12<F2> q12_conj(const QFq12<F2> &a) { return {f6_qp
 // feeds a sparse product, which takes that form).  ONE Fq6 product per pair.
 template <class F2>
 BN_COARSE QFq12<F2> q12_sqr(const QFq12<F2> &a) {
-    const Fq6<F2> o = f6_xq(a.h);
-    const Fq6<F2> c0 = f6_qpick(a.h, o), c1 = f6_qpick(o, a.h);
+    const Fq6<F2> c0 = f6_qlo(a.h), c1 = f6_qup(a.h);
     Fq6<F2> u;                                                    // v c1 + c0
     u.c0 = f2_lc_xi<1, 1>(c1.c2, c0.c0);
     u.c1 = f2_sum_for_mul(c1.c0, c0.c1);
     u.c2 = f2_sum_for_mul(c1.c1, c0.c2);
     const Fq6<F2> x = f6_qpick(c0, f6_add_norm(c0, c1)), y = f6_qpick(c1, u);
     const Fq6<F2> prod = f6_mul(x, y);                             // lower: ab, upper: t
-    const Fq6<F2> oprod = f6_xq(prod);
-    const Fq6<F2> ab = f6_qpick(prod, oprod), t = f6_qpick(oprod, prod);
+    const Fq6<F2> ab = f6_qlo(prod), t = f6_qup(prod);
     Fq6<F2> lo;
     lo.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_ssub(t.c0, ab.c0));          // t - ab - v ab
     lo.c1 = f2_lc3<1, -1, -1>(t.c1, ab.c1, ab.c0);
@@ -96,8 +112,7 @@ BN_COARSE QFq12<F2> q12_mul_by_024(const QFq12<F2> &f, const F2 &ell_0, const F2
 template <class F2, class S>
 BN_FN QFq12<F2> q12_apply_line(const QFq12<F2> &f, const Line<F2> &l, const G1Aff<S> &p) {
     const F2 mine = f2_scale(f2_qpick(l.ell_vw, l.ell_vv), quad_pick(p.y, p.x));
-    const F2 other = f2_xq(mine);
-    return q12_mul_by_024(f, l.ell_0, f2_qpick(mine, other), f2_qpick(other, mine));
+    return q12_mul_by_024(f, l.ell_0, f2_qlo(mine), f2_qup(mine));
 }
 
 // fq12.rs:295-307 (Karatsuba over Fq6): `b` hands out THIS pair's half of the multiplier (from the table, or a register copy);
@@ -113,11 +128,9 @@ BN_FN QFq12<F2> q12_mul_half(const QFq12<F2> &a, Fq6<F2> b, bool conj_b) {
     const F2 xb = f2_qpick(s.c1, f2_add(s.c0, s.c1)), yb = f2_qpick(t.c1, f2_norm(f2_add(t.c0, t.c1)));
     const F2 xc = f2_qpick(s.c2, f2_add(s.c0, s.c2)), yc = f2_qpick(t.c2, f2_norm(f2_add(t.c0, t.c2)));
     const F2 pa = f2_mul(xa, ya), pb = f2_mul(xb, yb), pc = f2_mul(xc, yc);
-    const F2 qa = f2_xq(pa), qb = f2_xq(pb), qc = f2_xq(pc);
-    const F2 v0 = f2_qpick(pa, qa), v1 = f2_qpick(pb, qb), v2 = f2_qpick(pc, qc);               // s_i t_i
-    const F2 k12 = f2_qpick(qa, pa), k01 = f2_qpick(qb, pb), k02 = f2_qpick(qc, pc);            // (s1+s2)(t1+t2), (s0+s1)(t0+t1), (s0+s2)(t0+t2)
-    const Fq6<F2> other = f6_xq(mine);
-    const Fq6<F2> aa = f6_qpick(mine, other), bb = f6_qpick(other, mine);
+    const F2 v0 = f2_qlo(pa), v1 = f2_qlo(pb), v2 = f2_qlo(pc);                                 // s_i t_i
+    const F2 k12 = f2_qup(pa), k01 = f2_qup(pb), k02 = f2_qup(pc);                              // (s1+s2)(t1+t2), (s0+s1)(t0+t1), (s0+s2)(t0+t2)
+    const Fq6<F2> aa = f6_qlo(mine), bb = f6_qup(mine);
     // ONE fused reduction  xi X + Y - Z  per coefficient for both roles (lane-uniform stream: separate reductions - three for the lower
     // pair, three for the cross product and three for the Karatsuba difference of the upper pair - would all run on both pairs):
     //   lower  c0 = aa + v bb:   (xi bb2 + aa0,  aa1 + bb0,  aa2 + bb1)
@@ -138,13 +151,12 @@ template <class F2> BN_OUTER QFq12<F2> q12_mul_o(const QFq12<F2> &a, const QFq12
 // square the lower pair takes tmp = a b, the upper m = (a + b)(a + xi b); 3 Fq2 products per pair.
 template <class F2>
 BN_COARSE QFq12<F2> q12_cyclotomic_sqr(const QFq12<F2> &f) {
-    const Fq6<F2> o = f6_xq(f.h);
-    const F2 z0 = f2_qpick(f.h.c0, o.c0), z4 = f2_qpick(f.h.c1, o.c1), z3 = f2_qpick(f.h.c2, o.c2);
-    const F2 z2 = f2_qpick(o.c0, f.h.c0), z1 = f2_qpick(o.c1, f.h.c1), z5 = f2_qpick(o.c2, f.h.c2);
+    const F2 z0 = f2_qlo(f.h.c0), z4 = f2_qlo(f.h.c1), z3 = f2_qlo(f.h.c2);
+    const F2 z2 = f2_qup(f.h.c0), z1 = f2_qup(f.h.c1), z5 = f2_qup(f.h.c2);
     auto fp4 = [&](const F2 &a, const F2 &b, F2 &tmp, F2 &m) {
         const F2 x = f2_qpick(a, f2_add(a, b)), y = f2_qpick(b, f2_lc_xi<1, 1>(b, a));
-        const F2 p = f2_mul(x, y), q = f2_xq(p);
-        tmp = f2_qpick(p, q); m = f2_qpick(q, p);
+        const F2 p = f2_mul(x, y);
+        tmp = f2_qlo(p); m = f2_qup(p);
     };
     F2 t01, m01, t23, m23, t45, m45;
     fp4(z0, z1, t01, m01); fp4(z2, z3, t23, m23); fp4(z4, z5, t45, m45);
@@ -164,8 +176,8 @@ BN_COARSE QFq12<F2> q12_cyclotomic_sqr(const QFq12<F2> &f) {
 // fq12.rs:284-292: the two Fq6 squares in parallel, d = c0^2 - v c1^2 and its inverse (one Fq inversion) on both pairs, own half * t
 template <class F2>
 BN_OUTER QFq12<F2> q12_inverse(const QFq12<F2> &a) {
-    const Fq6<F2> sq = f6_sqr(a.h), osq = f6_xq(sq);
-    const Fq6<F2> s0 = f6_qpick(sq, osq), s1 = f6_qpick(osq, sq);
+    const Fq6<F2> sq = f6_sqr(a.h);
+    const Fq6<F2> s0 = f6_qlo(sq), s1 = f6_qup(sq);
     Fq6<F2> d;
     d.c0 = f2_lc_xi<-1, 1>(s1.c2, s0.c0);
     d.c1 = f2_lc3<1, -1, 0>(s0.c1, s1.c0, s1.c0);
@@ -187,13 +199,13 @@ BN_FN QFq12<F2> q12_frobenius(const QFq12<F2> &a) {
 // results as pairing.hpp doubling_step<true> / addition_step (groups/mod.rs:612-634, 592-610).
 template <class F2>
 BN_FN void f2_mul_split(const F2 &a_lo, const F2 &b_lo, const F2 &a_up, const F2 &b_up, F2 &r_lo, F2 &r_up) {
-    const F2 m = f2_mul(f2_qpick(a_lo, a_up), f2_qpick(b_lo, b_up)), o = f2_xq(m);
-    r_lo = f2_qpick(m, o); r_up = f2_qpick(o, m);
+    const F2 m = f2_mul(f2_qpick(a_lo, a_up), f2_qpick(b_lo, b_up));
+    r_lo = f2_qlo(m); r_up = f2_qup(m);
 }
 template <class F2>
 BN_FN void f2_sqr_split(const F2 &a_lo, const F2 &a_up, F2 &r_lo, F2 &r_up) {
-    const F2 m = f2_sqr(f2_qpick(a_lo, a_up)), o = f2_xq(m);
-    r_lo = f2_qpick(m, o); r_up = f2_qpick(o, m);
+    const F2 m = f2_sqr(f2_qpick(a_lo, a_up));
+    r_lo = f2_qlo(m); r_up = f2_qup(m);
 }
 // 2 + 3 product slots per pair instead of 3 products + 6 squares
 template <class F2>

@@ -53,13 +53,13 @@ BN_FN void w_prod(W &w, const Role &r, uint32_t base) {
     }
     T res;
     if constexpr (SQR) {
-        res = f2b_sqr_body(a);
+        res = f2b_sqr_inl(a);
     } else {
         T b = w.ld(w_addr<RELX>(r.src[4], base));
 #pragma unroll
         for (int k = 1; k < NB; ++k) b = fe_add(b, w.ld(w_addr<RELX>(r.src[4 + k], base)));
         if (NB > 1) b = fe_norm(b);
-        res = f2b_mul_body(a, b);
+        res = f2b_mul_inl(a, b);
     }
     if (r.flags & 1) w.st(w_addr<RELX>(r.dst, base), res);
 }
@@ -93,7 +93,7 @@ BN_FN void w_fuse_sqr(W &w, const Role &r) {
     T z = fe_ssub(w.ld(r.src[6]), w.ld(r.src[7]));
     T a = fe_lc4_par<27, 3, 3, 2>(x, lane_partner(x), y, z);
     if (r.flags & 2) w.st(r.src[8], a);
-    T res = f2b_sqr_body(a);
+    T res = f2b_sqr_inl(a);
     if (r.flags & 1) w.st(r.dst, res);
 }
 

@@ -9,6 +9,8 @@ struct FeQ { FeP p[2]; };
 
 BN_FN FeQ quad_xchg(const FeQ &x) { return {{x.p[1], x.p[0]}}; }
 BN_FN FeQ quad_pick(const FeQ &lower_choice, const FeQ &upper_choice) { return {{lower_choice.p[0], upper_choice.p[1]}}; }
+BN_FN FeQ quad_lo(const FeQ &x) { return {{x.p[0], x.p[0]}}; }      // the lower pair's value on both pairs (GPU: DPP quad_perm [0,1,0,1])
+BN_FN FeQ quad_up(const FeQ &x) { return {{x.p[1], x.p[1]}}; }      // the upper pair's ([2,3,2,3])
 #define BN_Q1(NAME) BN_FN FeQ NAME(const FeQ &a) { return {{NAME(a.p[0]), NAME(a.p[1])}}; }
 #define BN_Q2(NAME) BN_FN FeQ NAME(const FeQ &a, const FeQ &b) { return {{NAME(a.p[0], b.p[0]), NAME(a.p[1], b.p[1])}}; }
 BN_Q1(lane_partner) BN_Q2(lane_pick) BN_Q2(fe_add) BN_Q1(fe_dbl) BN_Q2(fe_ssub) BN_Q1(fe_norm) BN_Q1(fe_half) BN_Q1(fe_std)
