@@ -252,6 +252,30 @@ BN_FN Fe fe_ssub(const Fe &a, const Fe &b) {
     return r;
 }
 
+// the difference of two elements with normalized limbs as a signed operand of fe_mul2s: |limb| < 2^29, |value| < max(a, b)
+BN_FN Fe fe_sdiff(const Fe &a, const Fe &b) {
+    BN_COUNT(addsub);
+    BN_REQUIRE(!a.sg && !b.sg && a.lb == 1 && b.lb == 1, "fe_sdiff takes normalized unsigned limbs");
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i];
+    BN_SETB(r, 1, (a.vb > b.vb ? a.vb : b.vb));
+    BN_IFB(r.sg = true;)
+    BN_VERIFY(r, "fe_sdiff");
+    return r;
+}
+// limb-wise negation of a signed (or unsigned) operand, no bias
+BN_FN Fe fe_sneg(const Fe &a) {
+    BN_COUNT(addsub);
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = 0u - a.l[i];
+    BN_SETB(r, a.lb, a.vb);
+    BN_IFB(r.sg = true;)
+    BN_VERIFY(r, "fe_sneg");
+    return r;
+}
+
 // a - b (mod q) as a + K*q - b, b must satisfy lb <= LB and vb <= K-1
 template <int LB, int K>
 BN_FN Fe fe_sub(const Fe &a, const Fe &b) {
@@ -633,6 +657,52 @@ BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
     return r;
 }
 
+// The dual product over SIGNED operands: every limb an int32 of magnitude below 2^29 - differences of two standard elements (fe_sdiff),
+// where a Karatsuba cross product would otherwise take sums and pay a carry propagation to get one of them back under 2^29 (tower.hpp
+// f6_mul).  27 terms of magnitude below 2^58 stay inside a signed 64-bit column; the carries are arithmetic shifts; the Montgomery digit
+// comes from the low 29 bits of the two's complement column as before.  The result is a SIGNED lazy value: limbs 0..7 in [0, 2^29), the
+// top limb carries the sign, |value| < ((A U + C V) / 169.3 + 1) q.  Only the fused reductions (fe_lc*) consume it.
+BN_FN Fe fe_mul2s(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
+#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+    return fe_mul2s_asm(a, u, c, v);
+#endif
+    BN_COUNT(mul2);
+    BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 2, "fe_mul2s column overflow (signed columns hold 27 terms of 2^58)");
+    BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 169, "fe_mul2s value bound");
+    int64_t acc = 0;
+    uint32_t m[9];
+    Fe r;
+#pragma unroll
+    for (int col = 0; col < 9; ++col) {
+#pragma unroll
+        for (int i = 0; i <= col; ++i) {
+            acc += (int64_t)(int32_t)a.l[i] * (int64_t)(int32_t)u.l[col - i];
+            acc += (int64_t)(int32_t)c.l[i] * (int64_t)(int32_t)v.l[col - i];
+        }
+#pragma unroll
+        for (int i = 0; i < col; ++i) acc += (int64_t)((uint64_t)m[i] * k::Q[col - i]);
+        m[col] = ((uint32_t)acc * k::QINV) & MASK29;
+        acc += (int64_t)((uint64_t)m[col] * k::Q[0]);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int col = 9; col < 17; ++col) {
+#pragma unroll
+        for (int i = col - 8; i <= 8; ++i) {
+            acc += (int64_t)(int32_t)a.l[i] * (int64_t)(int32_t)u.l[col - i];
+            acc += (int64_t)(int32_t)c.l[i] * (int64_t)(int32_t)v.l[col - i];
+        }
+#pragma unroll
+        for (int i = col - 8; i <= 8; ++i) acc += (int64_t)((uint64_t)m[i] * k::Q[col - i]);
+        r.l[col - 9] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    BN_SETB(r, 1, 2);
+    BN_IFB(r.sg = true;)
+    BN_VERIFY(r, "fe_mul2s");
+    return r;
+}
 // (a1 u1 + c1 v1 + a2 u2 + c2 v2 + a3 u3 + c3 v3) / R with ONE reduction: 486 + 81 mads.  Three Fq2 products of the lane-pair mapping summed
 // before they are reduced (tower.hpp f12_mul_by_024: every output coefficient of the sparse line product is such a sum).
 // Column bound: 6 * 9 + 9 = 63 terms of (2^29 - 1)^2 plus a carry stay below 2^64 ONLY for normalized limbs - every operand must have lb = 1.

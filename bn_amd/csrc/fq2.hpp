@@ -111,6 +111,11 @@ BN_FN Fe f2_scalar_load(const Fq2A *, const uint32_t *w) { return fe_from_u32x8(
 template <class TAB> BN_FN Fe f2_scalar_const(const Fq2A *, const TAB &tab) { return fe_const(tab); }
 
 
+// Karatsuba: a_i b_j + a_j b_i as a signed lazy sum (limb bound 3), given p_ii = a_i b_i and p_jj = a_j b_j (fq6.rs:26-39 forms it the same way)
+BN_FN Fq2A f2_cross(const Fq2A &ai, const Fq2A &aj, const Fq2A &bi, const Fq2A &bj, const Fq2A &pii, const Fq2A &pjj) {
+    return f2_ssub(f2_ssub(f2_mul(f2_add(ai, aj), f2_norm(f2_add(bi, bj))), pii), pjj);
+}
+
 // ===================================================================================================== policy B
 // One Fq2 element per PAIR of adjacent lanes (even lane: c0, odd lane: c1).  T is the per-lane scalar: Fe on the GPU;
 // the host simulation instantiates it with a 2-lane value type so the same code is checked on the CPU.
@@ -179,6 +184,15 @@ BN_FN T f2b_sqr_body(const T &a) {
     T t = lane_pick(fe_sub<1, 7>(a, pa), a);
     return fe_mul_body(s, t);
 }
+// the product of two SIGNED differences (fe_sdiff values: |limb| < 2^29) - a Karatsuba cross product (a_i - a_j)(b_j - b_i) of tower.hpp,
+// which needs no carry propagation of its operands; the result is a signed lazy value for the fused reductions
+template <class T>
+BN_FN T f2b_muls_body(const T &a, const T &b) {
+    T pa = lane_partner(a), pb = lane_partner(b);
+    T u = lane_pick(b, pb);
+    T v = lane_pick(fe_sneg(pb), b);
+    return fe_mul2s(a, u, pa, v);
+}
 #if !defined(BN_HOSTSIM) && !defined(BN_NO_EXEC_GLUE)
 // The GPU's operand set-up for the two leaves above, nine instructions per role decision instead of eighteen: where only the EVEN lane
 // of a pair differs from the odd one, the difference is applied IN PLACE to a register the exchange just produced, with the odd lanes
@@ -239,6 +253,23 @@ BN_FN Fe f2b_sqr_gpu(const Fe &a) {
 #undef BN_SQ
     return fe_mul_body(s, t);
 }
+BN_FN Fe f2b_muls_gpu(const Fe &a, const Fe &b) {        // signed operands: the even lane's negation is a plain 0 - x
+    const Fe a0 = lane_dpp_even(a), a1 = lane_dpp_odd(a);
+    Fe x = lane_partner(b);
+    uint64_t saved;
+    asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
+        "v_sub_u32 %[x0], 0, %[x0]\n\tv_sub_u32 %[x1], 0, %[x1]\n\tv_sub_u32 %[x2], 0, %[x2]\n\t"
+        "v_sub_u32 %[x3], 0, %[x3]\n\tv_sub_u32 %[x4], 0, %[x4]\n\tv_sub_u32 %[x5], 0, %[x5]\n\t"
+        "v_sub_u32 %[x6], 0, %[x6]\n\tv_sub_u32 %[x7], 0, %[x7]\n\tv_sub_u32 %[x8], 0, %[x8]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [x0] "+v"(x.l[0]), [x1] "+v"(x.l[1]), [x2] "+v"(x.l[2]), [x3] "+v"(x.l[3]), [x4] "+v"(x.l[4]), [x5] "+v"(x.l[5]), [x6] "+v"(x.l[6]),
+          [x7] "+v"(x.l[7]), [x8] "+v"(x.l[8]), [sv] "=&s"(saved)
+        : [m] "s"(BN_EVEN_LANES)
+        : "scc");
+    return fe_mul2s(a0, b, a1, x);
+}
+BN_LEAF_MUL u32x9 f2b_muls_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_muls_gpu(bn_unv(a), bn_unv(b))); }
+BN_FN Fe f2b_muls(const Fe &a, const Fe &b) { return bn_unv(f2b_muls_leaf(bn_tov(a), bn_tov(b))); }
 BN_FN Fe f2b_mul_inl(const Fe &a, const Fe &b) { return f2b_mul_gpu(a, b); }      // for callers that inline the leaf themselves (wave.hpp)
 BN_FN Fe f2b_sqr_inl(const Fe &a) { return f2b_sqr_gpu(a); }
 BN_LEAF_MUL u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_gpu(bn_unv(a), bn_unv(b))); }
@@ -250,9 +281,12 @@ template <class T> BN_FN T f2b_mul(const T &a, const T &b) { return f2b_mul_body
 template <class T> BN_FN T f2b_sqr(const T &a) { return f2b_sqr_body(a); }
 template <class T> BN_FN T f2b_mul_inl(const T &a, const T &b) { return f2b_mul_body(a, b); }
 template <class T> BN_FN T f2b_sqr_inl(const T &a) { return f2b_sqr_body(a); }
+template <class T> BN_FN T f2b_muls(const T &a, const T &b) { return f2b_muls_body(a, b); }
 #else
 template <class T> BN_FN T f2b_mul_inl(const T &a, const T &b) { return f2b_mul_body(a, b); }
 template <class T> BN_FN T f2b_sqr_inl(const T &a) { return f2b_sqr_body(a); }
+BN_LEAF_MUL u32x9 f2b_muls_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_muls_body(bn_unv(a), bn_unv(b))); }
+BN_FN Fe f2b_muls(const Fe &a, const Fe &b) { return bn_unv(f2b_muls_leaf(bn_tov(a), bn_tov(b))); }
 BN_LEAF_MUL u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_body(bn_unv(a), bn_unv(b))); }
 BN_LEAF_MUL u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_body(bn_unv(a))); }
 BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a), bn_tov(b))); }
@@ -277,6 +311,8 @@ template <class T> BN_FN Fq2B<T> f2_add(const Fq2B<T> &a, const Fq2B<T> &b) { re
 template <class T> BN_FN Fq2B<T> f2_dbl(const Fq2B<T> &a) { return {fe_dbl(a.v)}; }
 template <int LB, int K, class T> BN_FN Fq2B<T> f2_sub(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_sub<LB, K>(a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_ssub(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_ssub(a.v, b.v)}; }
+template <class T> BN_FN Fq2B<T> f2_sdiff(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_sdiff(a.v, b.v)}; }      // operands of f2_muls
+template <class T> BN_FN Fq2B<T> f2_muls(const Fq2B<T> &a, const Fq2B<T> &b) { return {f2b_muls(a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_norm(const Fq2B<T> &a) { return {fe_norm(a.v)}; }
 template <class T> BN_FN Fq2B<T> f2_std(const Fq2B<T> &a) { return {fe_std(a.v)}; }
 template <int C1, int C2, int C3, class T>
@@ -295,6 +331,17 @@ template <class T, class TAB>
 BN_FN Fq2B<T> f2_const(const Fq2B<T> *, const TAB &tab) { return {lane_const_pick(TP, tab[0], tab[1])}; }
 template <class T> BN_FN Fq2B<T> f2_select(bool take_b, const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_select(take_b, a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_mul(const Fq2B<T> &a, const Fq2B<T> &b) { return {f2b_mul(a.v, b.v)}; }
+// Karatsuba: a_i b_j + a_j b_i = (a_i - a_j)(b_j - b_i) + a_i b_i + a_j b_j, as a signed lazy sum (limb bound 3).  The differences of
+// normalized operands are signed values of limb magnitude below 2^29 and go into the signed dual product as they are, where the sums
+// (a_i + a_j)(b_i + b_j) cost a carry propagation each (27 instructions: -DBN_NO_SIGNED_KARATSUBA restores them).
+template <class T>
+BN_FN Fq2B<T> f2_cross(const Fq2B<T> &ai, const Fq2B<T> &aj, const Fq2B<T> &bi, const Fq2B<T> &bj, const Fq2B<T> &pii, const Fq2B<T> &pjj) {
+#ifdef BN_NO_SIGNED_KARATSUBA
+    return f2_ssub(f2_ssub(f2_mul(f2_add(ai, aj), f2_norm(f2_add(bi, bj))), pii), pjj);
+#else
+    return f2_add(f2_add(f2_muls(f2_sdiff(ai, aj), f2_sdiff(bj, bi)), pii), pjj);
+#endif
+}
 template <class T> BN_FN Fq2B<T> f2_sqr(const Fq2B<T> &a) { return {f2b_sqr(a.v)}; }
 template <class T> BN_FN Fq2B<T> f2_scale(const Fq2B<T> &a, const T &s) { return {fe_mul(a.v, s)}; }
 template <class T> BN_FN Fq2B<T> f2_half(const Fq2B<T> &a) { return {fe_half(a.v)}; }

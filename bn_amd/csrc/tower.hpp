@@ -40,34 +40,25 @@ BN_COARSE Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
     BN_FAIR_TICK();
     F2 aa = f2_mul(a.c0, b.c0), bb = f2_mul(a.c1, b.c1), cc = f2_mul(a.c2, b.c2);
     Fq6<F2> r;
-    {
-        F2 t0 = f2_mul(f2_add(a.c1, a.c2), f2_norm(f2_add(b.c1, b.c2)));
-        r.c0 = f2_lc_xi<1, 1>(f2_ssub(f2_ssub(t0, bb), cc), aa);          // xi (a1 b2 + a2 b1) + a0 b0
-    }
-    {
-        F2 t1 = f2_mul(f2_add(a.c0, a.c1), f2_norm(f2_add(b.c0, b.c1)));
-        r.c1 = f2_lc_xi<1, 1>(cc, f2_ssub(f2_ssub(t1, aa), bb));          // xi a2 b2 + a0 b1 + a1 b0
-    }
-    {
-        F2 t2 = f2_mul(f2_add(a.c0, a.c2), f2_norm(f2_add(b.c0, b.c2)));
-        r.c2 = f2_lc3<1, -1, -1>(f2_add(t2, bb), aa, cc);                // a0 b2 + a2 b0 + a1 b1
-    }
+    r.c0 = f2_lc_xi<1, 1>(f2_cross(a.c1, a.c2, b.c1, b.c2, bb, cc), aa);          // xi (a1 b2 + a2 b1) + a0 b0
+    r.c1 = f2_lc_xi<1, 1>(cc, f2_cross(a.c0, a.c1, b.c0, b.c1, aa, bb));          // xi a2 b2 + a0 b1 + a1 b0
+    r.c2 = f2_lc3<1, 1, 0>(f2_cross(a.c0, a.c2, b.c0, b.c2, aa, cc), bb, bb);     // a0 b2 + a2 b0 + a1 b1
     return r;
 }
 // The six Karatsuba products of f6_mul WITHOUT their recombination: a caller that subtracts or adds further Fq6 values right away
 // (the cross term of an Fq12 product or square) folds everything into ONE fused reduction per coefficient (f2_lc_xi2w / f2_lc3sw) instead
 // of three reductions here and three more there (round 4: Miller 3.806 -> 3.765 ms, final exponentiation 3.357 -> 3.341 ms, Gt::pow + 2.3 %;
 // profiles/r04g_ab_merged_recombination.txt; -DBN_NO_MERGED_RECOMB restores the two-level form).
-//   a b = (xi (k12 - v1 - v2) + v0) + (xi v2 + k01 - v0 - v1) v + (k02 + v1 - v0 - v2) v^2
-template <class F2> struct Fq6Raw { F2 v0, v1, v2, k12, k01, k02; };
+//   a b = (xi x12 + v0) + (xi v2 + x01) v + (x02 + v1) v^2,   x_ij = a_i b_j + a_j b_i (f2_cross: signed lazy sums, limb bound 3)
+template <class F2> struct Fq6Raw { F2 v0, v1, v2, x12, x01, x02; };
 template <class F2>
 BN_COARSE Fq6Raw<F2> f6_mul_raw(const Fq6<F2> &a, const Fq6<F2> &b) {
     BN_FAIR_TICK();
     Fq6Raw<F2> r;
     r.v0 = f2_mul(a.c0, b.c0); r.v1 = f2_mul(a.c1, b.c1); r.v2 = f2_mul(a.c2, b.c2);
-    r.k12 = f2_mul(f2_add(a.c1, a.c2), f2_norm(f2_add(b.c1, b.c2)));
-    r.k01 = f2_mul(f2_add(a.c0, a.c1), f2_norm(f2_add(b.c0, b.c1)));
-    r.k02 = f2_mul(f2_add(a.c0, a.c2), f2_norm(f2_add(b.c0, b.c2)));
+    r.x12 = f2_cross(a.c1, a.c2, b.c1, b.c2, r.v1, r.v2);
+    r.x01 = f2_cross(a.c0, a.c1, b.c0, b.c1, r.v0, r.v1);
+    r.x02 = f2_cross(a.c0, a.c2, b.c0, b.c2, r.v0, r.v2);
     return r;
 }
 // fq6.rs:113-127 (CH-SQR2)
@@ -125,9 +116,9 @@ BN_FN Fq12<F2> f12_mul_src(const Fq12<F2> &a, const BSrc &b, bool conj_b) {
     Fq6<F2> aa = f6_mul(a.c0, b.c0());
     Fq12<F2> r;
     // s t - aa - bb with the recombination of s t folded in
-    r.c1.c0 = f2_lc_xi2w<1, 1, -1>(f2_ssub(f2_ssub(t.k12, t.v1), t.v2), f2_ssub(t.v0, aa.c0), bb.c0);
-    r.c1.c1 = f2_lc_xi2w<1, 1, -1>(t.v2, f2_ssub(f2_ssub(t.k01, t.v0), t.v1), f2_add(aa.c1, bb.c1));
-    r.c1.c2 = f2_lc3sw<1, -1, 0>(f2_ssub(f2_ssub(f2_add(t.k02, t.v1), t.v0), t.v2), f2_add(aa.c2, bb.c2), aa.c2);
+    r.c1.c0 = f2_lc_xi2w<1, 1, -1>(t.x12, f2_ssub(t.v0, aa.c0), bb.c0);
+    r.c1.c1 = f2_lc_xi2w<1, 1, -1>(t.v2, t.x01, f2_add(aa.c1, bb.c1));
+    r.c1.c2 = f2_lc3sw<1, -1, 0>(f2_add(t.x02, t.v1), f2_add(aa.c2, bb.c2), aa.c2);
 #else
     Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add_norm(b.c0(), b1));
     Fq6<F2> bb = f6_mul(a.c1, b1);
@@ -158,9 +149,9 @@ BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
 #ifndef BN_NO_MERGED_RECOMB
     // t - ab - v ab with the recombination of t = (c0 + c1) u folded in: three reductions instead of six
     const Fq6Raw<F2> t = f6_mul_raw(f6_add_norm(a.c0, a.c1), u);
-    r.c0.c0 = f2_lc_xi2w<1, 1, -1>(f2_ssub(f2_ssub(f2_ssub(t.k12, t.v1), t.v2), ab.c2), t.v0, ab.c0);
-    r.c0.c1 = f2_lc_xi2w<1, 1, -1>(t.v2, f2_ssub(f2_ssub(t.k01, t.v0), t.v1), f2_add(ab.c1, ab.c0));
-    r.c0.c2 = f2_lc3sw<1, -1, 0>(f2_ssub(f2_ssub(f2_add(t.k02, t.v1), t.v0), t.v2), f2_add(ab.c2, ab.c1), ab.c1);
+    r.c0.c0 = f2_lc_xi2w<1, 1, -1>(f2_ssub(t.x12, ab.c2), t.v0, ab.c0);
+    r.c0.c1 = f2_lc_xi2w<1, 1, -1>(t.v2, t.x01, f2_add(ab.c1, ab.c0));
+    r.c0.c2 = f2_lc3sw<1, -1, 0>(f2_add(t.x02, t.v1), f2_add(ab.c2, ab.c1), ab.c1);
 #else
     Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), u);
     r.c0.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_ssub(t.c0, ab.c0));      // t - ab - v*ab

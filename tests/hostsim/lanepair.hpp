@@ -15,6 +15,11 @@ BN_FN FeP fe_dbl(const FeP &a) { return fe_add(a, a); }
 template <int LB, int K> BN_FN FeP fe_sub(const FeP &a, const FeP &b) { return {{fe_sub<LB, K>(a.v[0], b.v[0]), fe_sub<LB, K>(a.v[1], b.v[1])}}; }
 template <int LB, int K> BN_FN FeP fe_neg(const FeP &a) { return {{fe_neg<LB, K>(a.v[0]), fe_neg<LB, K>(a.v[1])}}; }
 BN_FN FeP fe_ssub(const FeP &a, const FeP &b) { return {{fe_ssub(a.v[0], b.v[0]), fe_ssub(a.v[1], b.v[1])}}; }
+BN_FN FeP fe_sdiff(const FeP &a, const FeP &b) { return {{fe_sdiff(a.v[0], b.v[0]), fe_sdiff(a.v[1], b.v[1])}}; }
+BN_FN FeP fe_sneg(const FeP &a) { return {{fe_sneg(a.v[0]), fe_sneg(a.v[1])}}; }
+BN_FN FeP fe_mul2s(const FeP &a, const FeP &u, const FeP &c, const FeP &v) {
+    return {{fe_mul2s(a.v[0], u.v[0], c.v[0], v.v[0]), fe_mul2s(a.v[1], u.v[1], c.v[1], v.v[1])}};
+}
 template <int C1, int C2, int C3>
 BN_FN FeP fe_lc3w(const FeP &x, const FeP &y, const FeP &z) { return {{fe_lc3w<C1, C2, C3>(x.v[0], y.v[0], z.v[0]), fe_lc3w<C1, C2, C3>(x.v[1], y.v[1], z.v[1])}}; }
 BN_FN FeP fe_norm(const FeP &a) { return {{fe_norm(a.v[0]), fe_norm(a.v[1])}}; }

@@ -29,6 +29,9 @@ BN_FN FeQ fe_lc4_par(const FeQ &x, const FeQ &y, const FeQ &z, const FeQ &w) { r
 template <int C1, int C2, int C3, int C4>
 BN_FN FeQ fe_lc4w_par(const FeQ &x, const FeQ &y, const FeQ &z, const FeQ &w) { return {{fe_lc4w_par<C1, C2, C3, C4>(x.p[0], y.p[0], z.p[0], w.p[0]), fe_lc4w_par<C1, C2, C3, C4>(x.p[1], y.p[1], z.p[1], w.p[1])}}; }
 template <int C1, int C2, int C3> BN_FN FeQ fe_lc3sw(const FeQ &x, const FeQ &y, const FeQ &z) { return {{fe_lc3sw<C1, C2, C3>(x.p[0], y.p[0], z.p[0]), fe_lc3sw<C1, C2, C3>(x.p[1], y.p[1], z.p[1])}}; }
+BN_FN FeQ fe_sdiff(const FeQ &a, const FeQ &b) { return {{fe_sdiff(a.p[0], b.p[0]), fe_sdiff(a.p[1], b.p[1])}}; }
+BN_FN FeQ fe_sneg(const FeQ &a) { return {{fe_sneg(a.p[0]), fe_sneg(a.p[1])}}; }
+BN_FN FeQ fe_mul2s(const FeQ &a, const FeQ &u, const FeQ &c, const FeQ &v) { return {{fe_mul2s(a.p[0], u.p[0], c.p[0], v.p[0]), fe_mul2s(a.p[1], u.p[1], c.p[1], v.p[1])}}; }
 BN_FN FeQ fe_mul2(const FeQ &a, const FeQ &u, const FeQ &c, const FeQ &v) { return {{fe_mul2(a.p[0], u.p[0], c.p[0], v.p[0]), fe_mul2(a.p[1], u.p[1], c.p[1], v.p[1])}}; }
 BN_FN FeQ fe_mul6(const FeQ &a1, const FeQ &u1, const FeQ &c1, const FeQ &v1, const FeQ &a2, const FeQ &u2, const FeQ &c2, const FeQ &v2,
                   const FeQ &a3, const FeQ &u3, const FeQ &c3, const FeQ &v3) {
