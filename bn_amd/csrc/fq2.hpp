@@ -303,6 +303,16 @@ BN_FN Fq2BPrep<T> f2b_prepare(const Fq2B<T> &b) {
     const T pb = lane_partner(b.v);
     return {lane_pick(b.v, pb), lane_pick(fe_norm(fe_neg<1, 9>(pb)), b.v)};
 }
+#if !defined(BN_HOSTSIM) && !defined(BN_NO_EXEC_GLUE)
+// the GPU's set-up (same limbs): b0 and b1 by quad_perm broadcasts, the even lane's negation in place under the EXEC mask, ONE carry
+// propagation over all lanes (the odd lane's b1 is normalized already and passes through unchanged): 54 instead of 63 instructions
+BN_FN Fq2BPrep<Fe> f2b_prepare(const Fq2B<Fe> &b) {
+    const Fe u = lane_dpp_even(b.v);
+    Fe t = lane_dpp_odd(b.v);
+    fe_neg_on_even_lanes<1, 9>(t);
+    return {u, fe_norm(t)};
+}
+#endif
 template <class T>
 BN_FN Fq2B<T> f2b_mul3(const Fq2B<T> &a1, const Fq2BPrep<T> &b1, const Fq2B<T> &a2, const Fq2BPrep<T> &b2, const Fq2B<T> &a3, const Fq2BPrep<T> &b3) {
     return {fe_mul6(a1.v, b1.u, lane_partner(a1.v), b1.v, a2.v, b2.u, lane_partner(a2.v), b2.v, a3.v, b3.u, lane_partner(a3.v), b3.v)};
