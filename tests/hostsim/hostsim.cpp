@@ -52,6 +52,12 @@ EXPORT void hs_fe_mul2(const uint32_t *a, const uint32_t *u, const uint32_t *c, 
     fe_to_u32x8(fe_mul2(fe_from_u32x8(a), fe_from_u32x8(u), fe_from_u32x8(c), fe_from_u32x8(v)), o);
 }
 
+// the signed dual product on differences of standard elements: (a - b)(c - d) + (b - a)(d - a), back to the standard image through a fused reduction
+EXPORT void hs_fe_mul2s(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint32_t *o) {
+    Fe x = fe_from_u32x8(a), y = fe_from_u32x8(b), z = fe_from_u32x8(c), w = fe_from_u32x8(d);
+    Fe r = fe_mul2s(fe_sdiff(x, y), fe_sdiff(z, w), fe_sdiff(y, x), fe_sdiff(w, x));
+    fe_to_u32x8(fe_mul(fe_lc3<1, 0, 0>(r, r, r), fe_one()), o);
+}
 EXPORT void hs_fq2_mul(const uint32_t *a, const uint32_t *b, uint32_t *o) { f2_store(f2_mul(f2_load((F2 *)0, a), f2_load((F2 *)0, b)), o); }
 EXPORT void hs_fq2_sqr(const uint32_t *a, uint32_t *o) { f2_store(f2_sqr(f2_load((F2 *)0, a)), o); }
 EXPORT void hs_fq2_mul_xi(const uint32_t *a, uint32_t *o) { f2_store(f2_mul_xi(f2_load((F2 *)0, a)), o); }

@@ -50,6 +50,10 @@ def test_fe_lazy_forms(oracle, hs):
         assert np.array_equal(hs.call("hs_fe_signed_mix", a, b, c, out_words=8), want)
         want = oracle.fp_add(FQ, oracle.fp_mul(FQ, a, b), oracle.fp_mul(FQ, c, d))
         assert np.array_equal(hs.call("hs_fe_mul2", a, b, c, d, out_words=8), want)
+        # the signed dual product (Karatsuba cross products): operands are differences of standard elements, the result a signed lazy value
+        sub, mul = (lambda x, y: oracle.fp_sub(FQ, x, y)), (lambda x, y: oracle.fp_mul(FQ, x, y))
+        want = oracle.fp_add(FQ, mul(sub(a, b), sub(c, d)), mul(sub(b, a), sub(d, a)))
+        assert np.array_equal(hs.call("hs_fe_mul2s", a, b, c, d, out_words=8), want)
 
 
 def test_fe_inverse(oracle, hs):
