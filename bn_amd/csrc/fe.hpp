@@ -403,7 +403,13 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
                std::fprintf(stderr, "fe_lc<%d,%d,%d,%d> lbs %u %u %u %u\n", C1, C2, C3, C4, x.lb, y.lb, z.lb, w.lb);)
     BN_REQUIRE((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) + (N4 ? A4 * w.lb : 0) <= 4, "fe_lc narrow part exceeds 32 bits");
     // signed estimate of floor(value / 2^232) that never exceeds the truth (margins: carries still parked in lower limbs,
-    // at most 9 per unit coefficient, and the truncation of FE_MU24, < 2^9 units)
+    // at most 9 per unit coefficient, and the truncation of FE_MU24, < 2^9 units).
+    // (Round 4 tried the top limb alone - the margin of 9 covers what limb 7 holds beyond its 29 bits, and it saves two instructions
+    // per input.  The arithmetic held in the host simulation, but on the GPU the four-lane Miller kernel then returned wrong values:
+    // with l[8] used directly, LLVM's DPP combiner folds the quad_perm move of a neighbour pair's top limb into the subtraction that
+    // forms `te` (v_sub_u32_dpp / v_subrev_u32_dpp), and that code computes something else than the unfolded pair of instructions -
+    // every pairing wrong, gone with -mllvm -amdgpu-dpp-combine=false.  Cause not established (ROCm 7.2, gfx950); the explicit limb-7
+    // term stays, and tests/test_build_quality.py keeps folded DPP subtractions out of the library.)
     auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8] + ((int32_t)f.l[7] >> 29); };
     const int32_t c2 = neg2 ? -C2 : C2;
     // 32-bit arithmetic (a value below vb q has a top limb below vb * 2^21.6, and the sum of |C| vb is at most 500: checked above):

@@ -126,3 +126,18 @@ def test_scalar_multiplication_loops_do_not_store_to_scratch():
         # before it may store its Jacobian table
         region = blocks[big[-4]:]
         assert sum(st for _, st in region) == 0, f"scratch stores inside the window loop of {kernel}: {region}"
+
+
+def test_no_folded_dpp_subtractions():
+    """Round 4: when the quotient estimate of the fused reductions read a neighbour pair's top limb directly, LLVM's DPP combiner folded
+    the quad_perm move into the subtraction (v_sub_u32_dpp / v_subrev_u32_dpp) and the four-lane Miller kernel returned wrong values for
+    every pairing on the GPU - right again with -mllvm -amdgpu-dpp-combine=false, and the folded instructions themselves compute what they
+    should (tools/dpp_fold_check.hip on the box).  Cause not established (fe.hpp fe_lc4_core keeps the form that is not folded); until it
+    is, a library that contains such an instruction is suspect even if the GPU parity tests of the day pass."""
+    import re
+    import isa_mix
+    so = ROOT / "bn_amd" / "libbn254_hip.so"
+    if not so.exists() or not (isa_mix.LLVM / "llvm-objdump").exists():
+        pytest.skip("library or llvm-objdump not present")
+    found = [line.strip()[:100] for text in isa_mix.disassemble(so) for line in text.splitlines() if re.match(r"^\s+v_sub(rev)?(b)?(_co)?_u32_dpp\s", line)]
+    assert not found, found[:5]
