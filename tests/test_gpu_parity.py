@@ -85,6 +85,25 @@ def test_reference_fq12_vector_on_gpu(oracle, kats, eng):
     assert (acc == cpy).all()
 
 
+def test_fq12_products_on_edge_coefficients(oracle, eng):
+    """the general Fq12 product of the lane-pair kernels on elements whose twelve coefficients are drawn from {0, 1, 2, q-1, q-2, (q-1)/2,
+    2^253, 2^29 - 1, 2^232, R mod q} and random values: the Karatsuba cross products run on SIGNED differences a_i - a_j (tower.hpp
+    f2_cross, fe_mul2s) - equal coefficients make them zero, 0 against q-1 drives them to either extreme; squares (a * a) and products by
+    one and by zero included.  Against oracle.fq12_mul, element for element"""
+    rng = np.random.default_rng(77)
+    edge = [0, 1, 2, M.Q - 1, M.Q - 2, (M.Q - 1) // 2, 1 << 253, (1 << 29) - 1, 1 << 232, M.MONT_R % M.Q]
+    pool = edge + [int.from_bytes(rng.bytes(40), "little") % M.Q for _ in range(6)]
+    n = 192
+    def draw():
+        return np.stack([oracle.fq12_from_ints([pool[i] for i in rng.integers(0, len(pool), 12)]) for _ in range(n)])
+    a, b = draw(), draw()
+    a[0] = oracle.fq12_from_ints([0] * 12); b[1] = oracle.fq12_from_ints([1] + [0] * 11); a[2] = oracle.fq12_from_ints([M.Q - 1] * 12); b[2] = oracle.fq12_from_ints([0, M.Q - 1] * 6)
+    b[3] = a[3]; b[4] = a[4]                                                      # squares through the product
+    want = np.stack([oracle.fq12_mul(x, y) for x, y in zip(a, b)])
+    assert np.array_equal(eng.gt_mul_batch(a, b), want)
+    assert np.array_equal(eng.gt_mul_batch(b, a), want)
+
+
 def test_reference_cyclotomic_exp_kat_on_gpu(oracle, kats):
     """fields/mod.rs:171-201 (test_cyclotomic_exp): orig.exp_by_neg_z() on the device, the reference's operation sequence
     (bn254_exp_by_neg_z_dev) - the vector is OFF the cyclotomic subgroup, so only that sequence reproduces it"""
