@@ -34,7 +34,8 @@
 // kernels backfill each other's freed slots, showed exactly that: 7.94 vs 7.24 M pairings/s).  Keeping the two waves in
 // lockstep is NOT the answer: measured 6 % slower than doing nothing, because both streams then hit the multiplier at the same
 // time; strict priority with a role swap is.  Policies (BN_B_FAIR), all through s_setprio at the top of the loop steps:
-//   5 (default) hand-over by progress in the Miller loop (4), clocked alternation in the final exponentiation (3)
+//   6 (default) hand-over by progress (4) in both kernels, each with its own hand-over point (BN_B_FAIR_PERMILLE, _EXP)
+//   5 hand-over by progress in the Miller loop (4), clocked alternation in the final exponentiation (3): the default of rounds 2-4
 //   4 one hand-over: the older wave keeps the priority for 1/(1+r) = 77 % of its steps, then yields for good
 //   3 opposite priorities, swapped every 2^BN_B_FAIR_SHIFT shader cycles counted from the start of the kernel
 //   2 progress counters of the 8 waves of a CU in LDS (512-thread workgroups), the wave behind gets the priority - slower:
@@ -42,7 +43,7 @@
 //   1 priority = (step number XOR wave slot) & 1
 //   0 plain age arbitration
 #ifndef BN_B_FAIR
-#define BN_B_FAIR 5
+#define BN_B_FAIR 6
 #endif
 #ifndef BN_B_BLOCK
 #define BN_B_BLOCK (BN_B_FAIR == 2 ? 512 : 64)
@@ -60,9 +61,12 @@
 #elif BN_B_FAIR == 4
 #define BN_MILLER_HOOK(step, total) bn_fair_handover(step, total)
 #define BN_EXP_HOOK(step, total) bn_fair_handover(step, total)
-#elif BN_B_FAIR == 5              // default: what measured best per kernel
+#elif BN_B_FAIR == 5              // rounds 2-4: hand-over in the Miller loop, clocked alternation in the final exponentiation
 #define BN_MILLER_HOOK(step, total) bn_fair_handover(step, total)
 #define BN_EXP_HOOK(step, total) bn_fair_priority_time()
+#elif BN_B_FAIR == 6              // default: hand-over in both, each with its own point (what measured best per kernel at the end of round 4)
+#define BN_MILLER_HOOK(step, total) bn_fair_handover<BN_B_FAIR_PERMILLE>(step, total)
+#define BN_EXP_HOOK(step, total) bn_fair_handover<BN_B_FAIR_PERMILLE_EXP>(step, total)
 #endif
 #ifndef BN_B_FAIR_SHIFT
 #define BN_B_FAIR_SHIFT 20          // 2^20 cycles: re-measured after the asm leaves (profiles/r03_ab_fair_policy.txt; 21 before)
@@ -79,10 +83,14 @@ __device__ __forceinline__ void bn_fair_priority(int step) {
 #ifndef BN_B_FAIR_PERMILLE
 #define BN_B_FAIR_PERMILLE 769
 #endif
+#ifndef BN_B_FAIR_PERMILLE_EXP
+#define BN_B_FAIR_PERMILLE_EXP 769
+#endif
+template <int PERMILLE = BN_B_FAIR_PERMILLE>
 __device__ __forceinline__ void bn_fair_handover(int step, int total) {
     const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1;
-    if (slot == 0) { if (step * 1000 < BN_B_FAIR_PERMILLE * total) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
-    else { if (step * 1000 < (1000 - BN_B_FAIR_PERMILLE) * total) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+    if (slot == 0) { if (step * 1000 < PERMILLE * total) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+    else { if (step * 1000 < (1000 - PERMILLE) * total) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
 }
 __shared__ uint32_t bn_fair_t0[16];                            // shader-clock stamp of each wave's start (>> 10)
 __device__ __forceinline__ void bn_fair_time_init() {
