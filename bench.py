@@ -157,6 +157,14 @@ def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=No
            "peak_source": "bn254_ubench_mac32 in this run: pure v_mad_u64_u32 stream, 8 waves/SIMD",
            "peak_at_kernel_occupancy": peak2, "kernel_occupancy_waves_per_simd": 2, "frac_of_occupancy_peak": d["achieved"] / peak2,
            "traffic": traffic, "traffic_source": src, "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"], "kernels": per}
+    sq = ROOT / "profiles" / "sq_counters.json"
+    if sq.exists():                          # the SQ counters of a separate session: VALU instructions per wave, issue interval per SIMD
+        sqd = json.loads(sq.read_text())
+        for k in per:
+            if k in sqd:
+                per[k]["valu_issue"] = sqd[k]
+        if dom in sqd:
+            out["valu_issue"] = sqd[dom]
     if all("traffic" in v for v in per.values()):
         # the whole step: what all kernels of the line move per step against the algorithmic bytes of the step (inputs in, results out once)
         out["traffic_per_step_all_kernels"] = sum(v["traffic"] * v["launches"] / steps for v in per.values())
