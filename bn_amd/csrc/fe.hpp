@@ -408,9 +408,17 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
     // per input.  The arithmetic held in the host simulation, but on the GPU the four-lane Miller kernel then returned wrong values:
     // with l[8] used directly, LLVM's DPP combiner folds the quad_perm move of a neighbour pair's top limb into the subtraction that
     // forms `te` (v_sub_u32_dpp / v_subrev_u32_dpp), and that code computes something else than the unfolded pair of instructions -
-    // every pairing wrong, gone with -mllvm -amdgpu-dpp-combine=false.  Cause not established (ROCm 7.2, gfx950); the explicit limb-7
-    // term stays, and tests/test_build_quality.py keeps folded DPP subtractions out of the library.)
+    // every pairing wrong, gone with -mllvm -amdgpu-dpp-combine=false.  Cause not established (ROCm 7.2, gfx950): the four-lane kernels keep
+    // the explicit limb-7 term (BN_LC_TOP_LIMB7 in bn254_kernels_q.hip), and tests/test_build_quality.py keeps folded DPP subtractions out
+    // of the library.  The host simulation runs the top-limb form with every bound checked; the two forms differ in the quotient
+    // estimate of rare cases only, never in the residue.)
+#if defined(BN_LC_TOP_LIMB7)
     auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8] + ((int32_t)f.l[7] >> 29); };
+#else
+    // the top limb alone (the lane-pair, wave and scalar-multiplication kernels): the margin of 9 per unit coefficient below covers what limb
+    // 7 holds beyond its 29 bits (|.| <= 4 units for limb bound 4; one unit is 3.2e-7 q), two instructions per input less
+    auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8]; };
+#endif
     const int32_t c2 = neg2 ? -C2 : C2;
     // 32-bit arithmetic (a value below vb q has a top limb below vb * 2^21.6, and the sum of |C| vb is at most 500: checked above):
     // one v_mul_hi_i32 and a shift on the GPU instead of a 64 x 32-bit product
