@@ -367,17 +367,17 @@ def expected_scaling(workload, world):
     SIMD (0.57 of the two-wave issue rate) - and the product tree, the 384-byte all-gather and the single final exponentiation do
     not shrink at all."""
     if workload == "pairing":
-        round_ms = 6.51                                          # one round of 2^16 pairings: profiles/r04z_bench_line.json
+        round_ms = 6.47                                          # one round of 2^16 pairings: profiles/r04z_bench_line.json
         ms = (TOTAL_MULTI // world) / BATCH * round_ms
         return {"ms_per_step": ms, "speedup_vs_1_gpu": float(world), "model": f"{TOTAL_MULTI // world // BATCH} rounds of 2^16 pairings x {round_ms} ms (one-GPU measurement), no exchange: linear",
                 "measured_on": "1 GPU only"}
     if workload == "product":
         # Miller part of the shard + one-launch product tree + tail (world-1 products, ONE final exponentiation); all-gather ~0.05 ms
-        parts = {1: (11.71, 0.19, 0.46), 2: (6.5, 0.19, 0.46), 4: (3.45, 0.19, 0.46), 8: (2.19, 0.15, 0.45)}.get(world)
+        parts = {1: (11.70, 0.21, 0.47), 2: (6.5, 0.20, 0.47), 4: (3.45, 0.20, 0.47), 8: (2.18, 0.15, 0.45)}.get(world)
         if not parts:
             return None
         ms = sum(parts) + (0.05 if world > 1 else 0.0)
-        return {"ms_per_step": ms, "speedup_vs_1_gpu": (11.71 + 0.19 + 0.46) / ms,
+        return {"ms_per_step": ms, "speedup_vs_1_gpu": (11.70 + 0.21 + 0.47) / ms,
                 "model": "shard Miller loops %.2f ms (2^18/N pairs: 4, 2, 1 pairs per lane pair at N = 1, 2, 4; one wave per SIMD at N = 8) + product tree %.2f + tail %.2f + all-gather 0.05 "
                          "(profiles/r04z_bench_line.json side.product_2_18 / product_2_15 and the headline's Miller kernel; N = 2: two pairs per lane pair, r03j_ab_shared_miller.txt scaled)" % parts, "measured_on": "1 GPU only"}
     return None
