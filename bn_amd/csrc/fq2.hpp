@@ -201,6 +201,26 @@ BN_FN T f2b_muls_body(const T &a, const T &b) {
 //   product: this lane's component = a0 * (own b) + a1 * X,   a0 / a1 = the pair's components of a in BOTH lanes (quad_perm [0,0,2,2] /
 //            [1,1,3,3]),  X = the partner's b, negated on the even lane          (45 -> 36 instructions around the 243 multiply-adds)
 //   square:  S = own a doubled, T = the partner's a;  even lane: S = a + T, T = a - T  (63 -> 45 around the 162 multiply-adds)
+#ifdef BN_SWIZZLE_EXCHANGE       // experiment: the exchanges of the product set-up through the LDS crossbar (ds_swizzle, quad-permute mode) instead of DPP moves
+BN_FN Fe lane_dpp_even(const Fe &x) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x.l[i], 0x80A0);
+    return r;
+}
+BN_FN Fe lane_dpp_odd(const Fe &x) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x.l[i], 0x80F5);
+    return r;
+}
+BN_FN Fe lane_partner_x(const Fe &x) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x.l[i], 0x80B1);
+    return r;
+}
+#else
 BN_FN Fe lane_dpp_even(const Fe &x) {
     Fe r;
 #pragma unroll
@@ -213,6 +233,8 @@ BN_FN Fe lane_dpp_odd(const Fe &x) {
     for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], 0xF5, 0xF, 0xF, true);
     return r;
 }
+BN_FN Fe lane_partner_x(const Fe &x) { return lane_partner(x); }
+#endif
 #define BN_EVEN_LANES 0x5555555555555555ull
 template <int LB, int K>
 BN_FN void fe_neg_on_even_lanes(Fe &x) {            // x <- fe_neg<LB, K>(x) on the even lanes, untouched on the odd ones
@@ -231,13 +253,13 @@ BN_FN void fe_neg_on_even_lanes(Fe &x) {            // x <- fe_neg<LB, K>(x) on 
 }
 BN_FN Fe f2b_mul_gpu(const Fe &a, const Fe &b) {
     const Fe a0 = lane_dpp_even(a), a1 = lane_dpp_odd(a);
-    Fe x = lane_partner(b);
+    Fe x = lane_partner_x(b);
     fe_neg_on_even_lanes<1, 9>(x);
     return fe_mul2(a0, b, a1, x);
 }
 BN_FN Fe f2b_sqr_gpu(const Fe &a) {
     constexpr Bias<1, 7> B{};
-    Fe t = lane_partner(a), s = fe_dbl(a);
+    Fe t = lane_partner_x(a), s = fe_dbl(a);
     uint64_t saved;
 #define BN_SQ(i) "v_add_u32 %[s" #i "], %[a" #i "], %[t" #i "]\n\tv_sub_u32 %[t" #i "], %[a" #i "], %[t" #i "]\n\tv_add_u32 %[t" #i "], %[b" #i "], %[t" #i "]\n\t"
     asm("s_and_saveexec_b64 %[sv], %[m]\n\t" BN_SQ(0) BN_SQ(1) BN_SQ(2) BN_SQ(3) BN_SQ(4) BN_SQ(5) BN_SQ(6) BN_SQ(7) BN_SQ(8) "s_mov_b64 exec, %[sv]"
@@ -255,7 +277,7 @@ BN_FN Fe f2b_sqr_gpu(const Fe &a) {
 }
 BN_FN Fe f2b_muls_gpu(const Fe &a, const Fe &b) {        // signed operands: the even lane's negation is a plain 0 - x
     const Fe a0 = lane_dpp_even(a), a1 = lane_dpp_odd(a);
-    Fe x = lane_partner(b);
+    Fe x = lane_partner_x(b);
     uint64_t saved;
     asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
         "v_sub_u32 %[x0], 0, %[x0]\n\tv_sub_u32 %[x1], 0, %[x1]\n\tv_sub_u32 %[x2], 0, %[x2]\n\t"
