@@ -7,9 +7,14 @@ import subprocess
 
 HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("BN254_LIB_PATH", HERE / "libbn254_hip.so"))     # override: kernel experiments only
-SOURCES = [HERE / "csrc" / f for f in ("bn254_hip.hip", "bn254_kernels_b.hip", "bn254_kernels_mul.hip", "bn254_kernels_w.hip", "bn254_kernels_q.hip", "bn254_multi.hip")]
+SOURCES = [HERE / "csrc" / f for f in ("bn254_hip.hip", "bn254_kernels_b.hip", "bn254_kernels_mul.hip", "bn254_kernels_w.hip", "bn254_kernels_q.hip", "bn254_multi.hip", "bn254_measure.hip")]
 OBJ_DIR = HERE / "csrc" / "build"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# EVERY unit is compiled with LLVM's DPP combiner off: with it on, the quad_perm move of a neighbour lane's limb is folded into the
+# subtraction that consumes it (v_sub_u32_dpp / v_subrev_u32_dpp), and in round 4 a build with such folds in the four-lane Miller kernel
+# returned wrong pairings on the GPU while the unfolded pair of instructions was right (cause not established; csrc/fe.hpp fe_lc4_core).
+# The flag costs nothing (34 folds become moves; profiles/r05_ab_dpp_combine_off.txt); tests/test_build_quality.py checks the result.
+DEVICE_FLAGS = ["-mllvm", "-amdgpu-dpp-combine=false"]
 
 _VP = C.c_void_p
 _SZ = C.c_size_t
@@ -60,6 +65,7 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_synthetic_scalars_dev": [_VP, C.c_uint64, C.c_uint64, _SZ, C.c_int, _VP, _VP],
     "bn254_tile_dev": [_VP, _VP, _SZ, _SZ, _VP, _VP],
     "bn254_ubench_mac32": [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "bn254_ubench_mac32_ex": [_VP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "bn254_wave_ubench": [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
     "bn254_gt_mul_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
     "bn254_gt_pow_batch_dev": [_VP, _VP, _VP, _VP, _SZ, _VP],
@@ -86,7 +92,7 @@ def build(force=False, verbose=False):
     hdrs = sorted((HERE / "csrc").glob("*.hpp")) + [HERE.parent / "include" / "bn254_hip.h"]
     hdr_m = max(h.stat().st_mtime for h in hdrs)
     extra = os.environ.get("BN254_EXTRA_HIPCC_FLAGS", "").split()           # experiments only
-    flags = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + extra
+    flags = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + DEVICE_FLAGS + extra
     OBJ_DIR.mkdir(exist_ok=True)
     stamp = OBJ_DIR / "flags.txt"
     if not stamp.exists() or stamp.read_text() != " ".join(flags):

@@ -233,7 +233,9 @@ int bn_get_ctx(bn254_ctx *&ctx) {
 // the device's CU count, so a partition or a smaller part gets thresholds that fit it.
 // The ONLY place this library reads its debug environment (BN254_RCCL_PATH, a file path, is read where RCCL is loaded): once per
 // process, into the seed values every new context starts from.
+constexpr size_t BN_LAUNCH_MAX = (size_t)1 << 22;       // units per launch (32-bit word offsets inside a kernel); also the cap of the size options
 namespace {
+bool bn_opt_valid(int key, long v);
 struct DebugEnv { long opt[BN254_OPT_COUNT_]; int exchange; bool affinity; };
 const DebugEnv &bn_debug_env() {
     static DebugEnv env;
@@ -249,22 +251,25 @@ const DebugEnv &bn_debug_env() {
             {"BN254_PIPELINE_CHUNK", BN254_OPT_PIPELINE_CHUNK}, {"BN254_PIPELINE_SLOTS", BN254_OPT_PIPELINE_SLOTS},
             {"BN254_STREAM_STOP_AT_ERROR", BN254_OPT_STREAM_STOP_AT_ERROR}};
         for (const auto &v : vars)
-            if (const char *e = getenv(v.name)) { const long x = atol(e); if (x >= 0) env.opt[v.key] = x; }
+            if (const char *e = getenv(v.name)) { const long x = atol(e); if (x >= 0 && bn_opt_valid(v.key, x)) env.opt[v.key] = x; }
         if (const char *e = getenv("BN254_MULTI_AFFINITY")) env.affinity = atoi(e) != 0;
         if (const char *e = getenv("BN254_MULTI_EXCHANGE")) env.exchange = !strcmp(e, "peer") ? BN254_EXCHANGE_PEER : !strcmp(e, "rccl") ? BN254_EXCHANGE_RCCL : BN254_EXCHANGE_AUTO;
     });
     return env;
 }
 // is `value` acceptable for `key`?  (negative values are always accepted: "restore the default")
+// Sizes of ONE launch are capped at BN_LAUNCH_MAX = 2^22 units: the kernels index their inputs, outputs and context-owned tables with 32-bit
+// word offsets (96 words per Fq12, 126 x lanes-in-the-launch table rows per lane), which 2^22 pairings keep below 2^32 in every mapping;
+// larger batches are cut into sub-launches by the host whatever the thresholds say.
 bool bn_opt_valid(int key, long v) {
     switch (key) {
-        case BN254_OPT_WAVE_PAIRING_MAX: case BN254_OPT_WAVE_FE_MAX: case BN254_OPT_QUAD_MAX: return true;
+        case BN254_OPT_WAVE_PAIRING_MAX: case BN254_OPT_WAVE_FE_MAX: case BN254_OPT_QUAD_MAX: return v <= (long)BN_LAUNCH_MAX;
         case BN254_OPT_MILLER_SHARED: return v == 0 || v == 1 || v == 2 || v == 4;
         case BN254_OPT_GT_POW_MODE: return v <= 2;
         case BN254_OPT_PRODUCT_CHUNK: return v >= 1 && v <= 4096;
         case BN254_OPT_PRODUCT_PER_WAVE: return v >= 1 && v <= 32;
         case BN254_OPT_PRODUCT_BFLY: return v <= 5;
-        case BN254_OPT_ROUND_PAIRS: case BN254_OPT_PIPELINE_CHUNK: return v >= 1;
+        case BN254_OPT_ROUND_PAIRS: case BN254_OPT_PIPELINE_CHUNK: return v >= 1 && v <= (long)BN_LAUNCH_MAX;
         case BN254_OPT_PIPELINE_SLOTS: return v >= 1 && v <= BN_MAX_SLOTS;
         case BN254_OPT_STREAM_STOP_AT_ERROR: return v <= 1;
         default: return false;
@@ -446,7 +451,6 @@ static int bn_for_parts(size_t n, size_t step, Fn fn) {
     }
     return BN254_OK;
 }
-constexpr size_t BN_LAUNCH_MAX = (size_t)1 << 22;       // units per launch where no table is involved (32-bit word offsets inside a kernel)
 
 // out[i] = pairing(p[i], q[i]).  Small batches: Miller loop + final exponentiation per WAVE, one launch; otherwise the lane-pair
 // kernels, the Miller values written to `out` and exponentiated in place (same 384-byte slots).

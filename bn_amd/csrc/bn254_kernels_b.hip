@@ -4,167 +4,47 @@
 // memory; the partner's limbs arrive by DPP (quad_perm [1,0,3,2]).  A batch of 2^16 pairings is 2048 waves = 2 per SIMD,
 // which is what the integer pipe needs to be saturated (profiles/r01_ubench_valu_rates.txt).
 //
-// This translation unit is compiled with the Fq6/Fq12-sized steps INLINED (BN_COARSE), so that values stay in VGPRs across
-// them; only the multiplier-sized leaves and the rarely executed outer steps are calls.
-#define BN_COARSE __device__ __forceinline__
-#ifndef BN_WAVES
-#define BN_WAVES 2          // resident waves per SIMD the kernels are compiled for (256 VGPRs each)
-#endif
-// ... and, since the measurement of round 1f, the multiplier- and reduction-sized leaves as well: without calls there is no
-// argument marshalling (v_mov was ~45 % of the non-leaf instructions) and no caller-saved/callee-saved split of the register
-// file.  The Miller loop body becomes ~160 KB of straight-line code (beyond the 64 KB instruction cache), and is still 7 %
-// faster than the call-based build (profiles/r01g_*).  -DBN_B_CALL_LEAVES restores the calls.
-#ifndef BN_B_CALL_LEAVES
-#define BN_LEAF_MUL __device__ __forceinline__
-#define BN_LEAF_RED __device__ __forceinline__
-#endif
-#ifdef BN_B_CALL_MUL               // experiments: call only one of the two leaf classes
-#undef BN_LEAF_MUL
-#endif
-#ifdef BN_B_CALL_RED
-#undef BN_LEAF_RED
-#endif
-#ifdef BN_B_INLINE_REDUCTIONS
-#define BN_INLINE_REDUCTIONS 1
-#endif
-// Two waves share a SIMD and the hardware arbitrates OLDEST FIRST: measured with per-wave time stamps (tools/wave_stamps.py),
+// This translation unit is compiled with everything on the hot loops INLINED (fe.hpp BN_INLINE_ALL: the Fq6/Fq12-sized steps and, since
+// the measurement of round 1f, the multiplier- and reduction-sized leaves): values stay in VGPRs across them, there is no argument
+// marshalling (v_mov was ~45 % of the non-leaf instructions) and no caller-saved/callee-saved split of the register file.  The Miller
+// loop body becomes ~160 KB of straight-line code (beyond the 64 KB instruction cache), and is still 7 % faster than the call-based
+// build (profiles/r01g_*).  Only the rarely executed outer steps are calls.
+#define BN_INLINE_ALL 1
+#define BN_WAVES 2          // resident waves per SIMD the kernels are compiled for (256 VGPRs each).  Three (168 VGPRs) was measured in round
+                            // 5: the engine's own squaring stream gains 4.4 % from a third wave when nothing spills, the real kernels compiled
+                            // to 168 VGPRs LOSE 17-25 % (profiles/r05_ubench_mix_occupancy.txt, r05_occupancy_ab.txt)
+// Two waves share a SIMD and the hardware arbitrates OLDEST FIRST: measured with per-wave time stamps (profiles/r01j_wave_lifetimes.txt),
 // wave 0 of every SIMD ran at solo speed and finished the Miller kernel after 3.0 ms while wave 1 crawled (0.3 of the solo
 // rate) and needed 5.2 ms - the SIMD ran ONE wave for the last 40 % of the kernel.  A SIMD with a privileged and a gap-filling
 // wave delivers 1.3x the work of one wave, so keeping both alive to the end is worth 10 % (two concurrent processes, whose
 // kernels backfill each other's freed slots, showed exactly that: 7.94 vs 7.24 M pairings/s).  Keeping the two waves in
 // lockstep is NOT the answer: measured 6 % slower than doing nothing, because both streams then hit the multiplier at the same
-// time; strict priority with a role swap is.  Policies (BN_B_FAIR), all through s_setprio at the top of the loop steps:
-//   6 (default) hand-over by progress (4) in both kernels, each with its own hand-over point (BN_B_FAIR_PERMILLE, _EXP)
-//   5 hand-over by progress in the Miller loop (4), clocked alternation in the final exponentiation (3): the default of rounds 2-4
-//   4 one hand-over: the older wave keeps the priority for 1/(1+r) = 77 % of its steps, then yields for good
-//   3 opposite priorities, swapped every 2^BN_B_FAIR_SHIFT shader cycles counted from the start of the kernel
-//   2 progress counters of the 8 waves of a CU in LDS (512-thread workgroups), the wave behind gets the priority - slower:
-//     the bookkeeping inside the Fq6 products costs more than the tail it removes
-//   1 priority = (step number XOR wave slot) & 1
-//   0 plain age arbitration
-#ifndef BN_B_FAIR
-#define BN_B_FAIR 6
-#endif
-#ifndef BN_B_BLOCK
-#define BN_B_BLOCK (BN_B_FAIR == 2 ? 512 : 64)
-#endif
-#if BN_B_FAIR == 2
-#define BN_MILLER_HOOK(step, total) bn_fair_progress()
-#define BN_EXP_HOOK(step, total) bn_fair_progress()
-#define BN_FAIR_TICK() bn_fair_progress()
-#elif BN_B_FAIR == 1
-#define BN_MILLER_HOOK(step, total) bn_fair_priority(step)
-#define BN_EXP_HOOK(step, total) bn_fair_priority(step)
-#elif BN_B_FAIR == 3
-#define BN_MILLER_HOOK(step, total) bn_fair_priority_time()
-#define BN_EXP_HOOK(step, total) bn_fair_priority_time()
-#elif BN_B_FAIR == 4
-#define BN_MILLER_HOOK(step, total) bn_fair_handover(step, total)
-#define BN_EXP_HOOK(step, total) bn_fair_handover(step, total)
-#elif BN_B_FAIR == 5              // rounds 2-4: hand-over in the Miller loop, clocked alternation in the final exponentiation
-#define BN_MILLER_HOOK(step, total) bn_fair_handover(step, total)
-#define BN_EXP_HOOK(step, total) bn_fair_priority_time()
-#elif BN_B_FAIR == 6              // default: hand-over in both, each with its own point (what measured best per kernel at the end of round 4)
-#define BN_MILLER_HOOK(step, total) bn_fair_handover<BN_B_FAIR_PERMILLE>(step, total)
-#define BN_EXP_HOOK(step, total) bn_fair_handover<BN_B_FAIR_PERMILLE_EXP>(step, total)
-#endif
-#ifndef BN_B_FAIR_SHIFT
-#define BN_B_FAIR_SHIFT 20          // 2^20 cycles: re-measured after the asm leaves (profiles/r03_ab_fair_policy.txt; 21 before)
-#endif
+// time; strict priority with ONE role swap is, set with s_setprio at the top of the loop steps.  Policies measured and retired
+// (profiles/r03_ab_fair_policy.txt, r04p_ab_fair_policy.txt; their code left with round 5): priority by step parity; opposite priorities
+// swapped every 2^20 shader cycles (the final exponentiation's policy in rounds 2-4: 0.8 % slower than the hand-over at the end of round
+// 4); progress counters of the waves of a CU in LDS with the wave behind privileged (slower: the bookkeeping inside the Fq6 products
+// costs more than the tail it removes); plain age arbitration (7 % slower).
 #include <hip/hip_runtime.h>
-__device__ __forceinline__ void bn_fair_priority(int step) {
-    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_ID.wave_id: 0 / 1 for the two resident waves
-    if ((step ^ slot) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-}
 // ONE hand-over: the older wave of a SIMD (slot 0) runs with priority until it has done 1/(1+r) of its steps (r = 0.3: the rate at
 // which the other wave advances meanwhile), then yields for good; the younger wave takes over when it has done r/(1+r) of its
 // steps - the same moment if the model holds, and the intermediate levels (1, 2) make either order of arrival safe.  Both
 // waves then finish together and the SIMD always runs its efficient mode: one privileged stream, one filling the gaps.
-#ifndef BN_B_FAIR_PERMILLE
-#define BN_B_FAIR_PERMILLE 769
-#endif
-#ifndef BN_B_FAIR_PERMILLE_EXP
-#define BN_B_FAIR_PERMILLE_EXP 769
-#endif
-template <int PERMILLE = BN_B_FAIR_PERMILLE>
+// (Hand-over point re-swept at the end of round 4: flat between 769 and 830 per mille in both kernels, worse outside.)
+constexpr int BN_B_FAIR_PERMILLE = 769;
 __device__ __forceinline__ void bn_fair_handover(int step, int total) {
-    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1;
-    if (slot == 0) { if (step * 1000 < PERMILLE * total) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
-    else { if (step * 1000 < (1000 - PERMILLE) * total) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1;      // HW_ID.wave_id: 0 / 1 for the two resident waves
+    if (slot == 0) { if (step * 1000 < BN_B_FAIR_PERMILLE * total) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+    else { if (step * 1000 < (1000 - BN_B_FAIR_PERMILLE) * total) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
 }
-__shared__ uint32_t bn_fair_t0[16];                            // shader-clock stamp of each wave's start (>> 10)
-__device__ __forceinline__ void bn_fair_time_init() {
-    if ((threadIdx.x & 63) == 0) bn_fair_t0[threadIdx.x >> 6] = (uint32_t)(__builtin_amdgcn_s_memtime() >> 10);
-    __builtin_amdgcn_s_setprio(0);
-}
-// opposite priorities for the two waves of a SIMD, swapped every 2^SHIFT cycles counted from the start of the kernel
-__device__ __forceinline__ void bn_fair_priority_time() {
-    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);
-    const uint32_t t0 = __builtin_amdgcn_readfirstlane(bn_fair_t0[threadIdx.x >> 6]);
-    const uint32_t phase = ((uint32_t)(__builtin_amdgcn_s_memtime() >> 10) - t0) >> (BN_B_FAIR_SHIFT - 10);
-    if ((phase ^ slot) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-}
-// progress counters of the (up to 16) waves of the workgroup, the index of the wave each one shares its SIMD with, and each
-// wave's current role (1 = runs with priority).  Roles swap when the privileged wave is BN_B_FAIR_LEAD ticks ahead: strict
-// priority is the efficient way to share a SIMD (the two instruction streams stay out of phase; in lockstep both hit the
-// multiplier at the same time and the pair is 6 % slower than even the unmanaged kernel), the swap only bounds the lead so
-// that both waves reach the end of the kernel within a few ticks of each other.
-#ifndef BN_B_FAIR_LEAD
-#define BN_B_FAIR_LEAD 8
-#endif
-#ifndef BN_B_FAIR_HI
-#define BN_B_FAIR_HI 3
-#endif
-__shared__ uint32_t bn_fair_ticks[16];
-__shared__ uint32_t bn_fair_partner[16];
-__shared__ uint32_t bn_fair_role[16];
-__shared__ uint32_t bn_fair_simd[16];
-__device__ __forceinline__ void bn_fair_init() {
-    const uint32_t w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        bn_fair_ticks[w] = 0;
-        bn_fair_simd[w] = (__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) >> 4) & 3;     // HW_ID.simd_id
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-        uint32_t partner = w;
-        for (uint32_t v = 0; v < nw; ++v)
-            if (v != w && bn_fair_simd[v] == bn_fair_simd[w]) partner = v;
-        bn_fair_partner[w] = partner;
-        bn_fair_role[w] = w <= partner;               // the first wave of a pair starts with the priority
-    }
-    __syncthreads();
-    __builtin_amdgcn_s_setprio(0);
-}
-__device__ __forceinline__ void bn_fair_progress() {
-    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t partner = __builtin_amdgcn_readfirstlane(bn_fair_partner[w]);
-    const int32_t mine = (int32_t)__builtin_amdgcn_readfirstlane(bn_fair_ticks[w]) + 1;
-    const int32_t other = (int32_t)__builtin_amdgcn_readfirstlane(bn_fair_ticks[partner]);
-    uint32_t role = __builtin_amdgcn_readfirstlane(bn_fair_role[w]);
-    if (partner != w) {
-        if (mine - other >= BN_B_FAIR_LEAD) role = 0;
-        else if (other - mine >= BN_B_FAIR_LEAD) role = 1;
-    }
-    if ((threadIdx.x & 63) == 0) { bn_fair_ticks[w] = (uint32_t)mine; bn_fair_role[w] = role; }
-#ifndef BN_B_FAIR_NOPRIO
-    if (role) __builtin_amdgcn_s_setprio(BN_B_FAIR_HI); else __builtin_amdgcn_s_setprio(0);
-#endif
-}
-#if BN_B_FAIR == 2
-#define BN_KERNEL_PROLOGUE() bn_fair_init()
-#elif BN_B_FAIR == 3 || BN_B_FAIR == 5
-#define BN_KERNEL_PROLOGUE() bn_fair_time_init()
-#else
-#define BN_KERNEL_PROLOGUE() ((void)0)
-#endif
+#define BN_MILLER_HOOK(step, total) bn_fair_handover(step, total)
+#define BN_EXP_HOOK(step, total) bn_fair_handover(step, total)
 #include "curve.hpp"
 #include "io.hpp"
 
 using namespace bn254;
 
 namespace {
-constexpr int BLOCK = BN_B_BLOCK;
+constexpr int BLOCK = 64;
 typedef Fq2B<Fe> F2;
 
 // Miller-loop state parked in LDS: 7 field elements x 9 limbs = 63 dwords per lane, laid out [dword][lane] so that a wave's
@@ -188,30 +68,12 @@ struct MillerStateLds {
     __device__ __forceinline__ G2Aff<F2> get_base() const { return {{ld_fe(3)}, {ld_fe(4)}}; }
     __device__ __forceinline__ void put_p(const G1Aff<Fe> &v) const { st_fe(5, v.x); st_fe(6, v.y); }
     __device__ __forceinline__ G1Aff<Fe> get_p() const { return {ld_fe(5), ld_fe(6)}; }
-    // a line waits in R's slots while R itself is in registers (miller_loop_naf_merged)
-    __device__ __forceinline__ void park_line(const F2 &a, const F2 &b, const F2 &c) const { st_fe(0, a.v); st_fe(1, b.v); st_fe(2, c.v); }
-    __device__ __forceinline__ void unpark_line(F2 &a, F2 &b, F2 &c) const { a.v = ld_fe(0); b.v = ld_fe(1); c.v = ld_fe(2); }
 };
 
-#ifdef BN_STAMP   // experiment: per-wave start/end wall-clock stamps (100 MHz) + XCC id, read back with bn254_debug_stamps
-__device__ uint64_t bn_stamps[3 * 4096];
-#define BN_STAMP_BEGIN() uint64_t stamp_t0_ = __builtin_amdgcn_s_memrealtime()
-#define BN_STAMP_END()                                                                                              \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 4096) {                 \
-        const uint32_t sw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                  \
-        bn_stamps[3 * sw_] = stamp_t0_; bn_stamps[3 * sw_ + 1] = __builtin_amdgcn_s_memrealtime();                 \
-        bn_stamps[3 * sw_ + 2] = (uint64_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32 | (uint32_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);                    \
-    }
-extern "C" int bn254_debug_stamps(uint64_t *out, size_t n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bn_stamps), n * 8); }
-#else
-#define BN_STAMP_BEGIN() ((void)0)
-#define BN_STAMP_END() ((void)0)
-#endif
 template <bool NAF>
 __device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
     // (the register allocation of this kernel is sensitive to its exact shape: 3 spilled VGPRs in this form, 14 when the value
     //  computation is factored into a helper)
-    BN_STAMP_BEGIN();
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
@@ -225,28 +87,20 @@ __device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t
     __shared__ uint32_t park[PARK_DWORDS * BLOCK];
     MillerStateLds st = {park + threadIdx.x};
     Fq12<F2> f;
-#ifdef BN_MILLER_MERGE_LINES
-    if constexpr (NAF) f = miller_loop_naf_merged(p, q, st);
-    else f = miller_loop_sched<NAF>(p, q, st);
-#else
     f = miller_loop_sched<NAF>(p, q, st);
-#endif
     Fq12<F2> one = f12_one<F2>();
     f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
     f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);
     if (live) f12_store(f, f_out + 96u * pair);
-    BN_STAMP_END();
 }
 
 // reference schedule: the Miller VALUES equal the reference's (bn254_miller_batch_dev, prepared-mode cross checks)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
-    BN_KERNEL_PROLOGUE();
-    miller_B_body<false>(g1, g2, f_out, n);
+        miller_B_body<false>(g1, g2, f_out, n);
 }
 // NAF schedule (pairing.hpp miller_loop_sched<true>): used wherever a final exponentiation follows
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_naf_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
-    BN_KERNEL_PROLOGUE();
-    miller_B_body<true>(g1, g2, f_out, n);
+        miller_B_body<true>(g1, g2, f_out, n);
 }
 
 // Table of the exponentiation machine (pairing.hpp ExpTableVars) in global memory.  One Fq6 half of a slot is 27 dwords per lane,
@@ -295,30 +149,26 @@ struct ExpTableMem {
 constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 2 * 7 * 4;
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n, uint32_t *table) {
-    BN_KERNEL_PROLOGUE();
-    BN_STAMP_BEGIN();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
     ExpTableMem tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
     Fq12<F2> f = final_exponentiation(f12_load<F2>(f_in + 96u * pair), tbl);
     if (live) f12_store(f, out + 96u * pair);
-    BN_STAMP_END();
 }
 // ---- the multi-pairing's Miller loop with a shared accumulator (pairing.hpp miller_loop_shared): M pairs per lane pair
 // State of the M pairs in global memory: per lane and pair 17 x 16 bytes - R (27 dwords in 7 groups of 4), the base point (18 in 5),
 // P (18 in 5) -, group-major, then the lane: every access of a wave is one coalesced dwordx4 instruction over 1 KB (ExpTableMem's
 // layout).  Both lanes of a pair hold P (an Fq point) replicated.
-#ifndef BN_SHARED_P_GLOBAL
-#define BN_SHARED_P_LDS 1    // the M affine P_i live in LDS ([pair][dword][lane]: 72 B per lane and pair, 18 KB per workgroup at M = 4, eight
-#endif                       // workgroups per CU = 147 of the 160 KB) instead of global memory: they are read in EVERY step of every pair
+// The M affine P_i live in LDS ([pair][dword][lane]: 72 B per lane and pair, 18 KB per workgroup at M = 4, eight workgroups per CU = 147 of
+// the 160 KB): they are read in EVERY step of every pair (in global memory: 2.2 % slower, profiles/r04e_ab_shared_p_lds.txt)
 template <int M>
 struct MillerStateMem {
     uint4 *base;             // wave-uniform
     uint32_t lane, stride;   // this lane's column, lanes in the launch
     uint32_t infmask;        // bit i: pair i is (treated as) infinite
-    uint32_t *plds;          // this lane's column of the workgroup's P store (BN_SHARED_P_LDS)
+    uint32_t *plds;          // this lane's column of the workgroup's P store
 #ifdef BN_AB_ALIAS_SCRATCH
     __device__ __forceinline__ uint32_t row(int, int g) const { return (uint32_t)g * stride + (lane & 8191u); }      // timing experiment, see ExpTableMem
 #else
@@ -353,7 +203,6 @@ struct MillerStateMem {
     __device__ __forceinline__ G2Proj<F2> get_r(int i) const { Fe t[3]; ld_n<3, 0>(i, t); return {{t[0]}, {t[1]}, {t[2]}}; }
     __device__ __forceinline__ void put_base(int i, const G2Aff<F2> &v) const { Fe t[2] = {v.x.v, v.y.v}; st_n<2, 7>(i, t); }
     __device__ __forceinline__ G2Aff<F2> get_base(int i) const { Fe t[2]; ld_n<2, 7>(i, t); return {{t[0]}, {t[1]}}; }
-#ifdef BN_SHARED_P_LDS
     __device__ __forceinline__ void put_p(int i, const G1Aff<Fe> &v) const {
 #pragma unroll
         for (int l = 0; l < 9; ++l) { plds[((i * 18) + l) * BLOCK] = v.x.l[l]; plds[((i * 18) + 9 + l) * BLOCK] = v.y.l[l]; }
@@ -364,10 +213,6 @@ struct MillerStateMem {
         for (int l = 0; l < 9; ++l) { v.x.l[l] = plds[((i * 18) + l) * BLOCK]; v.y.l[l] = plds[((i * 18) + 9 + l) * BLOCK]; }
         return v;
     }
-#else
-    __device__ __forceinline__ void put_p(int i, const G1Aff<Fe> &v) const { Fe t[2] = {v.x, v.y}; st_n<2, 12>(i, t); }
-    __device__ __forceinline__ G1Aff<Fe> get_p(int i) const { Fe t[2]; ld_n<2, 12>(i, t); return {t[0], t[1]}; }
-#endif
     __device__ __forceinline__ bool is_inf(int i) const { return (infmask >> i) & 1u; }
 };
 constexpr size_t MILLER_STATE_BYTES_PER_LANE_AND_PAIR = 17 * 16;
@@ -378,12 +223,8 @@ __device__ __forceinline__ void miller_shared_body(const uint32_t *g1, const uin
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t lp = t >> 1, groups = (n + M - 1) / M;
     const bool live = lp < groups;
-#ifdef BN_SHARED_P_LDS
     __shared__ uint32_t p_store[M * 18 * BLOCK];
     MillerStateMem<M> st = {state, t, gridDim.x * BLOCK, 0u, p_store + threadIdx.x};
-#else
-    MillerStateMem<M> st = {state, t, gridDim.x * BLOCK, 0u, nullptr};
-#endif
 #pragma unroll 1
     for (int i = 0; i < M; ++i) {
         uint32_t pair = (live ? lp : groups - 1) * M + (uint32_t)i;
@@ -405,19 +246,16 @@ __device__ __forceinline__ void miller_shared_body(const uint32_t *g1, const uin
     if (live) f12_store(f, f_out + 96u * lp);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_shared2_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n, uint4 *state) {
-    BN_KERNEL_PROLOGUE();
-    miller_shared_body<2>(g1, g2, f_out, n, state);
+        miller_shared_body<2>(g1, g2, f_out, n, state);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_shared4_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n, uint4 *state) {
-    BN_KERNEL_PROLOGUE();
-    miller_shared_body<4>(g1, g2, f_out, n, state);
+        miller_shared_body<4>(g1, g2, f_out, n, state);
 }
 
 // ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
 constexpr int NCOEFF = 102, COEFF_WORDS = 48;
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_g2_precompute_B(const uint32_t *g2, uint32_t *coeffs, uint32_t n) {
-    BN_KERNEL_PROLOGUE();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -434,8 +272,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 }
 // f[i] = miller_loop(coeffs, P[i])  (groups/mod.rs:486-519); coeff_stride = 0 shares one coefficient set among all P
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_prepared_B(const uint32_t *g1, const uint32_t *coeffs, uint32_t coeff_stride, uint32_t *f_out, uint32_t n) {
-    BN_KERNEL_PROLOGUE();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -462,8 +299,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 
 // out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
-    BN_KERNEL_PROLOGUE();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -479,7 +315,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // lane pair's own digit - at most 9 (16) different 1 KB rows per instruction instead of 64 different cache lines with the round-2
 // [lane][entry] layout.  Inputs in the cyclotomic subgroup (checked on the device: every value the reference's API can produce)
 // take the signed-window Granger-Scott chain (pairing.hpp gt_pow_cyclotomic), anything else the general one.
-#ifndef BN_POW_TABLE_ENTRY_MAJOR
 // [lane][entry][half][7 x 16 bytes]: the entry a lane reads depends on ITS digit, so contiguous 224-byte runs per lane (two cache
 // lines each) beat the entry-major rows (every lane's 16 bytes from a different 1 KB row: 4x the traffic, profiles/r03m_pmc_side.txt)
 struct PowTableLane {
@@ -516,15 +351,10 @@ struct PowTableLane {
     __device__ __forceinline__ Fq6<F2> c0(int i) const { return ld6(i, 0); }
     __device__ __forceinline__ Fq6<F2> c1(int i) const { return ld6(i, 1); }
 };
-#endif
 constexpr size_t POW_TABLE_DWORDS_PER_LANE = GT_GLS_ENTRIES * 2 * 7 * 4;          // 33 entries of 216 B: 7.4 KB per lane
 // the general chain as a real function: it is the rare path, and inlined next to the cyclotomic chain the two were register-allocated
 // together (97 spilled VGPRs)
-#ifdef BN_POW_TABLE_ENTRY_MAJOR
-typedef ExpTableMem PowTable;
-#else
 typedef PowTableLane PowTable;
-#endif
 __device__ __noinline__ void gt_pow_general_cold(const Fq12<F2> *base, const uint32_t *raw, const PowTable *tbl, Fq12<F2> *res) {
     PowTable t = *tbl;
     *res = gt_pow_windowed(*base, raw, t);
@@ -538,8 +368,7 @@ __device__ __noinline__ void gt_pow_gls_table_cold(const Fq12<F2> *base, const P
     gt_pow_gls_table(*base, t);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table, int mode) {
-    BN_KERNEL_PROLOGUE();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -552,11 +381,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
         fr_from_mont(kw, raw);
     };
     uint32_t raw[8];
-#ifdef BN_POW_TABLE_ENTRY_MAJOR
-    PowTable tbl = {(uint4 *)table, t, gridDim.x * BLOCK};
-#else
     PowTable tbl = {(uint4 *)table + (size_t)t * (POW_TABLE_DWORDS_PER_LANE / 4)};
-#endif
     const Fq12<F2> base = f12_load<F2>(a + 96u * pair);
     Fq12<F2> res;
     // wave-uniform choice.  mode 0: Frobenius decomposition when every element of the wave is cyclotomic (exact for values of order
@@ -570,8 +395,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 }
 // out[i] = a[i]^-1   (Gt::inverse, lib.rs:172 -> fq12.rs:284-292; one Fq inversion per element, constant-time divsteps)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_inverse_B(const uint32_t *a, uint32_t *out, uint32_t n) {
-    BN_KERNEL_PROLOGUE();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -584,8 +408,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // cyclotomic elements, which is all a pairing ever feeds it; this kernel exists so that the reference's known answer for the function
 // (fields/mod.rs:171-201, an element OFF the subgroup) runs on the device literally.
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_exp_by_neg_z_B(const uint32_t *a, uint32_t *out, uint32_t n) {
-    BN_KERNEL_PROLOGUE();
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;

@@ -8,12 +8,8 @@
 // This translation unit inlines the point operations and the multiplier leaves: the running point stays in registers for the
 // whole chain (in the call-based build of bn254_hip.hip every doubling went through private memory: 6 / 27 GB of HBM traffic
 // per 2^16 G1 / G2 multiplications).  Only the 16-entry window table is a per-lane array in private memory.
-#define BN_COARSE __device__ __forceinline__
-#define BN_LEAF_MUL __device__ __forceinline__
-#define BN_LEAF_RED __device__ __forceinline__
-#ifndef BN_MUL_WAVES
-#define BN_MUL_WAVES 3        // resident waves per SIMD the G1 kernels are compiled for (167 VGPRs, no spills; 2: -1 %, 4: spills)
-#endif
+#define BN_INLINE_ALL 1       // fe.hpp: leaves and Fq6/Fq12-sized steps force-inlined
+#define BN_MUL_WAVES 3        // resident waves per SIMD the G1 kernels are compiled for (160 VGPRs, no spills; 2: -1 %, 4: spills)
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "curve.hpp"
@@ -27,10 +23,9 @@ typedef Fq2B<Fe> F2;
 
 // The affine window table of a lane in global memory: [lane][entry 1..8][18 dwords padded to 80 bytes] - a lane reads the entry of
 // ITS digit as five 16-byte loads from one or two cache lines (curve.hpp AffTableVars explains why not a private array).
-#ifndef BN_AFF_ENTRY_U4
-#define BN_AFF_ENTRY_U4 5           // 16-byte groups per entry: 5 = packed (80 B, an entry may straddle two 128-byte lines), 8 = one line per entry
-#endif
-constexpr uint32_t AFF_ENTRY_U4 = BN_AFF_ENTRY_U4, AFF_LANE_U4 = 8 * AFF_ENTRY_U4;   // 80 B per entry, 640 B per lane
+// 16-byte groups per entry: 5 = packed (80 B: an entry may straddle two 128-byte lines; one whole line per entry measured no faster, a
+// prefetch one window ahead 2 % slower: profiles/r04c_ab_g1mul.txt)
+constexpr uint32_t AFF_ENTRY_U4 = 5, AFF_LANE_U4 = 8 * AFF_ENTRY_U4;                 // 80 B per entry, 640 B per lane
 template <class F>
 struct AffTableMem {
     uint4 *base;             // this lane's 8 entries
@@ -54,10 +49,6 @@ struct AffTableMem {
 #pragma unroll
         for (int i2 = 0; i2 < 9; ++i2) { x.l[i2] = w[i2]; y.l[i2] = w[9 + i2]; }
     }
-    // touch(i): start fetching entry i towards the caches (one dword; the value only keeps the load alive until consume());
-    // used a window ahead, when the digit is known but the four doublings still have to run (-DBN_MUL_PREFETCH; measured: -2 %, profiles/r04c_ab_g1mul.txt)
-    __device__ __forceinline__ uint32_t touch(int i) const { return ((const volatile uint32_t *)(base + (uint32_t)(i - 1) * AFF_ENTRY_U4))[0]; }
-    static __device__ __forceinline__ void consume(uint32_t token) { asm volatile("" ::"v"(token)); }
     // G1: (x, y) are Fe; G2 in the lane-pair mapping: this lane's components of (x, y)
     __device__ __forceinline__ void put(int i, const Aff<FqField> &v) const { put_fe(i, v.x, v.y); }
     __device__ __forceinline__ void put(int i, const Aff<Fq2Field<Fq2B<Fe>>> &v) const { put_fe(i, v.x.v, v.y.v); }

@@ -4,10 +4,7 @@
 // BN254_OPT_QUAD_MAX pairings per call, where the lane-pair kernels (bn254_kernels_b.hip: 4.2 ms whatever the count) would leave SIMDs
 // empty: 16 384 pairings are 1024 waves here - one per SIMD - against 512 there.  Everything on the hot loops is inlined, like in
 // the lane-pair kernels; with one wave per SIMD the register budget is 512 VGPRs, so nothing spills.
-#define BN_LC_TOP_LIMB7 1            // fe.hpp fe_lc4_core: this unit keeps the explicit limb-7 term of the quotient estimate (see there)
-#define BN_COARSE __device__ __forceinline__
-#define BN_LEAF_MUL __device__ __forceinline__
-#define BN_LEAF_RED __device__ __forceinline__
+#define BN_INLINE_ALL 1       // fe.hpp: leaves and Fq6/Fq12-sized steps force-inlined
 #include <hip/hip_runtime.h>
 #include "quad.hpp"
 #include "io.hpp"

@@ -9,9 +9,7 @@
 // (1.045 against 1.052 ms) and held a CU to three workgroups, one wave per SIMD - and a lone wave leaves half of the multiplier idle
 // (it issues a v_mad_u64_u32 every ~8 cycles whatever the dependencies: profiles/r03s_ubench_chain.txt).  With 11.5 KB a CU takes
 // thirteen: 1024 pairings cost what one does, 2048 1.5 ms instead of 3.2 ms (profiles/r03s_wave_roles_ab.txt).
-#define BN_COARSE __device__ __forceinline__
-#define BN_LEAF_MUL __device__ __forceinline__
-#define BN_LEAF_RED __device__ __forceinline__
+#define BN_INLINE_ALL 1       // fe.hpp: leaves and Fq6/Fq12-sized steps force-inlined
 #include <hip/hip_runtime.h>
 #include "wave.hpp"
 #include "io.hpp"

@@ -6,8 +6,7 @@
 //     exchange), and the multi-pairing product: one un-exponentiated Fq12 per GPU, ONE RCCL all-gather of 384 bytes per rank
 //     over xGMI (RCCL has no user-defined reduction), world-1 Fq12 products and a SINGLE final exponentiation - the fold of
 //     the reference's shootout/main.rs:11-16, bit for bit, because the final exponentiation is a homomorphism;
-//   * two small measurement/input kernels: the v_mad_u64_u32 issue-rate microbenchmark behind bench.py's same-run `peak`,
-//     and the on-device generator of the synthetic Fr scalars (SplitMix64 -> 512 bits -> mod r -> Montgomery form).
+// (The measurement and input-generation kernels of bench.py live in bn254_measure.hip.)
 // RCCL is resolved with dlopen at the first multi-device call, so the library itself has no link-time dependency on it.
 #include <dlfcn.h>
 #include <pthread.h>
@@ -91,18 +90,21 @@ void plan(const bn254_ctx *c, size_t n, size_t &chunk, int &nslots) {
 // destructor calls std::terminate): a thread constructor that throws (resource exhaustion) makes the remaining workers run inline, and
 // an exception out of fn - bad_alloc inside a std::function or vector, say - on whichever thread is held until every started thread
 // has been joined, then rethrown on the calling thread for the entry point's bn_no_throw to translate.
+// all_on_workers: job 0 gets a thread of its own too, so that nothing a job does to its thread (BnAffinityScope pins it) touches the CALLER's
+// thread - threads the HIP / RCCL runtime creates lazily from a pinned thread inherit the narrowed mask for good
 template <class Fn>
-void run_workers(int count, Fn fn) {
+void run_workers(int count, Fn fn, bool all_on_workers = false) {
     std::vector<std::exception_ptr> err((size_t)count);
     auto guarded = [&](int w) noexcept { try { fn(w); } catch (...) { err[(size_t)w] = std::current_exception(); } };
     std::vector<std::thread> th;
     th.reserve((size_t)count);
-    int started = 1;
-    for (int w = 1; w < count; ++w) {
+    const int first = all_on_workers ? 0 : 1;
+    int started = first;
+    for (int w = first; w < count; ++w) {
         try { th.emplace_back(guarded, w); ++started; } catch (...) { break; }
     }
-    guarded(0);
-    for (int w = started; w < count; ++w) guarded(w);
+    if (!all_on_workers) guarded(0);
+    for (int w = started; w < count; ++w) guarded(w);                    // (thread creation failed: the rest runs here, one after the other)
     for (auto &t : th) t.join();
     for (auto &e : err) if (e) std::rethrow_exception(e);
 }
@@ -224,12 +226,12 @@ static RankCpus rank_cpus_of_device(int dev) {
     r.valid = CPU_COUNT(&r.set) > 0;
     return r;
 }
-// pins the CURRENT thread for the lifetime of the object (worker threads end with it; the caller's thread - rank 0 runs there -
-// gets its old mask back)
+// pins the CURRENT thread for the lifetime of the object - worker threads only (they end with the call): the caller's thread is never
+// re-pinned, every rank of a multi-device call runs on a thread of its own (run_workers all_on_workers)
 struct BnAffinityScope {
     cpu_set_t old; bool restore = false;
-    explicit BnAffinityScope(const RankCpus &rc) {
-        if (!rc.valid) return;
+    BnAffinityScope(const RankCpus &rc, std::thread::id caller) {
+        if (!rc.valid || std::this_thread::get_id() == caller) return;
         if (pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;
         restore = pthread_setaffinity_np(pthread_self(), sizeof rc.set, &rc.set) == 0;
     }
@@ -341,11 +343,12 @@ static int pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, b
     std::lock_guard<std::mutex> lk(m->mu);
     const size_t G = m->ctx.size();
     std::vector<int> rcs(G, BN254_OK);
+    const std::thread::id caller = std::this_thread::get_id();
     run_workers((int)G, [&](int g) {
-        BnAffinityScope pin(m->cpus[(size_t)g]);
+        BnAffinityScope pin(m->cpus[(size_t)g], caller);
         const size_t lo = n * (size_t)g / G, hi = n * ((size_t)g + 1) / G;
         rcs[g] = bn254_pairing_batch(m->ctx[g], p + lo, q + lo, out + lo, hi - lo);
-    });
+    }, true);
     for (int rc : rcs) if (rc) return rc;
     return BN254_OK;
 }
@@ -372,7 +375,8 @@ static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q,
         HIP_TRY(hipStreamSynchronize(c->stream));
         return BN254_OK;
     };
-    run_workers((int)G, [&](int g) { BnAffinityScope pin(m->cpus[(size_t)g]); rcs[g] = local((size_t)g); });
+    const std::thread::id caller = std::this_thread::get_id();
+    run_workers((int)G, [&](int g) { BnAffinityScope pin(m->cpus[(size_t)g], caller); rcs[g] = local((size_t)g); }, true);
     for (int rc : rcs) if (rc) return rc;
     // 2. the ONE exchange step: 384 bytes per rank
     if (m->exchange == BN254_EXCHANGE_RCCL) {
@@ -412,134 +416,6 @@ static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q,
     HIP_TRY(hipMemcpyAsync(out, m->d_partial[0].p, sizeof(bn_gt), hipMemcpyDeviceToHost, c0->stream));
     HIP_TRY(hipStreamSynchronize(c0->stream));
     return BN254_OK;
-}
-
-}  // extern "C"
-
-// ============================================================================================ measurement / input kernels
-namespace {
-
-// 16 independent-ish v_mad_u64_u32 per iteration on 8 accumulators: the issue-rate ceiling of the instruction every field
-// multiplication of the engine is built from (tools/ubench.hip is the long form of this experiment)
-__global__ void __launch_bounds__(256) bn254_ubench_mad_k(uint32_t *out, uint32_t seed, int iters) {
-    uint32_t a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
-    uint64_t acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = a + i;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[u & 7]) : "v"(a), "v"(b) : "vcc");
-    }
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i];
-    if (s == 0x1234567) out[threadIdx.x] = (uint32_t)s;
-}
-
-// ---- Fr (8 x u32, Montgomery radix 2^256) just for the scalar generator: CIOS product, result < r
-__device__ void fr_mont_mul(const uint32_t *a, const uint32_t *b, uint32_t *out) {
-    using namespace bn254;
-    uint32_t t[10] = {};
-    for (int i = 0; i < 8; ++i) {
-        uint64_t c = 0;
-        for (int j = 0; j < 8; ++j) { uint64_t x = (uint64_t)a[j] * b[i] + t[j] + c; t[j] = (uint32_t)x; c = x >> 32; }
-        uint64_t x = (uint64_t)t[8] + c; t[8] = (uint32_t)x; t[9] = (uint32_t)(x >> 32);
-        uint32_t mq = t[0] * k::FR_INV32;
-        c = ((uint64_t)mq * k::FR_MOD32[0] + t[0]) >> 32;
-        for (int j = 1; j < 8; ++j) { uint64_t y = (uint64_t)mq * k::FR_MOD32[j] + t[j] + c; t[j - 1] = (uint32_t)y; c = y >> 32; }
-        x = (uint64_t)t[8] + c; t[7] = (uint32_t)x;
-        t[8] = t[9] + (uint32_t)(x >> 32);
-        t[9] = 0;
-    }
-    // t < 2r: one conditional subtraction
-    uint32_t d[8];
-    int64_t br = 0;
-    for (int i = 0; i < 8; ++i) { int64_t s = (int64_t)t[i] - (int64_t)k::FR_MOD32[i] + br; d[i] = (uint32_t)s; br = s >> 32; }
-    const bool ge = (t[8] != 0) || (br == 0);
-    for (int i = 0; i < 8; ++i) out[i] = ge ? d[i] : t[i];
-}
-__device__ uint64_t splitmix64_next(uint64_t &state) {
-    state += 0x9E3779B97F4A7C15ull;
-    uint64_t z = state;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-// out[j] = Montgomery image of (512-bit SplitMix64 draw of stream 2*(lo+j)+which) mod r   (bn_amd.distributed.synthetic_scalars)
-__global__ void __launch_bounds__(64) bn254_synthetic_scalars_k(uint64_t lo, uint32_t n, uint32_t which, uint64_t seed, uint32_t *out) {
-    using namespace bn254;
-    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= n) return;
-    uint64_t state = seed + (((lo + j) * 2 + which) << 32);
-    uint32_t w[16];
-    for (int i = 0; i < 8; ++i) { uint64_t z = splitmix64_next(state); w[2 * i] = (uint32_t)z; w[2 * i + 1] = (uint32_t)(z >> 32); }
-    uint32_t r2[8], r3[8], a[8], b[8];
-    for (int i = 0; i < 8; ++i) r2[i] = k::FR_R2_32[i];
-    fr_mont_mul(r2, r2, r3);                    // R^3 mod r
-    fr_mont_mul(w, r2, a);                      // low half  * R     (operand < 2^256, result < r)
-    fr_mont_mul(w + 8, r3, b);                  // high half * R^2 = high * 2^256 * R
-    uint32_t s[9];
-    uint64_t c = 0;
-    for (int i = 0; i < 8; ++i) { uint64_t x = (uint64_t)a[i] + b[i] + c; s[i] = (uint32_t)x; c = x >> 32; }
-    s[8] = (uint32_t)c;
-    uint32_t d[8];
-    int64_t br = 0;
-    for (int i = 0; i < 8; ++i) { int64_t t = (int64_t)s[i] - (int64_t)k::FR_MOD32[i] + br; d[i] = (uint32_t)t; br = t >> 32; }
-    const bool ge = (s[8] != 0) || (br == 0);
-    for (int i = 0; i < 8; ++i) out[8u * j + i] = ge ? d[i] : s[i];
-}
-// out[i] = src[0]  (tiles one point/record of `words` u32 over n records: the generator bases of the synthetic inputs)
-__global__ void __launch_bounds__(256) bn254_tile_k(const uint32_t *src, uint32_t words, uint64_t total, uint32_t *out) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < total) out[i] = src[i % words];
-}
-
-}  // namespace
-
-extern "C" {
-
-// G MAC32/s (lane multiply-accumulates per second) of a pure v_mad_u64_u32 stream at `waves_per_simd` resident waves
-int bn254_ubench_mac32(bn254_ctx *ctx, int waves_per_simd, int iters, double *gmac_per_s, double *ms_out) {
-    int rc = bn_get_ctx(ctx); if (rc) return rc;
-    if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !gmac_per_s) return BN254_E_BAD_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    BnDeviceGuard dev_guard;
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
-    const int blocks = prop.multiProcessorCount * waves_per_simd;          // 256 threads = one wave on each of a CU's 4 SIMDs
-    if ((rc = ctx->stage[0].reserve(4096))) return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    hipLaunchKernelGGL(bn254_ubench_mad_k, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t *)ctx->stage[0].p, 1u, iters / 8 + 1);   // warm-up
-    HIP_TRY(hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(bn254_ubench_mad_k, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t *)ctx->stage[0].p, 2u, iters);
-    HIP_TRY(hipEventRecord(e1, ctx->stream));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    *gmac_per_s = (double)blocks * 256.0 * 16.0 * iters / (ms * 1e-3) / 1e9;
-    if (ms_out) *ms_out = ms;
-    return BN254_OK;
-}
-
-int bn254_synthetic_scalars_dev(bn254_ctx *ctx, uint64_t seed, uint64_t lo, size_t n, int which, void *d_out, void *stream) {
-    int rc = bn_get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_out || n > 0x7fffffffu / 8 || (which != 0 && which != 1)) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(bn254_synthetic_scalars_k, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, lo, (uint32_t)n, (uint32_t)which, seed, (uint32_t *)d_out);
-    return (int)hipGetLastError();
-}
-int bn254_tile_dev(bn254_ctx *ctx, const void *d_record, size_t record_bytes, size_t n, void *d_out, void *stream) {
-    int rc = bn_get_ctx(ctx); if (rc) return rc;
-    if (n == 0) return BN254_OK;
-    if (!d_record || !d_out || record_bytes == 0 || record_bytes % 4) return BN254_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    const uint64_t total = (uint64_t)n * (record_bytes / 4);
-    hipLaunchKernelGGL(bn254_tile_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_record, (uint32_t)(record_bytes / 4), total, (uint32_t *)d_out);
-    return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -217,8 +217,6 @@ struct AffTableVars {
     Aff<F> e[9];
     BN_FN void put(int i, const Aff<F> &v) { e[i] = v; }
     BN_FN Aff<F> get(int i) const { return e[i]; }
-    BN_FN uint32_t touch(int) const { return 0; }
-    static BN_FN void consume(uint32_t) {}
 };
 template <class F, int N, bool CONJ_EXTRA = false, class Tab>
 BN_FN typename F::T table_to_common_z(const Jac<F> *tab, Tab &aff) {
@@ -451,23 +449,10 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw, 
     bool res_inf = true;
 #pragma unroll 1
     for (int w = GLV_WINDOWS - 1; w >= 0; --w) {
-#ifdef BN_MUL_PREFETCH
-        // both entries of this window start their way from memory BEFORE the four doublings (their digits are known)
-        uint32_t tok[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int d = booth_digit(half ? g.m2 : g.m1, w);
-            const int ad = d < 0 ? -d : d;
-            tok[half] = aff.touch(ad ? ad : 1);
-        }
-#endif
         if (w != GLV_WINDOWS - 1) {
 #pragma unroll 1
             for (int d = 0; d < 4; ++d) res = jac_double(res);    // infinity stays infinity (z = 0)
         }
-#ifdef BN_MUL_PREFETCH
-        Tab::consume(tok[0]); Tab::consume(tok[1]);
-#endif
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             const int d = booth_digit(half ? g.m2 : g.m1, w);

@@ -19,14 +19,19 @@
 #include <stdint.h>
 
 // BN_FN     small glue, always inlined
-// BN_LEAF   the multiplier-sized leaves (fe_mul, fe_mul2, fe_lc3, fe_inverse): real functions on the GPU (operands travel in
+// BN_LEAF   the multiplier-sized leaves (fe_mul, fe_mul2, fe_lc3, fe_inverse): real functions by default (operands travel in
 //           VGPRs: an Fe is 9 dwords, under the 16-dword by-value limit of the AMDGPU calling convention), so the hot code
 //           of a whole pairing stays inside the instruction cache instead of being replicated 19 000 times
-// BN_COARSE Fq6/Fq12-sized steps: real functions too; their operands live in private (scratch) memory in the one-lane
+// BN_COARSE Fq6/Fq12-sized steps: real functions by default; their operands live in private (scratch) memory in the one-lane
 //           mapping and in VGPRs in the lane-pair mapping
+// A translation unit that defines BN_INLINE_ALL before including this header (every kernel file of the lane-pair, four-lane, wave and
+// scalar-multiplication kernels) gets all three classes force-inlined: without calls there is no argument marshalling (v_mov was ~45 % of
+// the non-leaf instructions) and no caller-/callee-saved split of the register file (+7 %, profiles/r01g_*).
 #if defined(BN_HOSTSIM)
 #define BN_FN inline
 #define BN_LEAF inline
+#define BN_LEAF_MUL inline
+#define BN_LEAF_RED inline
 #define BN_COARSE inline
 #define BN_OUTER inline
 #define BN254_CONSTANT constexpr
@@ -34,16 +39,14 @@
 #else
 #include <hip/hip_runtime.h>
 #define BN_FN __device__ __forceinline__
-#ifndef BN_LEAF
 #define BN_LEAF __device__ __noinline__ inline
-#endif
-#ifndef BN_LEAF_MUL                 // the multiplier-sized leaves (fe_mul, f2b_mul, f2b_sqr)
+#ifdef BN_INLINE_ALL
+#define BN_LEAF_MUL __device__ __forceinline__      // the multiplier-sized leaves (fe_mul, f2b_mul, f2b_sqr)
+#define BN_LEAF_RED __device__ __forceinline__      // the reduction-sized leaves (fe_lc3 family)
+#define BN_COARSE __device__ __forceinline__
+#else
 #define BN_LEAF_MUL BN_LEAF
-#endif
-#ifndef BN_LEAF_RED                 // the reduction-sized leaves (fe_lc3 family)
 #define BN_LEAF_RED BN_LEAF
-#endif
-#ifndef BN_COARSE
 #define BN_COARSE __device__ __noinline__ inline
 #endif
 // BN_OUTER  big, rarely executed steps (inversions, Frobenius maps, the straight-line part of the final exponentiation):
@@ -53,21 +56,15 @@
 // keeps loads that follow in the source from being scheduled above this point (used where early loads only cause spills)
 #define BN_COMPILER_FENCE() asm volatile("" ::: "memory")
 #endif
-#ifndef BN_FAIR_TICK                // executed inside the Fq6-sized steps (a few thousand cycles apart); see bn254_kernels_b.hip
-#define BN_FAIR_TICK() ((void)0)
-#endif
-#ifndef BN_MILLER_HOOK              // executed at the top of every step of the Miller loop: step number, number of steps
+// Hooks of the two-waves-per-SIMD priority hand-over (bn254_kernels_b.hip defines both before including this header): executed at the top
+// of every step of the Miller loop resp. of the three exponentiation loops of the final exponentiation, with the step number and the count
+#ifndef BN_MILLER_HOOK
 #define BN_MILLER_HOOK(step, total) ((void)0)
-#endif
-#ifndef BN_EXP_HOOK                 // same for the three exponentiation loops of the final exponentiation
 #define BN_EXP_HOOK(step, total) ((void)0)
 #endif
 #include "bn254_constants.hpp"
-// GPU builds run the multiplier leaves and the 64-bit chains of the fused reductions as inline-asm instruction chains (same
-// arithmetic; -DBN_NO_ASM_LEAF / -DBN_NO_ASM_REDUCE restore the C++ bodies, which the host simulation always uses)
-#if !defined(BN_HOSTSIM) && !defined(BN_NO_ASM_LEAF)
-#define BN_ASM_LEAF 1
-#endif
+// GPU builds run the multiplier leaves and the 64-bit chains of the fused reductions as inline-asm instruction chains (fe_asm.hpp: same
+// arithmetic, fixed instruction order); the host simulation runs the C++ bodies, which also carry the bound checks
 
 #if defined(BN_BOUNDS)
 #include <cstdio>
@@ -170,10 +167,6 @@ BN_FN u32x9 bn_tov(const Fe &f) {
 #define BN_LEAF2(NAME, BODY)                                                                      \
     BN_LEAF_MUL u32x9 NAME##_leaf(u32x9 a, u32x9 b) { return bn_tov(BODY(bn_unv(a), bn_unv(b))); }   \
     BN_FN Fe NAME(const Fe &a, const Fe &b) { return bn_unv(NAME##_leaf(bn_tov(a), bn_tov(b))); }
-#if defined(BN_INLINE_REDUCTIONS)
-#define BN_LEAF3T(NAME, BODY)                                                                     \
-    template <int C1, int C2, int C3> BN_FN Fe NAME(const Fe &a, const Fe &b, const Fe &c) { return BODY<C1, C2, C3>(a, b, c); }
-#else
 #define BN_LEAF3T(NAME, BODY)                                                                     \
     template <int C1, int C2, int C3> BN_LEAF_RED u32x9 NAME##_leaf(u32x9 a, u32x9 b, u32x9 c) {     \
         return bn_tov(BODY<C1, C2, C3>(bn_unv(a), bn_unv(b), bn_unv(c)));                         \
@@ -181,7 +174,6 @@ BN_FN u32x9 bn_tov(const Fe &f) {
     template <int C1, int C2, int C3> BN_FN Fe NAME(const Fe &a, const Fe &b, const Fe &c) {      \
         return bn_unv(NAME##_leaf<C1, C2, C3>(bn_tov(a), bn_tov(b), bn_tov(c)));                  \
     }
-#endif
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -376,11 +368,6 @@ BN_FN Fe fe_reduce(const Fe &a) {
 // subtracts and the odd lane adds the partner's limb in xi-multiplications)
 // WIDE: every term enters the 64-bit chain on its own (no 32-bit pre-combination), which lifts the bound on the SUM of the inputs' limb
 // bounds - each input still has to fit int32 (lb <= 4).  Used where one reduction takes the place of several (quad.hpp).
-#if defined(BN_NO_PAR_SIGN2)     // experiment switch: the role-signed term of the _par reductions through negate-and-select (rounds 1-3)
-#define BN_PAR_SIGN2 false
-#else
-#define BN_PAR_SIGN2 true
-#endif
 // SIGN2: the middle term's sign really is a per-lane value (the _par callers): the term then enters the 64-bit chain with a per-lane
 // coefficient register (one multiply-add per limb) instead of a negate-and-select before the narrow sum (two to three instructions).
 template <int C1, int C2, int C3, int C4, bool WIDE = false, bool SIGN2 = false>
@@ -404,21 +391,14 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
     BN_REQUIRE((N1 ? A1 * x.lb : 0) + (N2 ? A2 * y.lb : 0) + (N3 ? A3 * z.lb : 0) + (N4 ? A4 * w.lb : 0) <= 4, "fe_lc narrow part exceeds 32 bits");
     // signed estimate of floor(value / 2^232) that never exceeds the truth (margins: carries still parked in lower limbs,
     // at most 9 per unit coefficient, and the truncation of FE_MU24, < 2^9 units).
-    // (Round 4 tried the top limb alone - the margin of 9 covers what limb 7 holds beyond its 29 bits, and it saves two instructions
-    // per input.  The arithmetic held in the host simulation, but on the GPU the four-lane Miller kernel then returned wrong values:
-    // with l[8] used directly, LLVM's DPP combiner folds the quad_perm move of a neighbour pair's top limb into the subtraction that
-    // forms `te` (v_sub_u32_dpp / v_subrev_u32_dpp), and that code computes something else than the unfolded pair of instructions -
-    // every pairing wrong, gone with -mllvm -amdgpu-dpp-combine=false.  Cause not established (ROCm 7.2, gfx950): the four-lane kernels keep
-    // the explicit limb-7 term (BN_LC_TOP_LIMB7 in bn254_kernels_q.hip), and tests/test_build_quality.py keeps folded DPP subtractions out
-    // of the library.  The host simulation runs the top-limb form with every bound checked; the two forms differ in the quotient
-    // estimate of rare cases only, never in the residue.)
-#if defined(BN_LC_TOP_LIMB7)
-    auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8] + ((int32_t)f.l[7] >> 29); };
-#else
-    // the top limb alone (the lane-pair, wave and scalar-multiplication kernels): the margin of 9 per unit coefficient below covers what limb
-    // 7 holds beyond its 29 bits (|.| <= 4 units for limb bound 4; one unit is 3.2e-7 q), two instructions per input less
+    // The top limb alone: the margin of 9 per unit coefficient covers what limb 7 holds beyond its 29 bits (|.| <= 4 units for limb bound
+    // 4; one unit is 3.2e-7 q).  NOTE for whoever touches the build flags: with this form LLVM's DPP combiner folds the quad_perm move of a
+    // neighbour pair's top limb into the subtraction that forms `te` (v_sub_u32_dpp / v_subrev_u32_dpp), and in the four-lane Miller kernel
+    // that code returned wrong values on the GPU (round 4; ROCm 7.2, gfx950; cause not established - the folded instruction in isolation
+    // computes what it should: tools/dpp_fold_check.hip).  The library is therefore built with -mllvm -amdgpu-dpp-combine=false in EVERY
+    // unit (bn_amd/_native.py; free: profiles/r05_ab_dpp_combine_off.txt), tests/test_build_quality.py rejects any DPP instruction other
+    // than v_mov_b32_dpp in the shipped code objects, and a GPU test rebuilds a kernel unit on the box and re-runs the goldens.
     auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8]; };
-#endif
     const int32_t c2 = neg2 ? -C2 : C2;
     // 32-bit arithmetic (a value below vb q has a top limb below vb * 2^21.6, and the sum of |C| vb is at most 500: checked above):
     // one v_mul_hi_i32 and a shift on the GPU instead of a 64 x 32-bit product
@@ -430,7 +410,7 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
     const int64_t kq = ((int64_t)te * (int64_t)k::FE_MU24) >> 45;     // floor; kq <= floor(value/q), kq >= value/q - 2
     Fe r;
     int64_t carry = 0;
-#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM) && !defined(BN_NO_ASM_REDUCE)
+#if !defined(BN_HOSTSIM)
     // GPU: the 64-bit chain of a limb as ONE asm statement of v_mad_i64_i32 (carry - kq q_i + narrow sum + the wide terms), like the
     // multiplier leaves (fe_asm.hpp): the compiler otherwise builds it from sign extensions, 64-bit adds and - in some contexts -
     // v_mul_lo / v_mul_hi pairs.  Same arithmetic, limb for limb.
@@ -541,15 +521,15 @@ BN_FN Fe fe_std(const Fe &x) { return fe_lc3<1, 0, 0>(x, x, x); }       // any l
 // Value: result < (A*B/169.3 + 1) q, so A*B <= 169 gives < 2q.
 // On the GPU the three multiplier leaves below run the same arithmetic with every column's multiply-add chain as ONE inline-asm
 // statement (fe_asm.hpp, tools/gen_asm_leaf.py): the compiler otherwise splits each column sum into two chains and joins them with
-// a 64-bit add (16 v_lshl_add_u64 per product); +3.6 % pairings/s (profiles/r03_ab_asm_leaf.txt).  The host simulation - and
-// -DBN_NO_ASM_LEAF - use the C++ bodies, which also carry the bound checks.
-#if defined(BN_ASM_LEAF)
+// a 64-bit add (16 v_lshl_add_u64 per product); +3.6 % pairings/s (profiles/r03_ab_asm_leaf.txt).  The host simulation uses the C++
+// bodies, which also carry the bound checks.
+#if !defined(BN_HOSTSIM)
 }  // namespace bn254
 #include "fe_asm.hpp"
 namespace bn254 {
 #endif
 BN_FN Fe fe_mul_body(const Fe &a, const Fe &b) {
-#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+#if !defined(BN_HOSTSIM)
     return fe_mul_asm(a, b);
 #endif
     BN_COUNT(mul);
@@ -587,7 +567,7 @@ BN_LEAF2(fe_mul, fe_mul_body)
 // a*a / R: the 36 cross products a_i a_j (i < j) are taken once against the doubled limbs 2 a_j, so the product part is 45
 // instead of 81 mads (+ the same 81 of the reduction).  Same column sums as fe_mul(a, a), hence the same bounds.
 BN_FN Fe fe_sqr_body(const Fe &a) {
-#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+#if !defined(BN_HOSTSIM)
     return fe_sqr_asm(a);
 #endif
     BN_COUNT(mul);
@@ -630,7 +610,7 @@ BN_LEAF1M(fe_sqr, fe_sqr_body)
 
 // (a*u + c*v) / R with ONE reduction: 162 + 81 mads.   Column bound: la*lu + lc*lv <= 6; value: A*U + C*V <= 169.
 BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
-#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+#if !defined(BN_HOSTSIM)
     return fe_mul2_asm(a, u, c, v);
 #endif
     BN_COUNT(mul2);
@@ -677,7 +657,7 @@ BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
 // comes from the low 29 bits of the two's complement column as before.  The result is a SIGNED lazy value: limbs 0..7 in [0, 2^29), the
 // top limb carries the sign, |value| < ((A U + C V) / 169.3 + 1) q.  Only the fused reductions (fe_lc*) consume it.
 BN_FN Fe fe_mul2s(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
-#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+#if !defined(BN_HOSTSIM)
     return fe_mul2s_asm(a, u, c, v);
 #endif
     BN_COUNT(mul2);
@@ -723,7 +703,7 @@ BN_FN Fe fe_mul2s(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
 // Value: sum of the vb products <= 338 gives a result below 3q.
 BN_FN Fe fe_mul6(const Fe &a1, const Fe &u1, const Fe &c1, const Fe &v1, const Fe &a2, const Fe &u2, const Fe &c2, const Fe &v2,
                  const Fe &a3, const Fe &u3, const Fe &c3, const Fe &v3) {
-#if defined(BN_ASM_LEAF) && !defined(BN_HOSTSIM)
+#if !defined(BN_HOSTSIM)
     return fe_mul6_asm(a1, u1, c1, v1, a2, u2, c2, v2, a3, u3, c3, v3);
 #endif
     BN_COUNT(mul2); BN_COUNT(mul2); BN_COUNT(mul2);           // (counted as three dual products: the executed-chain figures stay comparable)

@@ -151,10 +151,10 @@ BN_FN bool lane_pair_all_zero(const Fe &a) { bool z = fe_is_zero(a); return z &&
 BN_FN bool lane_pair_all_zero_std(const Fe &a) { bool z = fe_is_zero_std(a); return z && lane_partner_flag(z); }
 // reduce(C1*x + s*C2*y + C3*z), s = -1 on even lanes, +1 on odd lanes
 template <int C1, int C2, int C3>
-BN_FN Fe fe_lc3_par_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3, BN_PAR_SIGN2>(x, y, z, !lane_is_odd()); }
+BN_FN Fe fe_lc3_par_body(const Fe &x, const Fe &y, const Fe &z) { return fe_lc3_core<C1, C2, C3, true>(x, y, z, !lane_is_odd()); }
 BN_LEAF3T(fe_lc3_par, fe_lc3_par_body)
 template <int C1, int C2, int C3, int C4>
-BN_FN Fe fe_lc4_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4, false, BN_PAR_SIGN2>(x, y, z, w, !lane_is_odd()); }
+BN_FN Fe fe_lc4_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4, false, true>(x, y, z, w, !lane_is_odd()); }
 template <int C1, int C2, int C3, int C4>      // all terms in the 64-bit chain (fe.hpp WIDE)
 BN_FN Fe fe_lc4w_par(const Fe &x, const Fe &y, const Fe &z, const Fe &w) { return fe_lc4_core<C1, C2, C3, C4, true>(x, y, z, w, !lane_is_odd()); }
 template <int C1, int C2, int C3>
@@ -193,7 +193,7 @@ BN_FN T f2b_muls_body(const T &a, const T &b) {
     T v = lane_pick(fe_sneg(pb), b);
     return fe_mul2s(a, u, pa, v);
 }
-#if !defined(BN_HOSTSIM) && !defined(BN_NO_EXEC_GLUE)
+#if !defined(BN_HOSTSIM)
 // The GPU's operand set-up for the two leaves above, nine instructions per role decision instead of eighteen: where only the EVEN lane
 // of a pair differs from the odd one, the difference is applied IN PLACE to a register the exchange just produced, with the odd lanes
 // switched off in EXEC for those instructions (one asm statement: save, mask, nine limbs, restore) - not computed in all lanes and then
@@ -201,26 +201,7 @@ BN_FN T f2b_muls_body(const T &a, const T &b) {
 //   product: this lane's component = a0 * (own b) + a1 * X,   a0 / a1 = the pair's components of a in BOTH lanes (quad_perm [0,0,2,2] /
 //            [1,1,3,3]),  X = the partner's b, negated on the even lane          (45 -> 36 instructions around the 243 multiply-adds)
 //   square:  S = own a doubled, T = the partner's a;  even lane: S = a + T, T = a - T  (63 -> 45 around the 162 multiply-adds)
-#ifdef BN_SWIZZLE_EXCHANGE       // experiment: the exchanges of the product set-up through the LDS crossbar (ds_swizzle, quad-permute mode) instead of DPP moves
-BN_FN Fe lane_dpp_even(const Fe &x) {
-    Fe r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x.l[i], 0x80A0);
-    return r;
-}
-BN_FN Fe lane_dpp_odd(const Fe &x) {
-    Fe r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x.l[i], 0x80F5);
-    return r;
-}
-BN_FN Fe lane_partner_x(const Fe &x) {
-    Fe r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x.l[i], 0x80B1);
-    return r;
-}
-#else
+// (the same exchanges through the LDS crossbar - ds_swizzle in quad-permute mode - measured 5 % slower: profiles/r04r_ab_swizzle_exchange.txt)
 BN_FN Fe lane_dpp_even(const Fe &x) {
     Fe r;
 #pragma unroll
@@ -234,7 +215,6 @@ BN_FN Fe lane_dpp_odd(const Fe &x) {
     return r;
 }
 BN_FN Fe lane_partner_x(const Fe &x) { return lane_partner(x); }
-#endif
 #define BN_EVEN_LANES 0x5555555555555555ull
 template <int LB, int K>
 BN_FN void fe_neg_on_even_lanes(Fe &x) {            // x <- fe_neg<LB, K>(x) on the even lanes, untouched on the odd ones
@@ -298,21 +278,12 @@ BN_LEAF_MUL u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_gpu(bn_
 BN_LEAF_MUL u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_gpu(bn_unv(a))); }
 BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a), bn_tov(b))); }
 BN_FN Fe f2b_sqr(const Fe &a) { return bn_unv(f2b_sqr_leaf(bn_tov(a))); }
-#elif defined(BN_HOSTSIM)
+#else
 template <class T> BN_FN T f2b_mul(const T &a, const T &b) { return f2b_mul_body(a, b); }
 template <class T> BN_FN T f2b_sqr(const T &a) { return f2b_sqr_body(a); }
 template <class T> BN_FN T f2b_mul_inl(const T &a, const T &b) { return f2b_mul_body(a, b); }
 template <class T> BN_FN T f2b_sqr_inl(const T &a) { return f2b_sqr_body(a); }
 template <class T> BN_FN T f2b_muls(const T &a, const T &b) { return f2b_muls_body(a, b); }
-#else
-template <class T> BN_FN T f2b_mul_inl(const T &a, const T &b) { return f2b_mul_body(a, b); }
-template <class T> BN_FN T f2b_sqr_inl(const T &a) { return f2b_sqr_body(a); }
-BN_LEAF_MUL u32x9 f2b_muls_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_muls_body(bn_unv(a), bn_unv(b))); }
-BN_FN Fe f2b_muls(const Fe &a, const Fe &b) { return bn_unv(f2b_muls_leaf(bn_tov(a), bn_tov(b))); }
-BN_LEAF_MUL u32x9 f2b_mul_leaf(u32x9 a, u32x9 b) { return bn_tov(f2b_mul_body(bn_unv(a), bn_unv(b))); }
-BN_LEAF_MUL u32x9 f2b_sqr_leaf(u32x9 a) { return bn_tov(f2b_sqr_body(bn_unv(a))); }
-BN_FN Fe f2b_mul(const Fe &a, const Fe &b) { return bn_unv(f2b_mul_leaf(bn_tov(a), bn_tov(b))); }
-BN_FN Fe f2b_sqr(const Fe &a) { return bn_unv(f2b_sqr_leaf(bn_tov(a))); }
 #endif
 
 // A multiplier PREPARED for the lane-pair product: (u, v) such that this lane's component of a * b is own_a * u + partner_a * v.  With
@@ -325,7 +296,7 @@ BN_FN Fq2BPrep<T> f2b_prepare(const Fq2B<T> &b) {
     const T pb = lane_partner(b.v);
     return {lane_pick(b.v, pb), lane_pick(fe_norm(fe_neg<1, 9>(pb)), b.v)};
 }
-#if !defined(BN_HOSTSIM) && !defined(BN_NO_EXEC_GLUE)
+#if !defined(BN_HOSTSIM)
 // the GPU's set-up (same limbs): b0 and b1 by quad_perm broadcasts, the even lane's negation in place under the EXEC mask, ONE carry
 // propagation over all lanes (the odd lane's b1 is normalized already and passes through unchanged): 54 instead of 63 instructions
 BN_FN Fq2BPrep<Fe> f2b_prepare(const Fq2B<Fe> &b) {
@@ -365,14 +336,10 @@ template <class T> BN_FN Fq2B<T> f2_select(bool take_b, const Fq2B<T> &a, const 
 template <class T> BN_FN Fq2B<T> f2_mul(const Fq2B<T> &a, const Fq2B<T> &b) { return {f2b_mul(a.v, b.v)}; }
 // Karatsuba: a_i b_j + a_j b_i = (a_i - a_j)(b_j - b_i) + a_i b_i + a_j b_j, as a signed lazy sum (limb bound 3).  The differences of
 // normalized operands are signed values of limb magnitude below 2^29 and go into the signed dual product as they are, where the sums
-// (a_i + a_j)(b_i + b_j) cost a carry propagation each (27 instructions: -DBN_NO_SIGNED_KARATSUBA restores them).
+// (a_i + a_j)(b_i + b_j) cost a carry propagation each (27 instructions; profiles/r04n_ab_signed_karatsuba.txt).
 template <class T>
 BN_FN Fq2B<T> f2_cross(const Fq2B<T> &ai, const Fq2B<T> &aj, const Fq2B<T> &bi, const Fq2B<T> &bj, const Fq2B<T> &pii, const Fq2B<T> &pjj) {
-#ifdef BN_NO_SIGNED_KARATSUBA
-    return f2_ssub(f2_ssub(f2_mul(f2_add(ai, aj), f2_norm(f2_add(bi, bj))), pii), pjj);
-#else
     return f2_add(f2_add(f2_muls(f2_sdiff(ai, aj), f2_sdiff(bj, bi)), pii), pjj);
-#endif
 }
 template <class T> BN_FN Fq2B<T> f2_sqr(const Fq2B<T> &a) { return {f2b_sqr(a.v)}; }
 template <class T> BN_FN Fq2B<T> f2_scale(const Fq2B<T> &a, const T &s) { return {fe_mul(a.v, s)}; }

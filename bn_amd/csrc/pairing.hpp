@@ -23,21 +23,13 @@ template <class F2> struct Line { F2 ell_0, ell_vw, ell_vv; };  // ell_vw / ell_
 // mapped by (x, y) -> (t^2 x, t^3 y) first): the reduced pairing is invariant under the isomorphism, the Miller value is not.
 template <bool ISO = false, class F2>
 BN_COARSE Line<F2> doubling_step(G2Proj<F2> &r) {
-#ifdef BN_NO_HALF      // experiment switch: the reference's products by 2^-1
-    F2 a = f2_scale(f2_mul(r.x, r.y), f2_scalar_const(F2P, k::TWO_INV));
-#else
-    F2 a = f2_half(f2_mul(r.x, r.y));                                    // x y / 2 by a shift, not a product (fe_half)
-#endif
+    F2 a = f2_half(f2_mul(r.x, r.y));                                    // x y / 2 by a shift, not a product (fe_half; profiles/r02h_ab_half_vs_scale.txt)
     F2 b = f2_sqr(r.y), c = f2_sqr(r.z);
     F2 e;
     if constexpr (ISO) e = f2_mul_iso3b(c);
     else e = f2_mul_const(c, k::G2_3B);
     F2 f3 = f2_add(f2_add(e, e), e);                                     // f = 3e, lazy
-#ifdef BN_NO_HALF
-    F2 g = f2_scale(f2_add(b, f3), f2_scalar_const(F2P, k::TWO_INV));
-#else
     F2 g = f2_half_for_sqr(f2_add(b, f3));                               // (b + f)/2
-#endif
     F2 h = f2_lc3<1, -1, -1>(f2_sqr(f2_sum_for_mul(r.y, r.z)), b, c);
     F2 j = f2_sqr(r.x), e_sq = f2_sqr(e);
     Line<F2> l;
@@ -92,10 +84,6 @@ struct MillerStateVars {
     BN_FN G2Aff<F2> get_base() const { return base_; }
     BN_FN void put_p(const G1Aff<S> &v) { p_ = v; }
     BN_FN G1Aff<S> get_p() const { return p_; }
-    // three Fq2 values kept while the running point is in registers (the LDS store reuses R's slots for them)
-    F2 line_[3];
-    BN_FN void park_line(const F2 &a, const F2 &b, const F2 &c) { line_[0] = a; line_[1] = b; line_[2] = c; }
-    BN_FN void unpark_line(F2 &a, F2 &b, F2 &c) const { a = line_[0]; b = line_[1]; c = line_[2]; }
 };
 
 // groups/mod.rs:486-519 fused with :557-588.  The schedule (6u+2 with the top bit skipped: 64 doublings, an addition of Q
@@ -111,13 +99,11 @@ BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, St
     {
         G1Aff<S> p = p_in;
         G2Aff<F2> q = q_in;
-#ifndef BN_NO_ISO
-        if constexpr (NAF) {             // onto the isomorphic curve: (x, y) -> (t^2 x, t^3 y) for both points
+        if constexpr (NAF) {             // onto the isomorphic curve: (x, y) -> (t^2 x, t^3 y) for both points (profiles/r02i_ab_isomorphic_curve.txt)
             const S t2 = f2_scalar_const(F2P, k::ISO_T2), t3 = f2_scalar_const(F2P, k::ISO_T3);
             p = {fe_mul(p.x, t2), fe_mul(p.y, t3)};
             q = {f2_scale(q.x, t2), f2_scale(q.y, t3)};
         }
-#endif
         G2Proj<F2> r0 = {q.x, q.y, f2_one(F2P)};
         st.put_r(r0);
         st.put_base(q);
@@ -143,11 +129,7 @@ BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, St
                 if (j != 0) f = f12_sqr(f);                                         // f == 1 in the first step
                 BN_COMPILER_FENCE();                                                // R is fetched AFTER the squaring
                 G2Proj<F2> r = st.get_r();
-#ifndef BN_NO_ISO
                 l = doubling_step<NAF>(r);
-#else
-                l = doubling_step<false>(r);
-#endif
                 st.put_r(r);
             } else {
                 G2Proj<F2> r = st.get_r();
@@ -163,73 +145,9 @@ BN_FN Fq12<F2> miller_loop_sched(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, St
     }
     return f;
 }
-// The NAF schedule with the two lines of a step that adds +-Q multiplied together BEFORE they meet f:
-//     f <- f^2 * l_dbl * l_add  =  f^2 * (l_dbl l_add):   6 (line x line) + 17 (f x five-slot element) instead of 13 + 13 Fq2 products
-// on the 21 steps with a non-zero digit.  The doubling line waits in the store while the addition step runs (in the LDS store it
-// takes R's slots: R is in registers then).  Same value as miller_loop_sched<true> up to the order of Fq12 products, i.e. identical.
-// MEASURED SLOWER and therefore off by default (-DBN_MILLER_MERGE_LINES): 2.4 % fewer multiply-adds, but f (54 VGPRs) must wait in
-// registers through the addition step AND the line product, the allocator spills ~100 VGPRs of it (3 without the merge), and the
-// Miller kernel runs 3.98 -> 4.07 ms (profiles/r02x_ab_merge_lines.txt).  LDS has 17 spare dwords per lane, a half of f is 27.
-template <class F2, class S, class Store>
-BN_FN Fq12<F2> miller_loop_naf_merged(const G1Aff<S> &p_in, const G2Aff<F2> &q_in, Store &st) {
-    {
-        const S t2 = f2_scalar_const(F2P, k::ISO_T2), t3 = f2_scalar_const(F2P, k::ISO_T3);      // isomorphic curve (doubling_step<true>)
-        G1Aff<S> p = {fe_mul(p_in.x, t2), fe_mul(p_in.y, t3)};
-        G2Aff<F2> q = {f2_scale(q_in.x, t2), f2_scale(q_in.y, t3)};
-        G2Proj<F2> r0 = {q.x, q.y, f2_one(F2P)};
-        st.put_r(r0);
-        st.put_base(q);
-        st.put_p(p);
-    }
-    Fq12<F2> f = f12_one<F2>();
-    constexpr int ND = k::ATE_NAF_LEN - 1;
-#pragma unroll 1
-    for (int j = 0; j < ND; ++j) {
-        const int digit = k::ATE_NAF[ND - 1 - j];
-        BN_MILLER_HOOK(2 * j, 2 * (ND + 2));
-        if (j != 0) f = f12_sqr(f);
-        BN_COMPILER_FENCE();
-        G2Proj<F2> r = st.get_r();
-        F2 x0, x4, x2;
-        {
-            Line<F2> l = doubling_step<true>(r);
-            const G1Aff<S> pp = st.get_p();
-            x0 = l.ell_0; x4 = f2_scale(l.ell_vw, pp.y); x2 = f2_scale(l.ell_vv, pp.x);
-        }
-        if (digit == 0) {
-            st.put_r(r);
-            f = f12_mul_by_024(f, x0, x4, x2);
-        } else {
-            BN_MILLER_HOOK(2 * j + 1, 2 * (ND + 2));
-            st.park_line(x0, x4, x2);                                // the doubling line waits in R's slots (R is in registers now)
-            G2Aff<F2> b = st.get_base();
-            if (digit < 0) b.y = f2_neg(b.y);
-            F2 y0, y4, y2;
-            {
-                Line<F2> l = addition_step(r, b);
-                const G1Aff<S> pp = st.get_p();
-                y0 = l.ell_0; y4 = f2_scale(l.ell_vw, pp.y); y2 = f2_scale(l.ell_vv, pp.x);
-            }
-            st.unpark_line(x0, x4, x2);
-            st.put_r(r);
-            const LinePair<F2> lp = f12_line_product(x0, x4, x2, y0, y4, y2);
-            f = f12_mul_by_01234(f, lp);
-        }
-    }
-    // the two additions of pi(Q) and -pi^2(Q) (groups/mod.rs:578-582), one line at a time
-#pragma unroll 1
-    for (int j = ND; j < ND + 2; ++j) {
-        BN_MILLER_HOOK(2 * j + 1, 2 * (ND + 2));
-        G2Aff<F2> b = mul_by_q(st.get_base());
-        if (j == ND + 1) b.y = f2_neg(b.y);
-        st.put_base(b);
-        G2Proj<F2> r = st.get_r();
-        Line<F2> l = addition_step(r, b);
-        st.put_r(r);
-        f = apply_line(f, l, st.get_p());
-    }
-    return f;
-}
+// (Multiplying the two lines of a step that adds +-Q together BEFORE they meet f - 6 + 17 instead of 13 + 13 Fq2 products on 21 of the 88
+// steps, 2.4 % fewer multiply-adds - was implemented, bit-identical and measured 2 % SLOWER: f has to wait in registers through the addition
+// step and the line product, and the allocator spills ~100 VGPRs of it.  profiles/r02x_ab_merge_lines.txt; the code left with round 5.)
 // The multi-pairing's Miller loop with a SHARED accumulator: prod_i f_i = the f of  f <- f^2 * prod_i l_i(P_i)  (a product of Miller
 // values only ever meets one final exponentiation: shootout/main.rs:11-16), so M pairs on one lane pair pay ONE f^2 per doubling
 // step - 12 of the 33 Fq2 products of a step and pair - instead of M.  The price: the running points, the points being added and the

@@ -37,7 +37,6 @@ template <class F2> BN_FN Fq6<F2> f6_mul_by_v(const Fq6<F2> &a) { return {f2_mul
 // coefficient is finished as soon as its products exist (short live ranges: see f12_mul_by_024)
 template <class F2>
 BN_COARSE Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
-    BN_FAIR_TICK();
     F2 aa = f2_mul(a.c0, b.c0), bb = f2_mul(a.c1, b.c1), cc = f2_mul(a.c2, b.c2);
     Fq6<F2> r;
     r.c0 = f2_lc_xi<1, 1>(f2_cross(a.c1, a.c2, b.c1, b.c2, bb, cc), aa);          // xi (a1 b2 + a2 b1) + a0 b0
@@ -48,12 +47,11 @@ BN_COARSE Fq6<F2> f6_mul(const Fq6<F2> &a, const Fq6<F2> &b) {
 // The six Karatsuba products of f6_mul WITHOUT their recombination: a caller that subtracts or adds further Fq6 values right away
 // (the cross term of an Fq12 product or square) folds everything into ONE fused reduction per coefficient (f2_lc_xi2w / f2_lc3sw) instead
 // of three reductions here and three more there (round 4: Miller 3.806 -> 3.765 ms, final exponentiation 3.357 -> 3.341 ms, Gt::pow + 2.3 %;
-// profiles/r04g_ab_merged_recombination.txt; -DBN_NO_MERGED_RECOMB restores the two-level form).
+// profiles/r04g_ab_merged_recombination.txt).
 //   a b = (xi x12 + v0) + (xi v2 + x01) v + (x02 + v1) v^2,   x_ij = a_i b_j + a_j b_i (f2_cross: signed lazy sums, limb bound 3)
 template <class F2> struct Fq6Raw { F2 v0, v1, v2, x12, x01, x02; };
 template <class F2>
 BN_COARSE Fq6Raw<F2> f6_mul_raw(const Fq6<F2> &a, const Fq6<F2> &b) {
-    BN_FAIR_TICK();
     Fq6Raw<F2> r;
     r.v0 = f2_mul(a.c0, b.c0); r.v1 = f2_mul(a.c1, b.c1); r.v2 = f2_mul(a.c2, b.c2);
     r.x12 = f2_cross(a.c1, a.c2, b.c1, b.c2, r.v1, r.v2);
@@ -110,7 +108,6 @@ BN_FN Fq12<F2> f12_mul_src(const Fq12<F2> &a, const BSrc &b, bool conj_b) {
     // the Karatsuba cross term first: it is the only product that needs both halves of a and of b at once
     Fq6<F2> b1 = b.c1();
     if (conj_b) b1 = f6_neg(b1);
-#ifndef BN_NO_MERGED_RECOMB
     const Fq6Raw<F2> t = f6_mul_raw(f6_add_norm(a.c0, a.c1), f6_add_norm(b.c0(), b1));
     Fq6<F2> bb = f6_mul(a.c1, b1);
     Fq6<F2> aa = f6_mul(a.c0, b.c0());
@@ -119,13 +116,6 @@ BN_FN Fq12<F2> f12_mul_src(const Fq12<F2> &a, const BSrc &b, bool conj_b) {
     r.c1.c0 = f2_lc_xi2w<1, 1, -1>(t.x12, f2_ssub(t.v0, aa.c0), bb.c0);
     r.c1.c1 = f2_lc_xi2w<1, 1, -1>(t.v2, t.x01, f2_add(aa.c1, bb.c1));
     r.c1.c2 = f2_lc3sw<1, -1, 0>(f2_add(t.x02, t.v1), f2_add(aa.c2, bb.c2), aa.c2);
-#else
-    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), f6_add_norm(b.c0(), b1));
-    Fq6<F2> bb = f6_mul(a.c1, b1);
-    Fq6<F2> aa = f6_mul(a.c0, b.c0());
-    Fq12<F2> r;
-    r.c1 = f6_lc3<1, -1, -1>(t, aa, bb);
-#endif
     r.c0.c0 = f2_lc_xi<1, 1>(bb.c2, aa.c0);                  // aa + v*bb
     r.c0.c1 = f2_lc3<1, 1, 0>(aa.c1, bb.c0, bb.c0);
     r.c0.c2 = f2_lc3<1, 1, 0>(aa.c2, bb.c1, bb.c1);
@@ -146,18 +136,11 @@ BN_COARSE Fq12<F2> f12_sqr(const Fq12<F2> &a) {
     u.c1 = f2_sum_for_mul(a.c1.c0, a.c0.c1);
     u.c2 = f2_sum_for_mul(a.c1.c1, a.c0.c2);
     Fq12<F2> r;
-#ifndef BN_NO_MERGED_RECOMB
     // t - ab - v ab with the recombination of t = (c0 + c1) u folded in: three reductions instead of six
     const Fq6Raw<F2> t = f6_mul_raw(f6_add_norm(a.c0, a.c1), u);
     r.c0.c0 = f2_lc_xi2w<1, 1, -1>(f2_ssub(t.x12, ab.c2), t.v0, ab.c0);
     r.c0.c1 = f2_lc_xi2w<1, 1, -1>(t.v2, t.x01, f2_add(ab.c1, ab.c0));
     r.c0.c2 = f2_lc3sw<1, -1, 0>(f2_add(t.x02, t.v1), f2_add(ab.c2, ab.c1), ab.c1);
-#else
-    Fq6<F2> t = f6_mul(f6_add_norm(a.c0, a.c1), u);
-    r.c0.c0 = f2_lc_xi<-1, 1>(ab.c2, f2_ssub(t.c0, ab.c0));      // t - ab - v*ab
-    r.c0.c1 = f2_lc3<1, -1, -1>(t.c1, ab.c1, ab.c0);
-    r.c0.c2 = f2_lc3<1, -1, -1>(t.c2, ab.c2, ab.c1);
-#endif
     if constexpr (REDUCED_C1) r.c1 = f6_lc3<2, 0, 0>(ab, ab, ab);
     else r.c1 = f6_add_norm(ab, ab);                           // 2ab as a plain sum (carries propagated)
     return r;
@@ -210,34 +193,6 @@ BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &
     const F2 &z0 = f.c0.c0, &z1 = f.c0.c1, &z2 = f.c0.c2, &z3 = f.c1.c0, &z4 = f.c1.c1, &z5 = f.c1.c2;
     const F2 &x0 = ell_0, &x2 = ell_vv, &x4 = ell_vw;
     Fq12<F2> r;
-#ifdef BN_MUL024_OLD_ORDER
-    F2 d0 = f2_mul(z0, x0), d4 = f2_mul(z4, x4);
-    F2 s1 = f2_mul(z1, x2);                                              // running sum of the six cross products (lazy)
-    r.c0.c0 = f2_lc_xi<1, 1>(f2_add(s1, d4), d0);                        // xi (z1 x2 + z4 x4) + z0 x0
-    F2 d2 = f2_mul(z2, x2);
-    {
-        F2 z5x4 = f2_mul(z5, x4), z1x0 = f2_mul(z1, x0);
-        r.c0.c1 = f2_lc_xi<1, 1>(f2_add(z5x4, d2), z1x0);                // xi (z5 x4 + z2 x2) + z1 x0
-        s1 = f2_add(f2_add(s1, z5x4), z1x0);
-    }
-    {
-        F2 m02 = f2_mul(f2_add(z0, z2), f2_norm(f2_add(x0, x2))), z3x4 = f2_mul(z3, x4);
-        r.c0.c2 = f2_lc3<1, -1, -1>(f2_add(m02, z3x4), d0, d2);          // (z0+z2)(x0+x2) - d0 - d2 + z3 x4
-        s1 = f2_add(s1, z3x4);
-    }
-    {
-        F2 m24 = f2_mul(f2_add(z2, z4), f2_norm(f2_add(x2, x4))), z3x0 = f2_mul(z3, x0);
-        r.c1.c0 = f2_lc_xi<1, 1>(f2_ssub(f2_ssub(m24, d2), d4), z3x0);   // xi ((z2+z4)(x2+x4) - d2 - d4) + z3 x0
-        s1 = f2_add(s1, z3x0);
-    }
-    {
-        F2 z5x2 = f2_mul(z5, x2), m04 = f2_mul(f2_add(z0, z4), f2_norm(f2_add(x0, x4)));
-        r.c1.c1 = f2_lc_xi<1, 1>(z5x2, f2_ssub(f2_ssub(m04, d0), d4));   // xi z5 x2 + (z0+z4)(x0+x4) - d0 - d4
-        s1 = f2_add(s1, z5x2);
-    }
-    F2 ms = f2_mul(f2_sum3_for_mul(z1, z3, z5), f2_sum3_for_mul(x0, x2, x4));
-    r.c1.c2 = f2_lc3w<1, -1, 0>(ms, s1, s1);                              // (z1+z3+z5)(x0+x2+x4) - s1
-#else
     // Register-pressure order (the spills of this function cost the Miller loop ~10 %, profiles/r02k_*): the four Karatsuba sums
     // of f's coefficients are formed FIRST, so that every z_i dies right after its own products instead of living to the end;
     // peak ~17 nine-register values instead of ~21.
@@ -282,11 +237,9 @@ BN_COARSE Fq12<F2> f12_mul_by_024(const Fq12<F2> &f, const F2 &ell_0, const F2 &
     BN_COMPILER_FENCE();
     F2 ms = f2_mul(z135, f2_sum3_for_mul(x0, x2, x4));
     r.c1.c2 = f2_lc3w<1, -1, 0>(ms, s1, s1);                                          // (z1+z3+z5)(x0+x2+x4) - s1
-#endif
     return r;
 }
 
-#if !defined(BN_NO_LAZY_SPARSE)
 // The same product in the lane-pair mapping by LAZY REDUCTION instead of Karatsuba: each of the six output coefficients is a sum of three
 // Fq2 products,
 //     c0' = (z0 x0 + xi z1 x2 + xi z4 x4) + (z1 x0 + xi z2 x2 + xi z5 x4) v + (z2 x0 + z0 x2 + z3 x4) v^2
@@ -317,66 +270,6 @@ BN_COARSE Fq12<Fq2B<T>> f12_mul_by_024(const Fq12<Fq2B<T>> &f, const Fq2B<T> &el
         r.c0.c2 = f2b_mul3(z2, x0, z0, x2, z3, x4);
         r.c1.c2 = f2b_mul3(z5, x0, z3, x2, z1, x4);
     }
-    return r;
-}
-#endif
-
-// The product of TWO line elements, each with non-zero Fq2 slots 0, 2, 4 (a0 + a2 v^2 + a4 v w): five non-zero slots, the v^2 w
-// slot is empty.  6 Fq2 products (Karatsuba over the three coefficient pairs):
-//   at 1: a0 b0 + xi a4 b4 | at v: xi a2 b2 | at v^2: a0 b2 + a2 b0 | at w: xi (a2 b4 + a4 b2) | at v w: a0 b4 + a4 b0
-// Used by the NAF Miller loop on the steps that add Q: f * l_dbl * l_add = f * (l_dbl l_add) costs 6 + 17 instead of 13 + 13.
-template <class F2> struct LinePair { F2 s0, s1, s2, s3, s4; };      // coefficients of 1, v, v^2, w, v w
-template <class F2>
-BN_COARSE LinePair<F2> f12_line_product(const F2 &a0, const F2 &a4, const F2 &a2, const F2 &b0, const F2 &b4, const F2 &b2) {
-    // argument order (x0, x4, x2) = (ell_0, ell_vw * yP, ell_vv * xP), as f12_mul_by_024 takes them.
-    // Ordered for register pressure (f waits in registers meanwhile): sums first, then the inputs die with their own products.
-    LinePair<F2> r;
-    const F2 a02 = f2_add(a0, a2), a04 = f2_add(a0, a4), a24 = f2_add(a2, a4);
-    const F2 b02 = f2_norm(f2_add(b0, b2)), b04 = f2_norm(f2_add(b0, b4)), b24 = f2_norm(f2_add(b2, b4));
-    BN_COMPILER_FENCE();
-    const F2 d0 = f2_mul(a0, b0), d2 = f2_mul(a2, b2), d4 = f2_mul(a4, b4);
-    BN_COMPILER_FENCE();
-    r.s0 = f2_lc_xi<1, 1>(d4, d0);
-    r.s1 = f2_mul_xi(d2);
-    r.s2 = f2_lc3<1, -1, -1>(f2_mul(a02, b02), d0, d2);
-    BN_COMPILER_FENCE();
-    r.s4 = f2_lc3<1, -1, -1>(f2_mul(a04, b04), d0, d4);
-    BN_COMPILER_FENCE();
-    r.s3 = f2_mul_xi(f2_ssub(f2_ssub(f2_mul(a24, b24), d2), d4));
-    return r;
-}
-// (b0 + b1 v) * a in Fq6: 5 Fq2 products
-template <class F2>
-BN_COARSE Fq6<F2> f6_mul_by_01(const Fq6<F2> &a, const F2 &b0, const F2 &b1) {
-    F2 p00 = f2_mul(a.c0, b0), p11 = f2_mul(a.c1, b1);
-    F2 pk = f2_mul(f2_add(a.c0, a.c1), f2_norm(f2_add(b0, b1)));
-    Fq6<F2> r;
-    r.c1 = f2_lc3<1, -1, -1>(pk, p00, p11);                              // a0 b1 + a1 b0
-    {
-        F2 p21 = f2_mul(a.c2, b1);
-        r.c0 = f2_lc_xi<1, 1>(p21, p00);                                 // a0 b0 + xi a2 b1
-    }
-    F2 p20 = f2_mul(a.c2, b0);
-    r.c2 = f2_lc3<1, 1, 0>(p11, p20, p20);                               // a1 b1 + a2 b0
-    return r;
-}
-// f * L for L = (s0 + s1 v + s2 v^2) + (s3 + s4 v) w: Karatsuba over Fq6 with a dense (6), a two-term (5) and a dense (6) product
-template <class F2>
-BN_COARSE Fq12<F2> f12_mul_by_01234(const Fq12<F2> &f, const LinePair<F2> &l) {
-    // ordered for register pressure: both Karatsuba sums first (then f.c0 dies with aa, f.c1 with bb), the cross product last
-    const Fq6<F2> sa = f6_add_norm(f.c0, f.c1);
-    const F2 sb0 = f2_sum_for_mul(l.s0, l.s3), sb1 = f2_sum_for_mul(l.s1, l.s4);
-    BN_COMPILER_FENCE();
-    Fq6<F2> aa = f6_mul(f.c0, Fq6<F2>{l.s0, l.s1, l.s2});
-    BN_COMPILER_FENCE();
-    Fq6<F2> bb = f6_mul_by_01(f.c1, l.s3, l.s4);
-    BN_COMPILER_FENCE();
-    Fq6<F2> t = f6_mul(sa, Fq6<F2>{sb0, sb1, l.s2});
-    Fq12<F2> r;
-    r.c1 = f6_lc3<1, -1, -1>(t, aa, bb);
-    r.c0.c0 = f2_lc_xi<1, 1>(bb.c2, aa.c0);                  // aa + v*bb
-    r.c0.c1 = f2_lc3<1, 1, 0>(aa.c1, bb.c0, bb.c0);
-    r.c0.c2 = f2_lc3<1, 1, 0>(aa.c2, bb.c1, bb.c1);
     return r;
 }
 

@@ -60,18 +60,27 @@ class Engine:
         eng = self
 
         class _Scope:
+            def _restore(self_):
+                for k, raw in self_.saved.items():
+                    eng.set_option(k, raw)
+
             def __enter__(self_):
-                self_.old = {k: eng.get_option(k) for k in kw}
-                self_.dflt = {}
-                for k in kw:                       # is the current value the default?  (set -1, read, compare)
-                    eng.set_option(k, None); self_.dflt[k] = eng.get_option(k) == self_.old[k]
-                for k, v in kw.items():
-                    eng.set_option(k, v)
+                self_.saved = {}                   # name -> the RAW state to return to: None = default, else the explicit value
+                try:
+                    for k in kw:                   # is the current value the default?  (read, set -1, read, compare, put it back)
+                        old = eng.get_option(k); eng.set_option(k, None)
+                        raw = None if eng.get_option(k) == old else old
+                        self_.saved[k] = raw
+                        eng.set_option(k, raw)
+                    for k, v in kw.items():
+                        eng.set_option(k, v)
+                except Exception:                  # a rejected value (BN254_E_BAD_ARG) must not leave the context half-configured
+                    self_._restore()
+                    raise
                 return eng
 
             def __exit__(self_, *exc):
-                for k in kw:
-                    eng.set_option(k, None if self_.dflt[k] else self_.old[k])
+                self_._restore()
                 return False
         return _Scope()
 
@@ -273,10 +282,11 @@ class Engine:
         _native.check(self._lib.bn254_tile_dev(self._h, d_record, record_bytes, n, d_out, stream))
 
     # ---- measurement
-    def ubench_mac32(self, waves_per_simd=8, iters=1 << 15):
-        """(G lane-MAC32 per second of a pure v_mad_u64_u32 stream, kernel ms) - the same-run `roofline.peak` of bench.py"""
+    def ubench_mac32(self, waves_per_simd=8, iters=1 << 15, operand_bits=32):
+        """(G lane-MAC32 per second of a pure v_mad_u64_u32 stream, kernel ms) - the same-run `roofline.peak` of bench.py;
+        operand_bits = 29: on the engine's own limbs (the multiplier's rate depends on its data)"""
         g = C.c_double(); ms = C.c_double()
-        _native.check(self._lib.bn254_ubench_mac32(self._h, int(waves_per_simd), int(iters), C.byref(g), C.byref(ms)))
+        _native.check(self._lib.bn254_ubench_mac32_ex(self._h, int(waves_per_simd), int(iters), int(operand_bits), C.byref(g), C.byref(ms)))
         return g.value, ms.value
 
     def wave_ubench(self, which, iters=200):

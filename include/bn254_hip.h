@@ -97,7 +97,10 @@ int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping);
 /* ---- tunables ---------------------------------------------------------------------------------------------------------
    Every policy of the host side is a per-context option whose default is derived from the device the context is bound to (its
    compute-unit count, `CUs` below); the call paths read nothing from the environment.  value < 0 restores the default;
-   bn254_ctx_get_option reports the EFFECTIVE value.  ctx == NULL addresses the default context of the current device.  An option
+   bn254_ctx_get_option reports the EFFECTIVE value - or -1 for the four options whose default is decided PER CALL from the batch
+   size (BN254_OPT_PRODUCT_CHUNK / _PER_WAVE / _BFLY, BN254_OPT_PIPELINE_CHUNK) while none is set explicitly.  The size options
+   (BN254_OPT_WAVE_PAIRING_MAX, _WAVE_FE_MAX, _QUAD_MAX, _ROUND_PAIRS, _PIPELINE_CHUNK) accept at most 2^22: what one launch addresses
+   with 32-bit offsets; a value above is rejected with BN254_E_BAD_ARG (larger batches are cut into sub-launches regardless).  ctx == NULL addresses the default context of the current device.  An option
    may be changed at any time; a call in flight may see the old or the new value between two of its launches - harmless, because
    every option selects between kernels that return the same bytes (the one exception is stated at BN254_OPT_GT_POW_MODE).
    For experiments only, the variables BN254_WAVE_PAIRING_MAX, BN254_WAVE_FE_MAX, BN254_QUAD_MAX, BN254_MILLER_SHARED, BN254_GT_POW_MODE,
@@ -128,7 +131,8 @@ enum {
     BN254_OPT_PIPELINE_SLOTS = 11,  /* chunks in flight, 1..4.  Default 2: the number of streams the GPU overlaps without loss */
     BN254_OPT_STREAM_STOP_AT_ERROR = 12, /* bn254_g{1,2}_decode_stream: 1 = the crate's own behaviour - its Decodable returns Err at the first bad
                                        record (groups/mod.rs:165-175) -: `count` ends WITH the first record whose status is non-zero and
-                                       `consumed` behind it; 0 (default): decode every record, report every status */
+                                       `consumed` behind it (out[] and status[] beyond `count` are unspecified: the batch decoder has
+                                       already run over the records that follow); 0 (default): decode every record, report every status */
     BN254_OPT_COUNT_ = 13
 };
 int bn254_ctx_set_option(bn254_ctx *ctx, int key, long value);
@@ -181,7 +185,7 @@ int bn254_multi_device_count(const bn254_multi *m);
 int bn254_multi_exchange_kind(const bn254_multi *m);                 /* BN254_EXCHANGE_* */
 /* The host thread that drives a rank (its pageable H2D / D2H copies and launches) is pinned, for the duration of a call, to the CPUs
    of that GPU's NUMA node when the node is known (/sys/bus/pci/devices/<bus id>/numa_node) and the process may run there; the
-   caller's own thread gets its mask back.  Returns that node, or -1 when the rank's thread is not pinned. */
+   caller's own thread is never re-pinned (every rank runs on a worker thread of the call).  Returns that node, or -1 when the rank's thread is not pinned. */
 int bn254_multi_rank_numa_node(const bn254_multi *m, int rank);
 bn254_ctx *bn254_multi_ctx(bn254_multi *m, int rank);                /* rank's context (owned by m) */
 /* out[i] = pairing(p[i], q[i]); rank g owns the contiguous shard [n*g/G, n*(g+1)/G); no exchange (BASELINE configs[2]) */
@@ -264,6 +268,9 @@ int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uin
    `waves_per_simd` resident waves: G lane-MACs per second over the whole chip and the kernel's duration.  bench.py prints it
    as the same-run `roofline.peak`. */
 int bn254_ubench_mac32(bn254_ctx *ctx, int waves_per_simd, int iters, double *gmac_per_s, double *ms);
+/* the same on operands of `operand_bits` random bits (1..32): the multiplier's rate depends on its data (profiles/r04_ubench_mad_data_dependence.txt);
+   29 = the engine's own limbs, which is what bench.py prices `roofline.peak_at_kernel_occupancy` with */
+int bn254_ubench_mac32_ex(bn254_ctx *ctx, int waves_per_simd, int iters, int operand_bits, double *gmac_per_s, double *ms);
 /* d_out[i] = d_in[i].exp_by_neg_z() as the reference writes it (fields/fq12.rs:229-246), for ANY Fq12: the one function of the path
    whose known answer (fields/mod.rs:171-201) lies OFF the cyclotomic subgroup, where the result depends on the operation sequence.
    The engine's own exponentiation by u (shorter signed-digit chain, equal on every value a pairing produces) is not reachable with

@@ -210,17 +210,6 @@ EXPORT void hsb_pairing_naf(const uint32_t *g1, const uint32_t *g2, uint32_t *o)
     if (inf) f = f12_one<F2B>();
     f12_store(f, o);
 }
-// the NAF loop with the two lines of an addition step multiplied together first (miller_loop_naf_merged)
-EXPORT void hsb_pairing_naf_merged(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
-    bool inf = words_all_zero(g1 + 16, 8) || words_all_zero(g2 + 32, 16);
-    G1Aff<FeP> p; G2Aff<F2B> q;
-    pair_prologue<FeP>(f2_scalar_load((F2B *)0, g1), f2_scalar_load((F2B *)0, g1 + 8), f2_scalar_load((F2B *)0, g1 + 16),
-                       f2_load((F2B *)0, g2), f2_load((F2B *)0, g2 + 16), f2_load((F2B *)0, g2 + 32), p, q);
-    MillerStateVars<F2B, FeP> st;
-    Fq12<F2B> f = final_exponentiation(miller_loop_naf_merged(p, q, st));
-    if (inf) f = f12_one<F2B>();
-    f12_store(f, o);
-}
 // Gt::pow through the windowed chain of bn254_gt_pow_B (lane-pair mapping)
 EXPORT void hsb_gt_pow(const uint32_t *a, const uint32_t *k, uint32_t *o) {
     uint32_t raw[8];

@@ -29,11 +29,11 @@ template <int C1, int C2, int C3>
 BN_FN FeP fe_lc3(const FeP &x, const FeP &y, const FeP &z) { return {{fe_lc3<C1, C2, C3>(x.v[0], y.v[0], z.v[0]), fe_lc3<C1, C2, C3>(x.v[1], y.v[1], z.v[1])}}; }
 template <int C1, int C2, int C3>      // middle term: minus on the even lane, plus on the odd lane
 BN_FN FeP fe_lc3_par(const FeP &x, const FeP &y, const FeP &z) {
-    return {{fe_lc3_core<C1, C2, C3, BN_PAR_SIGN2>(x.v[0], y.v[0], z.v[0], true), fe_lc3_core<C1, C2, C3, BN_PAR_SIGN2>(x.v[1], y.v[1], z.v[1], false)}};
+    return {{fe_lc3_core<C1, C2, C3, true>(x.v[0], y.v[0], z.v[0], true), fe_lc3_core<C1, C2, C3, true>(x.v[1], y.v[1], z.v[1], false)}};
 }
 template <int C1, int C2, int C3, int C4>
 BN_FN FeP fe_lc4_par(const FeP &x, const FeP &y, const FeP &z, const FeP &w) {
-    return {{fe_lc4_core<C1, C2, C3, C4, false, BN_PAR_SIGN2>(x.v[0], y.v[0], z.v[0], w.v[0], true), fe_lc4_core<C1, C2, C3, C4, false, BN_PAR_SIGN2>(x.v[1], y.v[1], z.v[1], w.v[1], false)}};
+    return {{fe_lc4_core<C1, C2, C3, C4, false, true>(x.v[0], y.v[0], z.v[0], w.v[0], true), fe_lc4_core<C1, C2, C3, C4, false, true>(x.v[1], y.v[1], z.v[1], w.v[1], false)}};
 }
 template <int C1, int C2, int C3, int C4>
 BN_FN FeP fe_lc4w_par(const FeP &x, const FeP &y, const FeP &z, const FeP &w) {

@@ -128,16 +128,19 @@ def test_scalar_multiplication_loops_do_not_store_to_scratch():
         assert sum(st for _, st in region) == 0, f"scratch stores inside the window loop of {kernel}: {region}"
 
 
-def test_no_folded_dpp_subtractions():
+def test_only_plain_dpp_moves_and_the_flag_that_guarantees_them():
     """Round 4: when the quotient estimate of the fused reductions read a neighbour pair's top limb directly, LLVM's DPP combiner folded
     the quad_perm move into the subtraction (v_sub_u32_dpp / v_subrev_u32_dpp) and the four-lane Miller kernel returned wrong values for
     every pairing on the GPU - right again with -mllvm -amdgpu-dpp-combine=false, and the folded instructions themselves compute what they
-    should (tools/dpp_fold_check.hip on the box).  Cause not established (fe.hpp fe_lc4_core keeps the form that is not folded); until it
-    is, a library that contains such an instruction is suspect even if the GPU parity tests of the day pass."""
-    import re
+    should (tools/dpp_fold_check.hip on the box).  Cause not established, so since round 5 EVERY unit is built with the combiner off
+    (bn_amd/_native.py DEVICE_FLAGS; free: profiles/r05_ab_dpp_combine_off.txt) and this test - which does not skip: it builds the
+    library if it has to - rejects ANY DPP instruction other than the plain v_mov_b32_dpp in the shipped code objects (round 4's regex
+    let the same combiner's 34 v_add_u32_dpp through).  tests/test_gpu_soak.py re-runs the goldens on kernel units rebuilt on the GPU box."""
     import isa_mix
-    so = ROOT / "bn_amd" / "libbn254_hip.so"
-    if not so.exists() or not (isa_mix.LLVM / "llvm-objdump").exists():
-        pytest.skip("library or llvm-objdump not present")
-    found = [line.strip()[:100] for text in isa_mix.disassemble(so) for line in text.splitlines() if re.match(r"^\s+v_sub(rev)?(b)?(_co)?_u32_dpp\s", line)]
-    assert not found, found[:5]
+    from bn_amd import _native
+    so = _native.build()
+    assert (isa_mix.LLVM / "llvm-objdump").exists() and (isa_mix.LLVM / "clang-offload-bundler").exists(), "the ROCm LLVM tools are part of the image"
+    assert "-amdgpu-dpp-combine=false" in _native.DEVICE_FLAGS and "-amdgpu-dpp-combine=false" in (_native.OBJ_DIR / "flags.txt").read_text()
+    ops = collections.Counter(m.group(1) for text in isa_mix.disassemble(so) for m in re.finditer(r"^\s+(v_\w+_dpp)\s", text, re.M))
+    assert ops["v_mov_b32_dpp"] > 10000, ops                       # the lane-pair exchanges are there ...
+    assert set(ops) == {"v_mov_b32_dpp"}, ops                       # ... and nothing else carries a DPP modifier

@@ -146,6 +146,18 @@ def test_options_api(eng):
     with eng.options(product_chunk=3, pipeline_slots=1):
         assert eng.get_option("product_chunk") == 3 and eng.get_option("pipeline_slots") == 1
     assert eng.get_option("product_chunk") == -1 and eng.get_option("pipeline_slots") == 2
+    # size options are capped at what one launch addresses (2^22); a rejected value inside options() leaves the context as it was
+    for name in ("quad_max", "round_pairs", "wave_pairing_max", "wave_fe_max", "pipeline_chunk"):
+        eng.set_option(name, 1 << 22)
+        with pytest.raises(Exception):
+            eng.set_option(name, (1 << 22) + 1)
+        eng.set_option(name, None)
+    eng.set_option("wave_fe_max", 99)
+    with pytest.raises(Exception):
+        with eng.options(wave_fe_max=5, quad_max=7, miller_shared=3):      # the third value is invalid
+            pass
+    assert eng.get_option("wave_fe_max") == 99 and eng.get_option("quad_max") == 64 * cus and eng.get_option("miller_shared") == 0
+    eng.set_option("wave_fe_max", None)
 
 
 def test_pairing_batch_matches_oracle(oracle, eng):

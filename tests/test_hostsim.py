@@ -166,9 +166,6 @@ def test_lane_pair_mapping(oracle, hs, kats):
         P = oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)); Q = oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng))
         assert np.array_equal(hs.call("hsb_pairing_naf", P, Q, out_words=96), oracle.pairing(P, Q))
     assert np.array_equal(hs.call("hsb_pairing_naf", oracle.g1_one(), oracle.g2_one(), out_words=96), oracle.pairing(oracle.g1_one(), oracle.g2_one()))
-    # ... and the variant that multiplies the doubling and addition lines of a step together first
-    assert oracle.fq12_to_ints(hs.call("hsb_pairing_naf_merged", P0, Q0, out_words=96)) == I(kats["test_reduced_pairing"]["expected"])
-    assert np.array_equal(hs.call("hsb_pairing_naf_merged", P, Q, out_words=96), oracle.pairing(P, Q))
     assert np.array_equal(hs.call("hsb_pairing_naf", P, oracle.g2_zero(), out_words=96), oracle.fq12_one())
 
 

@@ -11,9 +11,9 @@ name=$1; shift
 B=bn_amd/csrc/build
 UNITS=${UNITS:-bn254_kernels_b}
 objs=""
-for u in bn254_hip bn254_kernels_b bn254_kernels_mul bn254_kernels_w bn254_kernels_q bn254_multi; do
+for u in bn254_hip bn254_kernels_b bn254_kernels_mul bn254_kernels_w bn254_kernels_q bn254_multi bn254_measure; do
   if [[ " $UNITS " == *" $u "* ]]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c bn_amd/csrc/$u.hip -o build_variants/${u}_$name.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -mllvm -amdgpu-dpp-combine=false "$@" -c bn_amd/csrc/$u.hip -o build_variants/${u}_$name.o &
     objs="$objs build_variants/${u}_$name.o"
   else
     objs="$objs $B/$u.o"

@@ -17,9 +17,7 @@
 // image (src/arith.rs:257-263,481-503: canonical at the boundary); (2) time per dependent dual product at 1, 2 and 4 waves per SIMD
 // on all 1024 SIMDs; (3) the instruction mix of both loops (tools/isa_mix.py on this binary).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I bn_amd/csrc tools/dfma_experiment.hip -o build_variants/dfma_experiment
-#define BN_COARSE __device__ __forceinline__
-#define BN_LEAF_MUL __device__ __forceinline__
-#define BN_LEAF_RED __device__ __forceinline__
+#define BN_INLINE_ALL 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

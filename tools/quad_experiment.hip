@@ -9,9 +9,7 @@
 // Both kernels store canonical bytes; the host compares them (the two mappings must agree bit for bit) and times them at element
 // counts where the lane-pair mapping leaves SIMDs empty (the regime the question is about) and where it fills the chip.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I bn_amd/csrc tools/quad_experiment.hip -o build_variants/quad_experiment
-#define BN_COARSE __device__ __forceinline__
-#define BN_LEAF_MUL __device__ __forceinline__
-#define BN_LEAF_RED __device__ __forceinline__
+#define BN_INLINE_ALL 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

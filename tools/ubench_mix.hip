@@ -6,9 +6,7 @@
 // below), launched with exactly N waves per SIMD on every CU; reports wall time per squaring, squarings per second and SIMD, and the
 // effective clock (s_memtime ticks / wall time).  A second stream ("dense") is the Fq12 product f <- f * g (tower.hpp f12_mul).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ibn_amd/csrc -Rpass-analysis=kernel-resource-usage tools/ubench_mix.hip -o /tmp/ubench_mix
-#define BN_COARSE __device__ __forceinline__
-#define BN_LEAF_MUL __device__ __forceinline__
-#define BN_LEAF_RED __device__ __forceinline__
+#define BN_INLINE_ALL 1
 #include <hip/hip_runtime.h>
 #include "tower.hpp"
 #include <cstdio>
