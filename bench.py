@@ -152,7 +152,7 @@ def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=No
     td = traffic_of(dom, unit_count * steps / stats[dom][1])
     traffic, src = (td["traffic"], td["traffic_source"]) if td else (None, None)
     d = per[dom]
-    out = {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d)", "kernel": dom, "achieved": d["achieved"], "peak": peak8,
+    out = {"bound": "valu-int32-mac at the socket power cap (neither hbm nor mfma: SURVEY.md 8d; 1388 of 1400 W under these kernels: profiles/r05_power_probe.txt)", "kernel": dom, "achieved": d["achieved"], "peak": peak8,
            "unit": "TMAC32/s", "frac": d["frac"],
            "achieved_is": "Fq products of the chain x 136 MAC32 (an 8 x 32-bit-limb Montgomery product) / measured kernel time",
            "peak_source": "bn254_ubench_mac32 in this run: pure v_mad_u64_u32 stream, 8 waves/SIMD",
@@ -445,7 +445,6 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="pairings per GPU per step (default: 2^16 at N = 1, 2^20/N at N > 1)")
-    ap.add_argument("--mapping", type=int, default=None, help="0: one lane per pairing, 1: lane pair per pairing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the `side` object (configs[3], configs[4], single-pairing latency) of the default line")
@@ -499,7 +498,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    eng = D.TorchEngine(bn_amd.Engine(gpu_index, mapping=args.mapping), dev)
+    eng = D.TorchEngine(bn_amd.Engine(gpu_index), dev)
     try:
         if args.workload in ("g1mul", "g2mul"):
             return bench_mul(args, eng, dev, world, rank, 1 if args.workload == "g1mul" else 2)
@@ -544,7 +543,7 @@ def main():
                          scaling, workload, {"roofline": rf, **({"expected_scaling": expected_scaling("pairing", world)} if world > 1 and args.batch is None else {})},
                          {"pairings_per_gpu": n, "inputs": "r*G1 / s*G2 (Jacobian, z != 1) resident in HBM", "parallelism": f"dp{world} (sharded, no collective)",
                           "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
-                          "mapping": 1 if args.mapping is None else args.mapping,
+                          "mapping": 1,
                           # the lane-pair kernels are launched in rounds of 256 pairings per CU (two waves on every SIMD): the library
                           # sizes its sub-launches from the CU count of the device it finds (bn_round_pairs in csrc/bn254_hip.hip)
                           "cus": cus, "pairings_per_launch": n if n <= 256 * cus else f"equal parts of at most {256 * cus}",

@@ -1,13 +1,9 @@
 // MI355X (gfx950) kernels and the C ABI of the batched BN254 pairing engine (include/bn254_hip.h).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC bn254_hip.hip -o libbn254_hip.so
 //
-// Kernels (one wave = 64 lanes, no cross-lane traffic in mapping A, DPP lane-pair exchange in mapping B):
-//   bn254_miller_*      G1/G2 Jacobian -> affine (Fermat inversions) -> fused Miller loop -> Fq12 (infinity -> one)
-//   bn254_final_exp_*   Fq12 -> Gt
-//   bn254_gt_product    Fq12 product tree (multi-pairing)
-//   bn254_g1_mul / bn254_g2_mul   G * Fr by the reference's double-and-add chain, optionally normalized
-// All global-memory traffic is the algorithmic input/output (672 B per pairing) plus, in mapping A, private-memory
-// (scratch) traffic for the Fq12-sized temporaries; see DESIGN.md for the measured numbers.
+// This unit holds the host side (contexts, options, launch policy: which of the wave / four-lane / lane-pair kernels of the other units runs a
+// call) and the wire-format kernels (one record per lane).  The pairing and scalar-multiplication kernels live in bn254_kernels_{b,q,w,mul}.hip.
+// (The one-lane-per-pairing kernels of rounds 1-4 - "mapping A", a test double - moved to tests/testdouble/ in round 5.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -27,93 +23,6 @@ using namespace bn254;
 namespace {
 
 constexpr int BLOCK = 64;
-
-template <class F2>
-__device__ __forceinline__ void miller_body(const uint32_t *__restrict__ g1, const uint32_t *__restrict__ g2, uint32_t *__restrict__ f_out) {
-    uint32_t w1[24], w2[48];
-#pragma unroll
-    for (int i = 0; i < 24; ++i) w1[i] = g1[i];
-#pragma unroll
-    for (int i = 0; i < 48; ++i) w2[i] = g2[i];
-    bool inf = words_all_zero(w1 + 16, 8) || words_all_zero(w2 + 32, 16);        // groups/mod.rs:766
-    G1Aff<Fe> p = g1_to_affine(fe_from_u32x8(w1), fe_from_u32x8(w1 + 8), fe_from_u32x8(w1 + 16));
-    G2Aff<F2> q = g2_to_affine(f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32));
-    Fq12<F2> f = miller_loop(p, q);
-    uint32_t o[96];
-    f12_store(f, o);
-    // Gt::one() in the reference image: c0.c0.c0 = R mod q, everything else 0
-    uint32_t one[8];
-    fe_to_u32x8(fe_one(), one);
-#pragma unroll
-    for (int i = 0; i < 96; ++i) f_out[i] = inf ? (i < 8 ? one[i] : 0u) : o[i];
-}
-
-__global__ void __launch_bounds__(BLOCK) bn254_miller_A(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
-    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= n) return;
-    miller_body<Fq2A>(g1 + 24u * idx, g2 + 48u * idx, f_out + 96u * idx);
-}
-
-__global__ void __launch_bounds__(BLOCK) bn254_final_exp_A(const uint32_t *f_in, uint32_t *out, uint32_t n) {
-    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= n) return;
-    uint32_t w[96];
-#pragma unroll
-    for (int i = 0; i < 96; ++i) w[i] = f_in[96u * idx + i];
-    Fq12<Fq2A> f = final_exponentiation(f12_load<Fq2A>(w));
-    f12_store(f, w);
-#pragma unroll
-    for (int i = 0; i < 96; ++i) out[96u * idx + i] = w[i];
-}
-
-// out[t] = product of in[t*chunk .. min(n,(t+1)*chunk))   (one Fq12 chain per lane; 3 levels reduce 2^18 values)
-__global__ void __launch_bounds__(BLOCK) bn254_gt_product_A(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t chunk) {
-    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
-    uint64_t lo = (uint64_t)t * chunk;
-    if (lo >= n) return;
-    uint64_t hi = lo + chunk < n ? lo + chunk : n;
-    uint32_t w[96];
-#pragma unroll
-    for (int i = 0; i < 96; ++i) w[i] = in[96u * lo + i];
-    Fq12<Fq2A> acc = f12_load<Fq2A>(w);
-    for (uint64_t j = lo + 1; j < hi; ++j) {
-#pragma unroll
-        for (int i = 0; i < 96; ++i) w[i] = in[96u * j + i];
-        acc = f12_mul(acc, f12_load<Fq2A>(w));
-    }
-    f12_store(acc, w);
-#pragma unroll
-    for (int i = 0; i < 96; ++i) out[96u * t + i] = w[i];
-}
-
-template <class F, int W, class LD, class ST>
-__device__ __forceinline__ void mul_body(const uint32_t *pt, const uint32_t *km, uint32_t *out, int normalize, LD ld, ST st) {
-    uint32_t kw[8], raw[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) kw[i] = km[i];
-    fr_from_mont(kw, raw);
-    uint32_t w[3 * W];
-#pragma unroll
-    for (int i = 0; i < 3 * W; ++i) w[i] = pt[i];
-    Jac<F> p = {ld(w), ld(w + W), ld(w + 2 * W)};
-    // normalize = 0: the reference's own chain (raw Jacobian limbs, bit-identical to `G * Fr`); 1: windowed + normalized
-    Jac<F> r = normalize ? jac_normalize<F>(scalar_mul_windowed<F>(p, raw)) : scalar_mul_reference_chain<F>(p, raw);
-    st(r.x, w); st(r.y, w + W); st(r.z, w + 2 * W);
-#pragma unroll
-    for (int i = 0; i < 3 * W; ++i) out[i] = w[i];
-}
-__global__ void __launch_bounds__(BLOCK) bn254_g1_mul_k(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
-    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= n) return;
-    mul_body<FqField, 8>(p + 24u * idx, k + 8u * idx, out + 24u * idx, normalize,
-                         [](const uint32_t *w) { return fe_from_u32x8(w); }, [](const Fe &a, uint32_t *w) { fe_to_u32x8(a, w); });
-}
-__global__ void __launch_bounds__(BLOCK) bn254_g2_mul_k(const uint32_t *p, const uint32_t *k, uint32_t *out, uint32_t n, int normalize) {
-    uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= n) return;
-    mul_body<Fq2Field<Fq2A>, 16>(p + 48u * idx, k + 8u * idx, out + 48u * idx, normalize,
-                                 [](const uint32_t *w) { return f2_load((const Fq2A *)nullptr, w); }, [](const Fq2A &a, uint32_t *w) { f2_store(a, w); });
-}
 
 // wire format (io_wire.hpp): one record per lane; byte-granular global accesses (65/129-byte strides), not a hot path
 __global__ void __launch_bounds__(BLOCK) bn254_g1_encode_k(const uint32_t *p, uint8_t *out, uint32_t n) {
@@ -316,65 +225,53 @@ size_t bn_sub_launch(const bn254_ctx *c, size_t n) {
 static size_t bn_wave_pairing_max(const bn254_ctx *c) { return (size_t)bn_opt(c, BN254_OPT_WAVE_PAIRING_MAX); }
 // naf: the value is only consumed by a final exponentiation, so the shorter NAF schedule may be used (pairing.hpp)
 int bn_launch_miller(bn254_ctx *c, const void *p, const void *q, void *f, size_t n, hipStream_t s, bool naf) {
-    if (c->mapping.load() == 1 && naf && n <= bn_wave_pairing_max(c)) {
+    if (naf && n <= bn_wave_pairing_max(c)) {
         BnScope sc(c, s, "miller_wave");
         return bn254_launch_pairing_W(p, q, f, n, 0, s);
     }
     // between the one-per-wave and the lane-pair regime: four lanes per pairing (bn254_kernels_q.hip) - while lane pairs would leave
     // SIMDs empty (up to BN254_OPT_QUAD_MAX = 64 per CU: one wave per SIMD of quads) the split Fq12 arithmetic is 1.4 x faster
-    if (c->mapping.load() == 1 && naf && n <= (size_t)bn_opt(c, BN254_OPT_QUAD_MAX)) {
+    if (naf && n <= (size_t)bn_opt(c, BN254_OPT_QUAD_MAX)) {
         BnScope sc(c, s, "miller_quad");
         return bn254_launch_miller_Q(p, q, f, n, s);
     }
-    if (c->mapping.load() == 1) {
-        const size_t step = bn_sub_launch(c, n);
-        for (size_t lo = 0; lo < n; lo += step) {
-            const size_t cnt = n - lo < step ? n - lo : step;
-            BnScope sc(c, s, "miller");
-            int rc = bn254_launch_miller_B((const char *)p + lo * sizeof(bn_g1), (const char *)q + lo * sizeof(bn_g2), (char *)f + lo * sizeof(bn_gt), cnt, naf ? 1 : 0, s);
-            if (rc) return rc;
-        }
-        return BN254_OK;
+    const size_t step = bn_sub_launch(c, n);
+    for (size_t lo = 0; lo < n; lo += step) {
+        const size_t cnt = n - lo < step ? n - lo : step;
+        BnScope sc(c, s, "miller");
+        int rc = bn254_launch_miller_B((const char *)p + lo * sizeof(bn_g1), (const char *)q + lo * sizeof(bn_g2), (char *)f + lo * sizeof(bn_gt), cnt, naf ? 1 : 0, s);
+        if (rc) return rc;
     }
-    if (n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;          // mapping A (test double): one launch, 32-bit word offsets
-    BnScope sc(c, s, "miller");
-    hipLaunchKernelGGL(bn254_miller_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)q, (uint32_t *)f, (uint32_t)n);
-    return (int)hipGetLastError();
+    return BN254_OK;
 }
 // Up to this many final exponentiations per call run ONE PER WAVE (bn254_kernels_w.hip: 0.48 ms up to 1024 - one wave per SIMD -,
 // 0.69 ms at 2048, 1.4 ms at 4096, while a lane pair needs 1.97 ms for its serial chain whatever the count): BN254_OPT_WAVE_FE_MAX.
 static size_t bn_wave_fe_max(const bn254_ctx *c) { return (size_t)bn_opt(c, BN254_OPT_WAVE_FE_MAX); }
 // table: the caller's own table buffer (pipelined path: one per chunk in flight) or NULL for the context's (under a BnScratchGuard)
 int bn_launch_final_exp(bn254_ctx *c, const void *f, void *out, size_t n, hipStream_t s, BnBuf *table) {
-    if (c->mapping.load() == 1 && n <= bn_wave_fe_max(c)) {
+    if (n <= bn_wave_fe_max(c)) {
         BnScope sc(c, s, "final_exp_wave");
         return bn254_launch_final_exp_W(f, out, n, s);
     }
-    if (c->mapping.load() == 1 && n <= (size_t)bn_opt(c, BN254_OPT_QUAD_MAX)) {
+    if (n <= (size_t)bn_opt(c, BN254_OPT_QUAD_MAX)) {
         BnBuf *t = table ? table : &c->exp_tbl;
         int rc = t->reserve(bn254_final_exp_table_bytes_Q(n)); if (rc) return rc;
         BnScope sc(c, s, "final_exp_quad");
         return bn254_launch_final_exp_Q(f, out, n, t->p, s);
     }
-    if (c->mapping.load() == 1) {
-        BnBuf *t = table ? table : &c->exp_tbl;
-        const size_t step = bn_sub_launch(c, n);
-        int rc = t->reserve(bn254_final_exp_table_bytes_B(step)); if (rc) return rc;       // ONE table, reused by every sub-launch (stream order)
-        for (size_t lo = 0; lo < n; lo += step) {
-            const size_t cnt = n - lo < step ? n - lo : step;
-            BnScope sc(c, s, "final_exp");
-            rc = bn254_launch_final_exp_B((const char *)f + lo * sizeof(bn_gt), (char *)out + lo * sizeof(bn_gt), cnt, t->p, s);
-            if (rc) return rc;
-        }
-        return BN254_OK;
+    BnBuf *t = table ? table : &c->exp_tbl;
+    const size_t step = bn_sub_launch(c, n);
+    int rc = t->reserve(bn254_final_exp_table_bytes_B(step)); if (rc) return rc;       // ONE table, reused by every sub-launch (stream order)
+    for (size_t lo = 0; lo < n; lo += step) {
+        const size_t cnt = n - lo < step ? n - lo : step;
+        BnScope sc(c, s, "final_exp");
+        rc = bn254_launch_final_exp_B((const char *)f + lo * sizeof(bn_gt), (char *)out + lo * sizeof(bn_gt), cnt, t->p, s);
+        if (rc) return rc;
     }
-    if (n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
-    BnScope sc(c, s, "final_exp");
-    hipLaunchKernelGGL(bn254_final_exp_A, dim3(grid_for(n)), dim3(BLOCK), 0, s, (const uint32_t *)f, (uint32_t *)out, (uint32_t)n);
-    return (int)hipGetLastError();
+    return BN254_OK;
 }
-// reduces n Fq12 values at `in` to one at `out`; `tmp` >= bn_product_tmp_bytes(n).  Lane-pair mapping: ONE launch (lane chunks ->
-// wave-cooperative fold -> arrival tree over the waves, bn254_kernels_w.hip); one-lane mapping (test double): a launch per level.
+// reduces n Fq12 values at `in` to one at `out`; `tmp` >= bn_product_tmp_bytes(n).  ONE launch (lane chunks -> wave-cooperative fold ->
+// arrival tree over the waves, bn254_kernels_w.hip).
 // Shape of the one-launch product tree, read off profiles/r03p_product_shape_sweep.txt.  Three ways to multiply, three prices:
 // a lane pair multiplies two values in ~20-30 us but 32 of them do so at once per wave (`chunk` values per lane pair, then `bfly`
 // butterfly levels across the pairs of a wave); the wave machine multiplies two values in ~2.7 us but one product at a time
@@ -396,37 +293,17 @@ static ProductShape product_shape(const bn254_ctx *c, size_t n) {
     return ps;
 }
 int bn_launch_product(bn254_ctx *c, const void *in, size_t n, void *out, void *tmp, hipStream_t s) {
-    if (c->mapping.load() == 1) {
-        size_t grid, sb, cw;
-        const ProductShape ps = product_shape(c, n);
-        bn254_gt_reduce_sizes_W(n, ps.chunk, ps.per_wave, &grid, &sb, &cw);
-        BnScope sc(c, s, "gt_product");
-        return bn254_launch_gt_reduce_W(in, n, ps.chunk, ps.per_wave, ps.bfly, tmp, (char *)tmp + sb, out, s);
-    }
-    const uint32_t chunk = 4;
-    const uint32_t *src = (const uint32_t *)in;
-    size_t level_cap = (n + chunk - 1) / chunk;
-    uint32_t *bufA = (uint32_t *)tmp, *bufB = (uint32_t *)tmp + 96 * level_cap;
-    bool useA = true;
-    while (true) {
-        size_t m = (n + chunk - 1) / chunk;
-        uint32_t *dst = (m == 1) ? (uint32_t *)out : (useA ? bufA : bufB);
-        {
-            BnScope sc(c, s, "gt_product");
-            hipLaunchKernelGGL(bn254_gt_product_A, dim3(grid_for(m)), dim3(BLOCK), 0, s, src, dst, (uint32_t)n, chunk);
-            int rc = (int)hipGetLastError();
-            if (rc) return rc;
-        }
-        if (m == 1) break;
-        src = dst; n = m; useA = !useA;
-    }
-    return BN254_OK;
+    size_t grid, sb, cw;
+    const ProductShape ps = product_shape(c, n);
+    bn254_gt_reduce_sizes_W(n, ps.chunk, ps.per_wave, &grid, &sb, &cw);
+    BnScope sc(c, s, "gt_product");
+    return bn254_launch_gt_reduce_W(in, n, ps.chunk, ps.per_wave, ps.bfly, tmp, (char *)tmp + sb, out, s);
 }
 // out = final_exponentiation(in[0] * ... * in[m-1]): the tail of a sharded multi-pairing (the partial products of the ranks, then
 // the ONE final exponentiation).  Up to 16 values: one wave-cooperative launch (15 products in a row cost what the second launch
 // and the tree's levels would); more: product tree, then the exponentiation.
 int bn_launch_product_final_exp(bn254_ctx *c, const void *in, size_t m, void *out, hipStream_t s) {
-    if (c->mapping.load() == 1 && m >= 1 && m <= 16) {
+    if (m >= 1 && m <= 16) {
         BnScope sc(c, s, "gt_tail");
         return bn254_launch_gt_tail_W(in, 1, (unsigned)m, out, 1, s);
     }
@@ -455,7 +332,7 @@ static int bn_for_parts(size_t n, size_t step, Fn fn) {
 // out[i] = pairing(p[i], q[i]).  Small batches: Miller loop + final exponentiation per WAVE, one launch; otherwise the lane-pair
 // kernels, the Miller values written to `out` and exponentiated in place (same 384-byte slots).
 int bn_launch_pairing(bn254_ctx *c, const void *p, const void *q, void *out, size_t n, hipStream_t s, BnBuf *table) {
-    if (c->mapping.load() == 1 && n <= bn_wave_pairing_max(c)) {
+    if (n <= bn_wave_pairing_max(c)) {
         BnScope sc(c, s, "pairing_wave");
         return bn254_launch_pairing_W(p, q, out, n, 1, s);
     }
@@ -467,21 +344,15 @@ int bn_launch_pairing(bn254_ctx *c, const void *p, const void *q, void *out, siz
 constexpr size_t BN_MUL_LANES_PER_LAUNCH = (size_t)1 << 18;
 int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize, BnBuf *table) {
     const size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
-    const bool mapping_b = ctx->mapping.load() == 1;
-    const size_t step = (mapping_b && normalize) ? BN_MUL_LANES_PER_LAUNCH / (g == 1 ? 1 : 2) : BN_LAUNCH_MAX;
+    const size_t step = normalize ? BN_MUL_LANES_PER_LAUNCH / (g == 1 ? 1 : 2) : BN_LAUNCH_MAX;
     BnBuf *t = table ? table : &ctx->mul_tbl;
-    if (mapping_b && normalize) { int rc = t->reserve(bn254_mul_table_bytes_M(g, n < step ? n : step)); if (rc) return rc; }
+    if (normalize) { int rc = t->reserve(bn254_mul_table_bytes_M(g, n < step ? n : step)); if (rc) return rc; }
     return bn_for_parts(n, step, [&](size_t lo, size_t cnt) -> int {
         const void *p = (const char *)d_p + lo * ps, *k = (const char *)d_k + lo * sizeof(bn_fr);
         void *o = (char *)d_out + lo * ps;
         BnScope sc(ctx, s, g == 1 ? "g1_mul" : "g2_mul");
-        if (mapping_b)          // registers-resident chains; G2 in the lane-pair mapping (bn254_kernels_mul.hip)
-            return g == 1 ? bn254_launch_g1_mul_M(p, k, o, cnt, normalize, t->p, s) : bn254_launch_g2_mul_M(p, k, o, cnt, normalize, t->p, s);
-        if (g == 1)
-            hipLaunchKernelGGL(bn254_g1_mul_k, dim3(grid_for(cnt)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)o, (uint32_t)cnt, normalize);
-        else
-            hipLaunchKernelGGL(bn254_g2_mul_k, dim3(grid_for(cnt)), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)k, (uint32_t *)o, (uint32_t)cnt, normalize);
-        return (int)hipGetLastError();
+        // registers-resident chains; G2 in the lane-pair mapping (bn254_kernels_mul.hip)
+        return g == 1 ? bn254_launch_g1_mul_M(p, k, o, cnt, normalize, t->p, s) : bn254_launch_g2_mul_M(p, k, o, cnt, normalize, t->p, s);
     });
 }
 
@@ -540,11 +411,10 @@ const char *bn254_error_string(int code) {
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
+// Kept for ABI compatibility with rounds 1-4: the one-lane-per-pairing mapping (0) was a test double and left the library in round 5
+// (tests/testdouble/); only 1 - the lane-pair mapping with its wave and four-lane siblings - is accepted.
 int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping) {
-    if (!ctx || (mapping != 0 && mapping != 1)) return BN254_E_BAD_ARG;
-    // atomic; every launch helper reads it for itself, so a call in flight may run its Miller loops under one mapping and its final
-    // exponentiation under the other - the values handed over are the reference's images, the result is the same bytes
-    ctx->mapping.store(mapping);
+    if (!ctx || mapping != 1) return BN254_E_BAD_ARG;
     return BN254_OK;
 }
 int bn254_ctx_set_option(bn254_ctx *ctx, int key, long value) {
@@ -627,7 +497,7 @@ int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, s
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
-    const int m = (ctx->mapping.load() == 1 && n > bn_wave_pairing_max(ctx)) ? miller_shared_m(ctx, n) : 1;
+    const int m = (n > bn_wave_pairing_max(ctx)) ? miller_shared_m(ctx, n) : 1;
     const size_t nv = (n + (size_t)m - 1) / (size_t)m;             // Miller values that reach the product tree
     const size_t fbytes = nv * 384;
     rc = ctx->ws.reserve(fbytes + bn_product_tmp_bytes(ctx, nv)); if (rc) return rc;

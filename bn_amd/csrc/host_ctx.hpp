@@ -74,7 +74,6 @@ struct BnSlot {
 struct bn254_ctx {
     int device = 0;
     int cus = 256;                      // compute units of the device (sizes one "round" of the lane-pair kernels: bn_round_pairs)
-    std::atomic<int> mapping{1};        // 1: lane-pair mapping (default), 0: one lane per pairing; read by slot-leased callers without ctx->mu
     std::atomic<long> opt[BN254_OPT_COUNT_];   // bn254_ctx_set_option: raw values, < 0 = "derive the default from the device" (bn_opt)
     std::mutex mu;                      // host-buffer entry points hold it for the whole call
     std::mutex scratch_mu;              // guards the scratch bookkeeping below (held only while enqueueing)

@@ -30,7 +30,7 @@ def _same_len(a, b):
 class Engine:
     """one context = one GPU (include/bn254_hip.h: bn254_ctx)"""
 
-    def __init__(self, device=0, mapping=None):
+    def __init__(self, device=0):
         self._lib = _native.lib()
         if self._lib.bn254_device_count() <= 0:
             raise _native.Bn254Error("no HIP device: bn_amd has no CPU fallback")
@@ -38,8 +38,6 @@ class Engine:
         _native.check(self._lib.bn254_ctx_create(int(device), C.byref(h)))
         self._ctx = h
         self.device = int(device)
-        if mapping is not None:
-            _native.check(self._lib.bn254_ctx_set_mapping(self._h, int(mapping)))
 
     def close(self):
         if getattr(self, "_ctx", None):

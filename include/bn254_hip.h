@@ -48,7 +48,7 @@
  *     slot: two callers with batches of up to one machine round (256 pairings per CU: 2^16 on an MI355X) run concurrently on two
  *     streams (the number of streams the GPU overlaps without loss), further callers and multi-chunk batches queue; every other
  *     entry point serialises its callers on the context.  Use one context per thread (or bn254_multi_*) for more overlap;
- *     bn254_ctx_set_mapping and bn254_ctx_set_option are atomic, but set them before concurrent use: a call in flight may run some
+ *     bn254_ctx_set_option is atomic, but set options before concurrent use: a call in flight may run some
  *     of its launches under the old and some under the new setting (same bytes either way);
  *   - the *_dev entry points are asynchronous on the caller's stream.  Context-owned scratch (the final-exponentiation table,
  *     the product workspace) is ordered across streams with events, so calls on different streams of one context are safe
@@ -91,7 +91,8 @@ int bn254_device_count(void);
 int bn254_ctx_create(int device, bn254_ctx **out);
 void bn254_ctx_destroy(bn254_ctx *ctx);
 const char *bn254_error_string(int code);
-/* 0: one pairing per lane (Fq2A); 1: one pairing per lane PAIR (Fq2B, the default).  Results are identical. */
+/* Kept for ABI compatibility: 1 = one pairing per lane PAIR (with its one-per-wave and four-lane siblings, chosen by batch size) is the only
+   mapping; 0 (one pairing per lane: the test double of rounds 1-4, now tests/testdouble/) is rejected with BN254_E_BAD_ARG. */
 int bn254_ctx_set_mapping(bn254_ctx *ctx, int mapping);
 
 /* ---- tunables ---------------------------------------------------------------------------------------------------------

@@ -58,8 +58,7 @@ def test_hot_loops_are_spill_free(kernel):
 
 # vgpr_spill_count ceilings of EVERY shipped kernel (tools/kernel_meta.py reads them from the code objects).  The ceilings are the
 # values of the build this test was written against: anything above means an edit moved a register allocation - look at
-# `tools/isa_mix.py --blocks KERNEL` before raising one.  The mapping-A kernels (bn254_*_A, *_mul_k) are the one-lane-per-pairing test
-# double, not a performance path; their spills are recorded, not guarded.
+# `tools/isa_mix.py --blocks KERNEL` before raising one.  (The one-lane test double lives in tests/testdouble/, not in this library.)
 SPILL_CEILING = {
     "bn254_miller_B": 3, "bn254_miller_naf_B": 0, "bn254_final_exp_B": 7, "bn254_miller_shared2_B": 19, "bn254_miller_shared4_B": 19,
     "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 0, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 11, "bn254_gt_inverse_B": 4,
@@ -70,7 +69,7 @@ SPILL_CEILING = {
     "bn254_g1_encode_k": 0, "bn254_g2_encode_k": 0, "bn254_g1_decode_k": 0, "bn254_g2_decode_k": 18, "bn254_fr_encode_k": 0, "bn254_fr_decode_k": 0,
     "bn254_ubench_mad_k": 0, "bn254_synthetic_scalars_k": 0, "bn254_tile_k": 0,
 }
-UNGUARDED = {"bn254_miller_A", "bn254_final_exp_A", "bn254_gt_product_A", "bn254_g1_mul_k", "bn254_g2_mul_k"}
+UNGUARDED = set()
 # kernels that must fit their occupancy target without private memory beyond small call frames: the hot state of the scalar
 # multiplications used to be written to scratch on every addition (round 4: 10.7 KB per G1 multiplication) - private memory that
 # is only the window-table setup stays below these sizes

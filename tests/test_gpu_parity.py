@@ -41,14 +41,15 @@ def test_reference_kats_on_gpu(oracle, kats, eng):
 
 def test_reference_miller_loop_kat_on_gpu(oracle, kats, eng):
     """groups/mod.rs:522-547 (test_miller_loop) literally: miller_loop(precompute(k2 G2), k1 G1) through bn254_miller_batch_dev - the
-    reference-schedule kernel, whose un-exponentiated value must be the reference's twelve field elements - in both lane mappings"""
+    reference-schedule kernel, whose un-exponentiated value must be the reference's twelve field elements - and through the one-lane test double"""
     import torch
     import bn_amd
     from bn_amd import distributed as D
     k = kats["test_miller_loop"]
     P = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_decimal(FR, k["k1"])); Q = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, k["k2"]))
-    for mapping in (1, 0):
-        e = bn_amd.Engine(0, mapping=mapping)
+    from testdouble import OneLaneEngine
+    for mapping in (1, 0):                       # 1: the product's lane-pair kernels; 0: the one-lane test double (tests/testdouble/)
+        e = bn_amd.Engine(0) if mapping == 1 else OneLaneEngine(0)
         te = D.TorchEngine(e, torch.device("cuda", 0))
         dp = torch.from_numpy(P.reshape(1, 12).view(np.int64)).to(te.device); dq = torch.from_numpy(Q.reshape(1, 24).view(np.int64)).to(te.device)
         f = te.empty(1, 48)
@@ -239,16 +240,18 @@ def test_reference_api_mirror(oracle):
 
 @pytest.mark.parametrize("mapping", [0, 1])
 def test_both_lane_mappings_agree_with_oracle(oracle, mapping):
-    """mapping 0: one lane per pairing (Fq2A); mapping 1: one lane PAIR per pairing (Fq2B, DPP exchange) - same bytes"""
+    """mapping 1: the product (one lane PAIR per pairing, Fq2B, DPP exchange); mapping 0: the one-lane test double of tests/testdouble/
+    (Fq2A: the same tower / pairing / curve templates over the other Fq2) - same bytes"""
     import bn_amd
-    e = bn_amd.Engine(0, mapping=mapping)
+    from testdouble import OneLaneEngine
+    e = bn_amd.Engine(0) if mapping == 1 else OneLaneEngine(0)
     rng = np.random.default_rng(107)
     n = 97                                    # odd: the last wave has an unpaired tail
     P, Q = _points(oracle, rng, n)
     P[5] = oracle.g1_zero(); Q[6] = oracle.g2_zero(); P[7] = oracle.g1_one(); Q[7] = oracle.g2_one()
     assert np.array_equal(e.pairing_batch(P, Q), oracle.pairing_batch(P, Q))
     assert np.array_equal(e.pairing_product(P[:33], Q[:33]), oracle.pairing_product(P[:33], Q[:33]))
-    # G * Fr: mapping 0 = call-based kernels with G2 over Fq2A, mapping 1 = inlined kernels with G2 on lane pairs
+    # G * Fr: the test double = call-based kernels with G2 over Fq2A and plain 4-bit windows, the product = inlined GLV / GLS kernels with G2 on lane pairs
     k = _fr(oracle, _scalars(rng, n))
     assert np.array_equal(e.g1_mul_batch(P, k), canon_infinity(oracle.g1_mul_batch(P, k)))
     assert np.array_equal(e.g2_mul_batch(Q, k), canon_infinity(oracle.g2_mul_batch(Q, k)))
@@ -286,8 +289,9 @@ def test_full_size_batch_properties(oracle):
     from bn_amd import distributed as D
     dev = torch.device("cuda", 0)
     n = 1 << 16
-    engB = D.TorchEngine(bn_amd.Engine(0, mapping=1), dev)
-    engA = D.TorchEngine(bn_amd.Engine(0, mapping=0), dev)
+    from testdouble import OneLaneEngine
+    engB = D.TorchEngine(bn_amd.Engine(0), dev)
+    engA = D.TorchEngine(OneLaneEngine(0), dev)                 # the one-lane test double: a second implementation at full size
     P, Q = D.synthetic_points(engB, 0, n)
     outB = D.pairing_batch_sharded(engB, P, Q); outB2 = D.pairing_batch_sharded(engB, P, Q); outA = D.pairing_batch_sharded(engA, P, Q)
     torch.cuda.synchronize()
@@ -424,7 +428,8 @@ def test_miller_values_equal_reference_schedule(oracle, mapping):
     import bn_amd
     from bn_amd import distributed as D
     dev = torch.device("cuda", 0)
-    e = bn_amd.Engine(0, mapping=mapping)
+    from testdouble import OneLaneEngine
+    e = bn_amd.Engine(0) if mapping == 1 else OneLaneEngine(0)
     rng = np.random.default_rng(77)
     n = 33
     P, Q = _points(oracle, rng, n)
@@ -635,8 +640,9 @@ def test_config3_shard_size_2_17(oracle):
     dev = torch.device("cuda", 0)
     n = 1 << 17
     lo = 3 * n                                   # the shard GPU 3 of 8 would own
-    engB = D.TorchEngine(bn_amd.Engine(0, mapping=1), dev)
-    engA = D.TorchEngine(bn_amd.Engine(0, mapping=0), dev)
+    from testdouble import OneLaneEngine
+    engB = D.TorchEngine(bn_amd.Engine(0), dev)
+    engA = D.TorchEngine(OneLaneEngine(0), dev)                 # the one-lane test double: a second implementation at full size
     P, Q = D.synthetic_points(engB, lo, lo + n)
     outB = engB.pairing_batch(P, Q); outB2 = engB.pairing_batch(P, Q); outA = engA.pairing_batch(P, Q)
     h0 = engB.pairing_batch(P[:n // 2].contiguous(), Q[:n // 2].contiguous()); h1 = engB.pairing_batch(P[n // 2:].contiguous(), Q[n // 2:].contiguous())

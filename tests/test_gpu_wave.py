@@ -222,6 +222,13 @@ def test_quad_kernels_match_oracle_and_lane_pair_kernels(oracle, te, goldens):
         assert (e2.kernel_stats("miller_quad")[1], e2.kernel_stats("final_exp_quad")[1]) == ((1, 1) if want_quad else (0, 0)), m
         assert e2.kernel_stats("miller")[1] == (0 if want_quad else 1), m
         assert torch.equal(out, ref[:m]), m
+        if m == thr_q:
+            # the four-lane kernels at their REAL operating size against the ORACLE itself (not only against the lane-pair kernels): 2048
+            # indices spread over the whole launch - first and last waves, every XCD's share, both pairs of a quad
+            idx = np.unique(np.concatenate([np.arange(64), np.arange(m - 64, m), np.random.default_rng(308).integers(0, m, 1920)]))
+            ti = torch.from_numpy(idx).to(Pd.device)
+            want = oracle.pairing_batch(Pd[ti].cpu().numpy().view(np.uint64), Qd[ti].cpu().numpy().view(np.uint64))
+            assert np.array_equal(out[ti].cpu().numpy().view(np.uint64), want), "four-lane kernels differ from the oracle at n = quad_max"
     e2.profile(False)
     Pn = Pd[:6].cpu().numpy().view(np.uint64); Qn = Qd[:6].cpu().numpy().view(np.uint64)
     assert np.array_equal(ref[:6].cpu().numpy().view(np.uint64), oracle.pairing_batch(Pn, Qn))
