@@ -11,9 +11,9 @@ SOURCES = [HERE / "csrc" / f for f in ("bn254_hip.hip", "bn254_kernels_b.hip", "
 OBJ_DIR = HERE / "csrc" / "build"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # EVERY unit is compiled with LLVM's DPP combiner off: with it on, the quad_perm move of a neighbour lane's limb is folded into the
-# subtraction that consumes it (v_sub_u32_dpp / v_subrev_u32_dpp), and in round 4 a build with such folds in the four-lane Miller kernel
-# returned wrong pairings on the GPU while the unfolded pair of instructions was right (cause not established; csrc/fe.hpp fe_lc4_core).
-# The flag costs nothing (34 folds become moves; profiles/r05_ab_dpp_combine_off.txt); tests/test_build_quality.py checks the result.
+# subtraction that consumes it, and when the DPP value is the SUBTRAHEND the combiner emits v_subrev_u32_dpp d, x, a - which on gfx950 computes
+# dpp(a) - x instead of a - dpp(x) (profiles/r05_dpp_fold_bisect.txt; round 4: every four-lane pairing wrong).  The flag costs nothing (34 harmless
+# folds into v_add_u32 become moves; profiles/r05_ab_dpp_combine_off.txt); tests/test_build_quality.py checks the result.
 DEVICE_FLAGS = ["-mllvm", "-amdgpu-dpp-combine=false"]
 
 _VP = C.c_void_p

@@ -393,11 +393,13 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
     // at most 9 per unit coefficient, and the truncation of FE_MU24, < 2^9 units).
     // The top limb alone: the margin of 9 per unit coefficient covers what limb 7 holds beyond its 29 bits (|.| <= 4 units for limb bound
     // 4; one unit is 3.2e-7 q).  NOTE for whoever touches the build flags: with this form LLVM's DPP combiner folds the quad_perm move of a
-    // neighbour pair's top limb into the subtraction that forms `te` (v_sub_u32_dpp / v_subrev_u32_dpp), and in the four-lane Miller kernel
-    // that code returned wrong values on the GPU (round 4; ROCm 7.2, gfx950; cause not established - the folded instruction in isolation
-    // computes what it should: tools/dpp_fold_check.hip).  The library is therefore built with -mllvm -amdgpu-dpp-combine=false in EVERY
-    // unit (bn_amd/_native.py; free: profiles/r05_ab_dpp_combine_off.txt), tests/test_build_quality.py rejects any DPP instruction other
-    // than v_mov_b32_dpp in the shipped code objects, and a GPU test rebuilds a kernel unit on the box and re-runs the goldens.
+    // neighbour pair's top limb into the subtraction that forms `te` - `v_subrev_u32_dpp d, x, a` where the DPP value is the subtrahend - and on
+    // gfx950 that instruction computes dpp(a) - x, not a - dpp(x): the permutation lands on the operand that becomes the minuend after the
+    // opcode's operand reversal (round 5, profiles/r05_dpp_fold_bisect.txt: one hand-folded instruction in otherwise good assembly makes every
+    // four-lane pairing wrong; tools/variants/dpp_subrev_check.hip shows what it computes).  The library is therefore built with
+    // -mllvm -amdgpu-dpp-combine=false in EVERY unit (bn_amd/_native.py; free: profiles/r05_ab_dpp_combine_off.txt), tests/test_build_quality.py
+    // rejects any DPP instruction other than v_mov_b32_dpp in the shipped code objects, and a GPU test rebuilds kernel units on the box and
+    // re-runs the goldens.
     auto top = [](const Fe &f) -> int32_t { return (int32_t)f.l[8]; };
     const int32_t c2 = neg2 ? -C2 : C2;
     // 32-bit arithmetic (a value below vb q has a top limb below vb * 2^21.6, and the sum of |C| vb is at most 500: checked above):

@@ -144,7 +144,6 @@ BN_FN QFq12<F2> q12_mul_half(const QFq12<F2> &a, Fq6<F2> b, bool conj_b) {
     r.c2 = f2_lc3sw<1, -1, 0>(f2_qpick(aa.c2, f2_ssub(f2_ssub(f2_add(k02, v1), v0), v2)), f2_qpick(f2_neg_lazy(bb.c1), f2_add(aa.c2, bb.c2)), zero);
     return {r};
 }
-template <class F2> BN_COARSE QFq12<F2> q12_mul(const QFq12<F2> &a, const QFq12<F2> &b) { return q12_mul_half(a, b.h, false); }
 template <class F2> BN_OUTER QFq12<F2> q12_mul_o(const QFq12<F2> &a, const QFq12<F2> &b) { return q12_mul_half(a, b.h, false); }
 
 // Granger-Scott (fq12.rs:178-227 as tower.hpp f12_cyclotomic_sqr): the lower pair holds (z0, z4, z3), the upper (z2, z1, z5).  Per Fp4

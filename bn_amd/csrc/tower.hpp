@@ -23,15 +23,11 @@ template <int C1, int C2, int C3, class F2>
 BN_FN Fq6<F2> f6_lc3(const Fq6<F2> &x, const Fq6<F2> &y, const Fq6<F2> &z) {
     return {f2_lc3<C1, C2, C3>(x.c0, y.c0, z.c0), f2_lc3<C1, C2, C3>(x.c1, y.c1, z.c1), f2_lc3<C1, C2, C3>(x.c2, y.c2, z.c2)};
 }
-template <class F2> BN_FN Fq6<F2> f6_add(const Fq6<F2> &a, const Fq6<F2> &b) { return f6_lc3<1, 1, 0>(a, b, b); }
 // a + b in the cheapest form the FIRST operand of f6_mul accepts (lane-pair mapping: carries propagated, not reduced)
 template <class F2> BN_FN Fq6<F2> f6_add_norm(const Fq6<F2> &a, const Fq6<F2> &b) {
     return {f2_sum_for_mul(a.c0, b.c0), f2_sum_for_mul(a.c1, b.c1), f2_sum_for_mul(a.c2, b.c2)};
 }
-template <class F2> BN_FN Fq6<F2> f6_sub(const Fq6<F2> &a, const Fq6<F2> &b) { return f6_lc3<1, -1, 0>(a, b, b); }
 template <class F2> BN_FN Fq6<F2> f6_neg(const Fq6<F2> &a) { return f6_lc3<-1, 0, 0>(a, a, a); }
-// v * x   (fq6.rs:59-65)
-template <class F2> BN_FN Fq6<F2> f6_mul_by_v(const Fq6<F2> &a) { return {f2_mul_xi(a.c2), a.c0, a.c1}; }
 
 // fq6.rs:144-158: 6 Fq2 products (Karatsuba), the two xi-multiplications folded into the final reductions; each output
 // coefficient is finished as soon as its products exist (short live ranges: see f12_mul_by_024)
@@ -305,7 +301,6 @@ BN_COARSE Fq12<F2> f12_cyclotomic_sqr(const Fq12<F2> &f) {
 
 // out-of-line twins for the straight-line (non-loop) callers
 template <class F2> BN_OUTER Fq12<F2> f12_mul_o(const Fq12<F2> &a, const Fq12<F2> &b) { return f12_mul(a, b); }
-template <class F2> BN_OUTER Fq12<F2> f12_cyclotomic_sqr_o(const Fq12<F2> &a) { return f12_cyclotomic_sqr(a); }
 
 #undef F2P
 }  // namespace bn254

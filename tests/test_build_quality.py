@@ -130,8 +130,8 @@ def test_scalar_multiplication_loops_do_not_store_to_scratch():
 def test_only_plain_dpp_moves_and_the_flag_that_guarantees_them():
     """Round 4: when the quotient estimate of the fused reductions read a neighbour pair's top limb directly, LLVM's DPP combiner folded
     the quad_perm move into the subtraction (v_sub_u32_dpp / v_subrev_u32_dpp) and the four-lane Miller kernel returned wrong values for
-    every pairing on the GPU - right again with -mllvm -amdgpu-dpp-combine=false, and the folded instructions themselves compute what they
-    should (tools/dpp_fold_check.hip on the box).  Cause not established, so since round 5 EVERY unit is built with the combiner off
+    every pairing on the GPU - right again with -mllvm -amdgpu-dpp-combine=false.  Round 5 found the cause (profiles/r05_dpp_fold_bisect.txt):
+    on gfx950 `v_subrev_u32_dpp d, x, a` computes dpp(a) - x, not a - dpp(x) as LLVM models it.  Since round 5 EVERY unit is built with the combiner off
     (bn_amd/_native.py DEVICE_FLAGS; free: profiles/r05_ab_dpp_combine_off.txt) and this test - which does not skip: it builds the
     library if it has to - rejects ANY DPP instruction other than the plain v_mov_b32_dpp in the shipped code objects (round 4's regex
     let the same combiner's 34 v_add_u32_dpp through).  tests/test_gpu_soak.py re-runs the goldens on kernel units rebuilt on the GPU box."""

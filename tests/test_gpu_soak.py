@@ -89,3 +89,32 @@ def test_kernel_units_rebuilt_on_the_box_reproduce_the_goldens(tmp_path):
     env = dict(os.environ, BN254_LIB_PATH=str(lib))
     r = subprocess.run([sys.executable, "-c", _GOLDEN_RUNNER, str(ROOT), str(lib)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REBUILT-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_subrev_dpp_semantics_of_this_gpu(tmp_path):
+    """Characterisation, not parity: WHY the library is built with LLVM's DPP combiner off (profiles/r05_dpp_fold_bisect.txt).  On the MI355X
+    boxes of round 5 `v_subrev_u32_dpp d, x, y` computes dpp(y) - x - the lane permutation lands on the operand that becomes the minuend after
+    the opcode's operand reversal - where LLVM's model (and the assembler syntax) say y - dpp(x); GCNDPPCombine emits exactly that instruction
+    when a DPP value is the subtrahend, and one such fold made every four-lane pairing wrong in round 4.  The shipped library contains no DPP
+    instruction other than v_mov_b32_dpp (tests/test_build_quality.py), so NEITHER behaviour affects the product; this test records which one
+    the box under test has: the known quirk passes, the documented behaviour skips with a note (the guard could be revisited there), anything
+    else fails (an unknown third behaviour deserves a look before trusting DPP at all)."""
+    from bn_amd import _native
+    hipcc = shutil.which("hipcc") or _native.HIPCC
+    if not pathlib.Path(hipcc).exists():
+        pytest.skip("no hipcc on this box")
+    exe = tmp_path / "dpp_subrev_check"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", str(ROOT / "tools" / "variants" / "dpp_subrev_check.hip"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120).stdout
+    import re
+    rows = {}
+    for line in out.splitlines():
+        m = re.match(r"(v_\w+)\s+d,.*?(\[[\d,]+\]|\(no DPP\)).*?y - dpp\(x\)\s+(\d+) \| dpp\(x\) - y\s+(\d+) \| dpp\(y\) - x\s+(\d+)", line)
+        if m:
+            rows[(m.group(1), m.group(2))] = tuple(int(x) for x in m.group(3, 4, 5))
+    assert ("v_subrev_u32_dpp", "[1,0,3,2]") in rows and ("v_sub_u32_dpp", "[1,0,3,2]") in rows, out
+    assert rows[("v_sub_u32_dpp", "[1,0,3,2]")][1] == 64, out                    # the plain form: dpp(x) - y, as documented
+    doc, _, quirk = rows[("v_subrev_u32_dpp", "[1,0,3,2]")]
+    if doc == 64:
+        pytest.skip("v_subrev_u32_dpp follows the documented operand order on this box (y - dpp(x)): the round-4 miscompile would not occur here")
+    assert quirk == 64, out

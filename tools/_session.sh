@@ -1,1 +1,1 @@
-python tools/host_api_chunks.py | tee gpurun_out/r05_host_api_chunks.json
+timeout 900 python -m pytest tests/test_gpu_soak.py tests/test_gpu_wave.py -m gpu -q -x 2>&1 | tail -4
