@@ -6,7 +6,7 @@
 //! Results are `==`-equal (and, for `Gt`, byte-equal) to what the crate computes on the CPU.
 extern crate bn;
 
-use bn::{Fr, G1, G2, Gt};
+use bn::{Fr, Group, G1, G2, Gt};          // Group: `zero()` / `one()` of G1 and G2 are trait methods (src/lib.rs:56-77)
 use std::os::raw::{c_int, c_long, c_void};
 
 extern "C" {
@@ -21,6 +21,18 @@ extern "C" {
     fn bn254_g1_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut G1, status: *mut i32, n: usize) -> c_int;
     fn bn254_g2_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut G2, status: *mut i32, n: usize) -> c_int;
     fn bn254_gt_inverse_batch(ctx: *mut c_void, a: *const Gt, out: *mut Gt, n: usize) -> c_int;
+    // prepared-G2 mode (the crate's internal G2Precomp, src/groups/mod.rs:472-483): 102 line coefficients per Q, then many P against them
+    fn bn254_g2_precompute(ctx: *mut c_void, q: *const G2, coeffs: *mut EllCoeffs, n: usize) -> c_int;
+    fn bn254_pairing_prepared_batch(ctx: *mut c_void, p: *const G1, coeffs: *const EllCoeffs, shared: c_int, out: *mut Gt, n: usize) -> c_int;
+    // wire format of the crate's Encodable / Decodable impls (src/groups/mod.rs:143-205, src/fields/fp.rs:24-36), fixed-size records and the stream
+    fn bn254_fr_encode_batch(ctx: *mut c_void, k: *const Fr, out: *mut u8, n: usize) -> c_int;
+    fn bn254_fr_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut Fr, status: *mut i32, n: usize) -> c_int;
+    fn bn254_g1_encode_batch(ctx: *mut c_void, p: *const G1, out: *mut u8, n: usize) -> c_int;
+    fn bn254_g2_encode_batch(ctx: *mut c_void, p: *const G2, out: *mut u8, n: usize) -> c_int;
+    fn bn254_g1_encode_stream(ctx: *mut c_void, p: *const G1, n: usize, out: *mut u8, cap: usize, written: *mut usize) -> c_int;
+    fn bn254_g2_encode_stream(ctx: *mut c_void, p: *const G2, n: usize, out: *mut u8, cap: usize, written: *mut usize) -> c_int;
+    fn bn254_g1_decode_stream(ctx: *mut c_void, bytes: *const u8, len: usize, out: *mut G1, status: *mut i32, max_points: usize, count: *mut usize, consumed: *mut usize) -> c_int;
+    fn bn254_g2_decode_stream(ctx: *mut c_void, bytes: *const u8, len: usize, out: *mut G2, status: *mut i32, max_points: usize, count: *mut usize, consumed: *mut usize) -> c_int;
     // one node, several GPUs (include/bn254_hip.h "bn254_multi"): one context + host thread per device inside the library
     fn bn254_multi_create(devices: *const c_int, ndev: c_int, out: *mut *mut c_void) -> c_int;
     fn bn254_multi_create_ex(devices: *const c_int, ndev: c_int, exchange: c_int, out: *mut *mut c_void) -> c_int;     // -1 auto, 0 peer copies, 1 RCCL
@@ -33,6 +45,18 @@ extern "C" {
     fn bn254_pairing_batch_multi(m: *mut c_void, p: *const G1, q: *const G2, out: *mut Gt, n: usize) -> c_int;
     fn bn254_pairing_product_multi(m: *mut c_void, p: *const G1, q: *const G2, n: usize, out: *mut Gt) -> c_int;
 }
+
+/// One line-function coefficient of a prepared G2 point: the crate's `EllCoeffs { ell_0, ell_vw, ell_vv: Fq2 }` (src/groups/mod.rs:472-476) as the
+/// C ABI lays it out (`bn_ell_coeffs`: three Fq2 = 3 x 8 u64 Montgomery limbs); the crate keeps the type private, so the binding carries its own.
+#[derive(Clone, Copy)]
+#[repr(C)]
+pub struct EllCoeffs { pub ell_0: [u64; 8], pub ell_vw: [u64; 8], pub ell_vv: [u64; 8] }
+/// `BN254_PREPARED_COEFFS` of include/bn254_hip.h: coefficients per prepared point (G2Precomp.coeffs, src/groups/mod.rs:478-483)
+pub const PREPARED_COEFFS: usize = 102;
+/// `BN254_FR_WIRE_BYTES` / `BN254_G1_WIRE_BYTES` / `BN254_G2_WIRE_BYTES`
+pub const FR_WIRE_BYTES: usize = 32;
+pub const G1_WIRE_BYTES: usize = 65;
+pub const G2_WIRE_BYTES: usize = 129;
 
 // Thread safety: every host-buffer entry point of the C ABI may be called from any number of threads on one context (including the
 // process-wide default context behind a NULL ctx), like the crate's own `pairing` (its types are `Send + Sync`,
@@ -129,19 +153,100 @@ pub fn g2_add_batch(a: &[G2], b: &[G2], sub: bool) -> Result<Vec<G2>, GpuError> 
 /// point); `Err(code)` per record carries the crate's error in order of appearance: 1 "integer is not less than modulus",
 /// 2 "integer not less than modulus squared", 3 "invalid leading byte", 4 "point is not on the curve", 5 "point is not in the subgroup"
 pub fn g2_decode_batch(records: &[u8]) -> Result<Vec<Result<G2, i32>>, GpuError> {
-    assert_eq!(records.len() % 129, 0);
-    let n = records.len() / 129;
+    assert_eq!(records.len() % G2_WIRE_BYTES, 0);
+    let n = records.len() / G2_WIRE_BYTES;
     let (mut out, mut status) = (vec![G2::zero(); n], vec![0i32; n]);
     check(unsafe { bn254_g2_decode_batch(std::ptr::null_mut(), records.as_ptr(), out.as_mut_ptr(), status.as_mut_ptr(), n) })?;
     Ok(out.into_iter().zip(status).map(|(p, s)| if s == 0 { Ok(p) } else { Err(s) }).collect())
 }
 
 pub fn g1_decode_batch(records: &[u8]) -> Result<Vec<Result<G1, i32>>, GpuError> {
-    assert_eq!(records.len() % 65, 0);
-    let n = records.len() / 65;
+    assert_eq!(records.len() % G1_WIRE_BYTES, 0);
+    let n = records.len() / G1_WIRE_BYTES;
     let (mut out, mut status) = (vec![G1::zero(); n], vec![0i32; n]);
     check(unsafe { bn254_g1_decode_batch(std::ptr::null_mut(), records.as_ptr(), out.as_mut_ptr(), status.as_mut_ptr(), n) })?;
     Ok(out.into_iter().zip(status).map(|(p, s)| if s == 0 { Ok(p) } else { Err(s) }).collect())
+}
+
+/// `q.to_affine().precompute()` for every q (src/groups/mod.rs:557-588; q must not be infinity): 102 coefficients per point, in schedule order
+pub fn g2_precompute(q: &[G2]) -> Result<Vec<EllCoeffs>, GpuError> {
+    let mut out = vec![EllCoeffs { ell_0: [0; 8], ell_vw: [0; 8], ell_vv: [0; 8] }; q.len() * PREPARED_COEFFS];
+    check(unsafe { bn254_g2_precompute(std::ptr::null_mut(), q.as_ptr(), out.as_mut_ptr(), q.len()) })?;
+    Ok(out)
+}
+
+/// `final_exponentiation(prepared.miller_loop(p[i]))` (src/groups/mod.rs:486-519, 768) against ONE prepared point (`coeffs.len() == 102`) or one
+/// per p (`coeffs.len() == 102 * p.len()`)
+pub fn pairing_prepared_batch(p: &[G1], coeffs: &[EllCoeffs]) -> Result<Vec<Gt>, GpuError> {
+    let shared = coeffs.len() == PREPARED_COEFFS;
+    assert!(shared || coeffs.len() == PREPARED_COEFFS * p.len());
+    let mut out = vec![Gt::one(); p.len()];
+    check(unsafe { bn254_pairing_prepared_batch(std::ptr::null_mut(), p.as_ptr(), coeffs.as_ptr(), shared as c_int, out.as_mut_ptr(), p.len()) })?;
+    Ok(out)
+}
+
+/// the crate's `Encodable for Fr` (src/fields/fp.rs:24-36): 32 big-endian bytes per scalar
+pub fn fr_encode_batch(k: &[Fr]) -> Result<Vec<u8>, GpuError> {
+    let mut out = vec![0u8; k.len() * FR_WIRE_BYTES];
+    check(unsafe { bn254_fr_encode_batch(std::ptr::null_mut(), k.as_ptr(), out.as_mut_ptr(), k.len()) })?;
+    Ok(out)
+}
+
+/// `Decodable for Fr`: `Err(1)` = "integer is not less than modulus"
+pub fn fr_decode_batch(records: &[u8]) -> Result<Vec<Result<Fr, i32>>, GpuError> {
+    assert_eq!(records.len() % FR_WIRE_BYTES, 0);
+    let n = records.len() / FR_WIRE_BYTES;
+    let (mut out, mut status) = (vec![Fr::zero(); n], vec![0i32; n]);
+    check(unsafe { bn254_fr_decode_batch(std::ptr::null_mut(), records.as_ptr(), out.as_mut_ptr(), status.as_mut_ptr(), n) })?;
+    Ok(out.into_iter().zip(status).map(|(k, s)| if s == 0 { Ok(k) } else { Err(s) }).collect())
+}
+
+/// fixed-size records `[4][x][y]` (infinity: tag 0 and padding), 65 bytes per G1 point
+pub fn g1_encode_batch(p: &[G1]) -> Result<Vec<u8>, GpuError> {
+    let mut out = vec![0u8; p.len() * G1_WIRE_BYTES];
+    check(unsafe { bn254_g1_encode_batch(std::ptr::null_mut(), p.as_ptr(), out.as_mut_ptr(), p.len()) })?;
+    Ok(out)
+}
+
+pub fn g2_encode_batch(p: &[G2]) -> Result<Vec<u8>, GpuError> {
+    let mut out = vec![0u8; p.len() * G2_WIRE_BYTES];
+    check(unsafe { bn254_g2_encode_batch(std::ptr::null_mut(), p.as_ptr(), out.as_mut_ptr(), p.len()) })?;
+    Ok(out)
+}
+
+/// the crate's own variable-length stream (what `bincode::encode` yields for a sequence of points: infinity is the lone byte 0)
+pub fn g1_encode_stream(p: &[G1]) -> Result<Vec<u8>, GpuError> {
+    let mut out = vec![0u8; p.len() * G1_WIRE_BYTES];
+    let mut written = 0usize;
+    check(unsafe { bn254_g1_encode_stream(std::ptr::null_mut(), p.as_ptr(), p.len(), out.as_mut_ptr(), out.len(), &mut written) })?;
+    out.truncate(written);
+    Ok(out)
+}
+
+pub fn g2_encode_stream(p: &[G2]) -> Result<Vec<u8>, GpuError> {
+    let mut out = vec![0u8; p.len() * G2_WIRE_BYTES];
+    let mut written = 0usize;
+    check(unsafe { bn254_g2_encode_stream(std::ptr::null_mut(), p.as_ptr(), p.len(), out.as_mut_ptr(), out.len(), &mut written) })?;
+    out.truncate(written);
+    Ok(out)
+}
+
+/// up to `max_points` points from the crate's stream format; returns the points (a rejected record comes back as `Err(status)`, the decoder
+/// goes on with the next record unless `GpuOption::StreamStopAtError` is set) and the number of bytes consumed
+pub fn g1_decode_stream(bytes: &[u8], max_points: usize) -> Result<(Vec<Result<G1, i32>>, usize), GpuError> {
+    let (mut out, mut status) = (vec![G1::zero(); max_points], vec![0i32; max_points]);
+    let (mut count, mut consumed) = (0usize, 0usize);
+    check(unsafe { bn254_g1_decode_stream(std::ptr::null_mut(), bytes.as_ptr(), bytes.len(), out.as_mut_ptr(), status.as_mut_ptr(), max_points, &mut count, &mut consumed) })?;
+    out.truncate(count); status.truncate(count);
+    Ok((out.into_iter().zip(status).map(|(p, s)| if s == 0 { Ok(p) } else { Err(s) }).collect(), consumed))
+}
+
+pub fn g2_decode_stream(bytes: &[u8], max_points: usize) -> Result<(Vec<Result<G2, i32>>, usize), GpuError> {
+    let (mut out, mut status) = (vec![G2::zero(); max_points], vec![0i32; max_points]);
+    let (mut count, mut consumed) = (0usize, 0usize);
+    check(unsafe { bn254_g2_decode_stream(std::ptr::null_mut(), bytes.as_ptr(), bytes.len(), out.as_mut_ptr(), status.as_mut_ptr(), max_points, &mut count, &mut consumed) })?;
+    out.truncate(count); status.truncate(count);
+    Ok((out.into_iter().zip(status).map(|(p, s)| if s == 0 { Ok(p) } else { Err(s) }).collect(), consumed))
 }
 
 #[cfg(test)]

@@ -143,11 +143,25 @@ def test_header_parses_completely():
 
 def test_rust_crate_matches_header():
     rust = rust_declarations(RUST_LIB.read_text())
-    assert len(rust) >= 20, sorted(rust)
+    assert len(rust) >= 30, sorted(rust)
     assert compare(c_declarations(), rust, "bindings/rust/src/lib.rs") == []
     # every function the crate's wrappers call is declared in its extern block
-    called = set(re.findall(r"\b(bn254_\w+)\s*\(", RUST_LIB.read_text()))
+    txt = RUST_LIB.read_text()
+    called = set(re.findall(r"\b(bn254_\w+)\s*\(", txt))
     assert called <= set(rust), called - set(rust)
+    # what the wrappers use of the crate exists there under that name and kind (checked against the reference when it is mounted: the
+    # compiler is not available, a grep is): G1 / G2 `zero()` and `one()` are methods of the trait `Group`, which must then be imported;
+    # Fr::zero / Gt::one are inherent
+    imported = set(re.search(r"use bn::\{([^}]*)\}", txt).group(1).replace(" ", "").split(","))
+    assert {"Fr", "G1", "G2", "Gt"} <= imported
+    if re.search(r"\bG[12]::(zero|one)\(", txt):
+        assert "Group" in imported, "G1::zero() / G2::one() need `use bn::Group`"
+    ref = pathlib.Path("/root/reference/src/lib.rs")
+    if ref.exists():
+        rtxt = ref.read_text()
+        assert re.search(r"pub trait Group", rtxt) and "impl Group for G1" in rtxt and "impl Group for G2" in rtxt
+        for inherent in ("pub fn zero() -> Self { Fr(", "pub fn one() -> Self { Gt("):
+            assert inherent in rtxt, inherent
 
 
 def test_integration_md_snippets_match_header():
@@ -166,9 +180,13 @@ def test_option_and_exchange_discriminants():
     from bn_amd import _native
     assert {k.upper(): v for k, v in _native.OPTIONS.items()} == {k: v for k, v in c_enum("BN254_OPT_").items() if not k.endswith("_")}
     assert {k.upper(): v for k, v in _native.EXCHANGE.items()} == ex
-    # record sizes the wrappers hard-code
-    sizes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define BN254_(G[12])_WIRE_BYTES (\d+)", HEADER.read_text())}
-    assert f"% {sizes['G1']}" in txt and f"% {sizes['G2']}" in txt
+    # record sizes and the coefficient count the wrappers carry as constants
+    sizes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define BN254_(\w+?)(?:_WIRE_BYTES)? (\d+)", HEADER.read_text())}
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (\w+): usize = (\d+);", txt)}
+    assert consts == {"PREPARED_COEFFS": sizes["PREPARED_COEFFS"], "FR_WIRE_BYTES": sizes["FR"], "G1_WIRE_BYTES": sizes["G1"], "G2_WIRE_BYTES": sizes["G2"]}, (consts, sizes)
+    # the binding's own EllCoeffs mirrors bn_ell_coeffs: three arrays of 8 u64, in the header's order
+    m = re.search(r"pub struct EllCoeffs \{([^}]*)\}", txt)
+    assert m and re.findall(r"pub (\w+): \[u64; 8\]", m.group(1)) == re.search(r"typedef struct \{ uint64_t ([^;]*); \} bn_ell_coeffs", HEADER.read_text()).group(1).replace("[8]", "").split(", ")
 
 
 def test_ctypes_table_matches_header():
