@@ -159,6 +159,8 @@ def test_options_api(eng):
             pass
     assert eng.get_option("wave_fe_max") == 99 and eng.get_option("quad_max") == 64 * cus and eng.get_option("miller_shared") == 0
     eng.set_option("wave_fe_max", None)
+    # bn254_ctx_set_mapping is kept for ABI compatibility: 1 is the only mapping, the one-lane test double (0) left the library in round 5
+    assert eng._lib.bn254_ctx_set_mapping(eng._h, 1) == 0 and eng._lib.bn254_ctx_set_mapping(eng._h, 0) == -2
 
 
 def test_pairing_batch_matches_oracle(oracle, eng):
