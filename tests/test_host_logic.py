@@ -30,6 +30,26 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.bn254_error_string(-1).decode().startswith("no usable HIP device")
 
 
+def test_test_double_builds_and_stays_out_of_the_product():
+    """tests/testdouble/: the one-lane-per-pairing kernels (a second GPU implementation for the parity tests) cross-compile for gfx950, export
+    their five entry points - and the PRODUCT library holds none of them: no *_A kernel, no one-lane scalar-multiplication kernel"""
+    import ctypes
+    import testdouble
+    lib = ctypes.CDLL(str(testdouble.build()))
+    for name in ("bntd_miller", "bntd_final_exp", "bntd_gt_product", "bntd_g1_mul", "bntd_g2_mul"):
+        assert hasattr(lib, name)
+    sys.path.insert(0, str(ROOT / "tools"))
+    import kernel_meta
+    from bn_amd import _native
+    product = set(kernel_meta.kernel_meta(_native.build()))
+    assert not [k for k in product if k.endswith("_A") or k in ("bn254_g1_mul_k", "bn254_g2_mul_k")], product
+    assert set(kernel_meta.kernel_meta(testdouble.LIB)) == {"bntd_miller_A", "bntd_final_exp_A", "bntd_gt_product_A", "bntd_g1_mul_k", "bntd_g2_mul_k"}
+    # nothing under bn_amd/ refers to the test double or to the oracle
+    for f in (ROOT / "bn_amd").rglob("*.py"):
+        txt = f.read_text()
+        assert "testdouble" not in txt and "bn_oracle" not in txt and "hostsim" not in txt, f
+
+
 def test_fails_loudly_without_gpu():
     import bn_amd
     from bn_amd import _native
