@@ -317,25 +317,49 @@ def bench_product(args, eng, dev, world, rank):
                                {"kernel_ms_per_step": kms, "kernel_traffic": ktr, "expected_scaling": expected_scaling("product", world)}, {"process_group": (dist.get_backend() if dist.is_initialized() else None)})), flush=True)
 
 
+def run_prepared(eng, dev, dist, P, Q, n, mode, steps, warmup):
+    """n pairings of the P against ONE prepared Q (the first of Q).  mode "native": the device-native table of bn254_g2_prepare (88 lines of
+    the engine's own schedule as ready multiplier operands, 33.8 KB per Q); "reference": the reference image of G2Precomp (bn_ell_coeffs,
+    102 x 192 B: groups/mod.rs:472-483) converted by every lane at every line - kept for the reference's known answers.  Returns the wall
+    time of `steps` steps, the roofline object of the Miller kernel and the per-kernel milliseconds."""
+    out = eng.empty(n, 48)
+    if mode == "native":
+        prep = eng.e.g2_prepare_dev(Q.data_ptr(), 1, eng._stream())
+        step = lambda: eng.e.pairing_prepared_native_dev(P.data_ptr(), prep, out.data_ptr(), n, stream=eng._stream())
+        kname = "miller_native"
+    else:
+        coeffs = eng.empty(102, 24)
+        eng.e.g2_precompute_dev(Q.data_ptr(), coeffs.data_ptr(), 1, eng._stream())
+
+        def step():
+            eng.e.miller_prepared_dev(P.data_ptr(), coeffs.data_ptr(), True, out.data_ptr(), n, eng._stream())
+            eng.e.final_exp_batch_dev(out.data_ptr(), out.data_ptr(), n, eng._stream())
+        kname = "miller_prepared"
+    elapsed = timed_steps(dist, dev, step, steps, warmup)
+    ks = min(steps, 5)
+    st = kernel_times(eng, dev, step, (kname, "final_exp"), ks)
+    # the Miller kernel priced over the chain it EXECUTES (host-simulation count, profiles/executed_chain_lengths.json) - the convention of
+    # the side kernels; `frac_vs_reference_chain`: over the reference's miller_loop (groups/mod.rs:486-519: 11 952 multiplications as written)
+    rf = roofline(eng, {kname: st[kname]}, n, FQMUL_OWN[kname] * MAC32_PER_FQMUL, steps=ks, ref_mac32_per_unit=11952 * MAC32_PER_FQMUL)
+    if mode == "native":
+        prep.close()
+    return elapsed, rf, {k: v[0] / max(v[1], 1) for k, v in st.items()}
+
+
 def bench_prepared(args, eng, dev, world, rank):
-    """side metric: prepared-G2 mode - 2^16 pairings of random P against ONE precomputed Q per GPU per step"""
+    """side metric: prepared-G2 mode - 2^16 pairings of random P against ONE prepared Q per GPU per step"""
     import torch.distributed as dist
     from bn_amd import distributed as D
     n = args.batch or BATCH
     P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
-    coeffs = eng.empty(102, 24)
-    eng.e.g2_precompute_dev(Q.data_ptr(), coeffs.data_ptr(), 1, eng._stream())
-    out = eng.empty(n, 48)
-
-    def step():
-        eng.e.miller_prepared_dev(P.data_ptr(), coeffs.data_ptr(), True, out.data_ptr(), n, eng._stream())
-        eng.e.final_exp_batch_dev(out.data_ptr(), out.data_ptr(), n, eng._stream())
-    elapsed = timed_steps(dist, dev, step, args.steps, args.warmup)
+    mode = args.prepared_mode
+    elapsed, rf, kms = run_prepared(eng, dev, dist, P, Q, n, mode, args.steps, args.warmup)
     if rank == 0:
-        st = kernel_times(eng, dev, step, ("miller_prepared", "final_exp"), min(args.steps, 5))
+        what = ("one device-native table (88 lines x 384 B, bn254_g2_prepare) read by all lanes" if mode == "native"
+                else "102 x 192 B reference-image coefficients (bn254_g2_precompute) shared by all lanes")
         print(json.dumps(_line("BN254 pairings/sec against one prepared G2 point (bit-exact vs ref)", "pairings/s", world * n * args.steps / elapsed,
-                               world, args, elapsed, "weak", f"{n} random P against one precomputed Q (102 x 192 B coefficients shared by all lanes)",
-                               {"kernel_ms": {k: v[0] / max(v[1], 1) for k, v in st.items()}})), flush=True)
+                               world, args, elapsed, "weak", f"{n} random P against one prepared Q: {what}",
+                               {"roofline": rf, "kernel_ms": kms}, {"prepared_mode": mode})), flush=True)
 
 
 def side_object(eng, dev, dist, P16, Q16):
@@ -450,6 +474,8 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the `side` object (configs[3], configs[4], single-pairing latency) of the default line")
     ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product"], default="pairing",
                     help="pairing: the headline metric (default); the others are side metrics with their own line")
+    ap.add_argument("--prepared-mode", choices=["native", "reference"], default="native",
+                    help="--workload prepared: the device-native table of bn254_g2_prepare (default) or the reference-image coefficients")
     ap.add_argument("--mode", choices=["dist", "multi_c"], default="dist",
                     help="dist (default, what the driver runs): one process per GPU over torch.distributed/RCCL, inputs resident in HBM; "
                          "multi_c: ONE host process drives all GPUs through bn254_*_multi of the C ABI (host buffers, PCIe inclusive)")

@@ -47,6 +47,15 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_pairing_prepared_batch": [_VP, _VP, _VP, C.c_int, _VP, _SZ],
     "bn254_g2_precompute_dev": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_miller_prepared_dev": [_VP, _VP, _VP, C.c_int, _VP, _SZ, _VP],
+    "bn254_g2_prepare": [_VP, _VP, _SZ, C.POINTER(_VP)],
+    "bn254_g2_prepare_dev": [_VP, _VP, _SZ, C.POINTER(_VP), _VP],
+    "bn254_g2_prepared_destroy": [_VP],
+    "bn254_g2_prepared_count": [_VP],
+    "bn254_g2_prepared_bytes": [_VP],
+    "bn254_g2_prepared_export": [_VP, _VP, _VP, _SZ],
+    "bn254_pairing_prepared_native_batch": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_miller_prepared_native_dev": [_VP, _VP, _VP, _SZ, _VP, _SZ, _VP],
+    "bn254_pairing_prepared_native_batch_dev": [_VP, _VP, _VP, _SZ, _VP, _SZ, _VP],
     "bn254_gt_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_gt_pow_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_gt_inverse_batch": [_VP, _VP, _VP, _SZ],
@@ -163,6 +172,9 @@ def lib():
         l.bn254_error_string.restype = C.c_char_p
         l.bn254_ctx_destroy.restype = None
         l.bn254_multi_destroy.restype = None
+        l.bn254_g2_prepared_destroy.restype = None
+        l.bn254_g2_prepared_count.restype = C.c_size_t
+        l.bn254_g2_prepared_bytes.restype = C.c_size_t
         l.bn254_multi_ctx.restype = C.c_void_p
         _lib = l
     return _lib

@@ -1,5 +1,6 @@
 // MI355X (gfx950) kernels and the C ABI of the batched BN254 pairing engine (include/bn254_hip.h).
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC bn254_hip.hip -o libbn254_hip.so
+// Built by bn_amd/_native.py build(): hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-dpp-combine=false -c <each unit>, then one
+// -shared link.  The -mllvm flag is REQUIRED in every unit (fe.hpp fe_lc4_core: a DPP fold into a reversed subtraction computes the wrong value on gfx950).
 //
 // This unit holds the host side (contexts, options, launch policy: which of the wave / four-lane / lane-pair kernels of the other units runs a
 // call) and the wire-format kernels (one record per lane).  The pairing and scalar-multiplication kernels live in bn254_kernels_{b,q,w,mul}.hip.
@@ -538,6 +539,64 @@ int bn254_miller_prepared_dev(bn254_ctx *ctx, const void *d_p, const void *d_coe
     BnScope sc(ctx, s, "miller_prepared");
     return bn254_launch_miller_prepared_B(d_p, d_coeffs, shared, d_f, n, s);
 }
+// ---- native prepared-G2 mode (include/bn254_hip.h): the handle owns its table; one launch addresses it with 32-bit columns (2 per point)
+constexpr size_t BN_PREPARED_MAX = (size_t)1 << 22;
+int bn254_g2_prepare_dev(bn254_ctx *ctx, const void *d_q, size_t nq, bn254_g2_prepared **out, void *stream) {
+    if (!out) return BN254_E_BAD_ARG;
+    *out = nullptr;
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (!d_q || nq == 0 || nq > BN_PREPARED_MAX) return BN254_E_BAD_ARG;
+    BnDeviceGuard dev_guard;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    bn254_g2_prepared *h = new (std::nothrow) bn254_g2_prepared();
+    if (!h) return BN254_E_ALLOC;
+    h->device = ctx->device; h->nq = nq; h->bytes = bn254_native_table_bytes_B(nq);
+    if (hipMalloc(&h->table, h->bytes) != hipSuccess) { delete h; return BN254_E_ALLOC; }
+    if (hipMalloc(&h->inf, nq * sizeof(uint32_t)) != hipSuccess) { hipFree(h->table); delete h; return BN254_E_ALLOC; }
+    {
+        BnScope sc(ctx, s, "g2_prepare_native");
+        rc = bn254_launch_g2_prepare_native_B(d_q, h->table, h->inf, nq, s);
+    }
+    if (rc) { hipFree(h->table); hipFree(h->inf); delete h; return rc; }
+    *out = h;
+    return BN254_OK;
+}
+void bn254_g2_prepared_destroy(bn254_g2_prepared *h) {
+    if (!h) return;
+    BnDeviceGuard dev_guard;
+    hipSetDevice(h->device);
+    hipFree(h->table); hipFree(h->inf);
+    delete h;
+}
+size_t bn254_g2_prepared_count(const bn254_g2_prepared *h) { return h ? h->nq : 0; }
+size_t bn254_g2_prepared_bytes(const bn254_g2_prepared *h) { return h ? h->bytes + h->nq * sizeof(uint32_t) : 0; }
+// p[i] against point (nq == 1 ? 0 : q_first + i): sub-launches of at most one machine round, like the fused Miller loop
+static int bn_launch_miller_native(bn254_ctx *c, const void *p, const bn254_g2_prepared *h, size_t q_first, void *f, size_t n, hipStream_t s) {
+    const int shared = h->nq == 1;
+    const size_t step = bn_sub_launch(c, n);
+    for (size_t lo = 0; lo < n; lo += step) {
+        const size_t cnt = n - lo < step ? n - lo : step;
+        BnScope sc(c, s, "miller_native");
+        int rc = bn254_launch_miller_native_B((const char *)p + lo * sizeof(bn_g1), h->table, h->inf, h->nq, shared ? 0 : q_first + lo, shared, (char *)f + lo * sizeof(bn_gt), cnt, s);
+        if (rc) return rc;
+    }
+    return BN254_OK;
+}
+#define BN_PREP_CHECK()                                                                                              \
+    if (!prep || prep->device != ctx->device || (prep->nq != 1 && (q_first > prep->nq || n > prep->nq - q_first))) return BN254_E_BAD_ARG
+int bn254_miller_prepared_native_dev(bn254_ctx *ctx, const void *d_p, const bn254_g2_prepared *prep, size_t q_first, void *d_f, size_t n, void *stream) {
+    BN_DEV_PROLOGUE(!d_p || !d_f, BN_N_MAX);
+    BN_PREP_CHECK();
+    return bn_launch_miller_native(ctx, d_p, prep, q_first, d_f, n, s);
+}
+int bn254_pairing_prepared_native_batch_dev(bn254_ctx *ctx, const void *d_p, const bn254_g2_prepared *prep, size_t q_first, void *d_out, size_t n, void *stream) {
+    BN_DEV_PROLOGUE(!d_p || !d_out, BN_N_MAX);
+    BN_PREP_CHECK();
+    BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
+    rc = bn_launch_miller_native(ctx, d_p, prep, q_first, d_out, n, s); if (rc) return rc;
+    return bn_launch_final_exp(ctx, d_out, d_out, n, s, nullptr);
+}
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream) {
     BN_DEV_PROLOGUE(!d_a || !d_b || !d_out, BN_N_MAX);
     return bn_for_parts(n, BN_LAUNCH_MAX, [&](size_t lo, size_t cnt) -> int {
@@ -645,6 +704,39 @@ int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_co
     HIP_TRY(hipMemcpyAsync(dc.p, coeffs, cb, hipMemcpyHostToDevice, ctx->stream));
     rc = bn254_miller_prepared_dev(ctx, dp.p, dc.p, shared, dout.p, n, ctx->stream); if (rc) return rc;
     rc = bn254_final_exp_batch_dev(ctx, dout.p, dout.p, n, ctx->stream); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_g2_prepare(bn254_ctx *ctx, const bn_g2 *q, size_t nq, bn254_g2_prepared **out) {
+    if (!out) return BN254_E_BAD_ARG;
+    *out = nullptr;
+    if (!q || nq == 0 || nq > BN_PREPARED_MAX) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    BnBuf &dq = ctx->stage[0];
+    if ((rc = dq.reserve(nq * sizeof(bn_g2)))) return rc;
+    HIP_TRY(hipMemcpyAsync(dq.p, q, nq * sizeof(bn_g2), hipMemcpyHostToDevice, ctx->stream));
+    rc = bn254_g2_prepare_dev(ctx, dq.p, nq, out, ctx->stream); if (rc) return rc;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { bn254_g2_prepared_destroy(*out); *out = nullptr; return (int)e; }
+    return BN254_OK;
+}
+int bn254_g2_prepared_export(bn254_ctx *ctx, const bn254_g2_prepared *prep, void *host_table, size_t bytes) {
+    if (!prep || !host_table || bytes != prep->bytes) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    if (prep->device != ctx->device) return BN254_E_BAD_ARG;
+    HIP_TRY(hipMemcpyAsync(host_table, prep->table, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_pairing_prepared_native_batch(bn254_ctx *ctx, const bn_g1 *p, const bn254_g2_prepared *prep, bn_gt *out, size_t n) {
+    if (n == 0) return BN254_OK;
+    if (!p || !prep || !out || n > BN_N_MAX) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    BnBuf &dp = ctx->stage[0], &dout = ctx->stage[2];
+    if ((rc = dp.reserve(n * sizeof(bn_g1))) || (rc = dout.reserve(n * sizeof(bn_gt)))) return rc;
+    HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
+    rc = bn254_pairing_prepared_native_batch_dev(ctx, dp.p, prep, 0, dout.p, n, ctx->stream); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;

@@ -297,6 +297,125 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     if (live) f12_store(f, f_out + 96u * pair);
 }
 
+// ---- NATIVE prepared-G2 mode (pairing.hpp precompute_native / miller_loop_native): NATIVE_LINES records per Q, one record = 12 x 16 bytes per
+// lane of the pair: groups 0-6 hold A (this lane's component), xi B u, xi B v (27 dwords + 1 pad), groups 7-11 B u, B v (18 + 2 pad), all in the
+// 9 x 29-bit radix-2^261 limbs the multiplier takes.  Group-major, then the column (2 x Q index + lane parity): with one table per pairing a
+// wave's access is one coalesced dwordx4 instruction over 1 KB; with ONE shared Q every lane of a parity reads the same 16 bytes (stride 2
+// columns: a broadcast out of the L1 / L2, 33.8 KB per Q for the whole launch).  33 792 B per Q.
+constexpr int NATIVE_GROUPS = 12;
+struct NativeTableMem {
+    uint4 *base;             // wave-uniform
+    uint32_t col, stride;    // this lane's column, columns in the table (2 x number of Q)
+    __device__ __forceinline__ uint4 *row(int line, int g) const { return base + (size_t)(uint32_t)(line * NATIVE_GROUPS + g) * stride; }
+    template <int N, int G0>
+    __device__ __forceinline__ void st_n(int line, const Fe *v) const {
+        uint32_t w[((9 * N + 3) / 4) * 4];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int l = 0; l < 9; ++l) w[9 * k + l] = v[k].l[l];
+#pragma unroll
+        for (int l = 9 * N; l < ((9 * N + 3) / 4) * 4; ++l) w[l] = 0;
+#pragma unroll
+        for (int g = 0; g < (9 * N + 3) / 4; ++g) row(line, G0 + g)[col] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+    }
+    template <int N, int G0>
+    __device__ __forceinline__ void ld_n(int line, Fe *v) const {
+        uint32_t w[((9 * N + 3) / 4) * 4];
+#pragma unroll
+        for (int g = 0; g < (9 * N + 3) / 4; ++g) {
+            const uint4 x = row(line, G0 + g)[col];
+            w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int l = 0; l < 9; ++l) v[k].l[l] = w[9 * k + l];
+    }
+    // between the two passes of precompute_native a record parks ell_0, d, c (groups 0-6) and the running product of the d (groups 7-9)
+    __device__ __forceinline__ void put_raw(int i, const F2 &e0, const F2 &d, const F2 &c, const F2 &pref) const {
+        Fe t[3] = {e0.v, d.v, c.v}; st_n<3, 0>(i, t);
+        st_n<1, 7>(i, &pref.v);
+    }
+    __device__ __forceinline__ void get_raw(int i, F2 &e0, F2 &d, F2 &c) const { Fe t[3]; ld_n<3, 0>(i, t); e0.v = t[0]; d.v = t[1]; c.v = t[2]; }
+    __device__ __forceinline__ F2 get_prefix(int i) const { Fe t; ld_n<1, 7>(i, &t); return {t}; }
+    __device__ __forceinline__ void put_final(int i, const Fe &a, const Fq2BPrep<Fe> &b, const Fq2BPrep<Fe> &xb) const {
+        Fe t[3] = {a, xb.u, xb.v}; st_n<3, 0>(i, t);
+        Fe u[2] = {b.u, b.v}; st_n<2, 7>(i, u);
+    }
+};
+// table[.., 2 pair + lane] <- the native lines of q[pair]; q_inf[pair] <- (q[pair] is infinity: the pairing is then one, groups/mod.rs:766).
+// Not a hot path: one launch per set of Q, ~0.5 Miller loops of work per Q (two passes around ONE inversion).  Lanes beyond n repeat the last
+// pair and store the same bytes to the same addresses (every lane re-reads only what it wrote itself).
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_g2_prepare_native_B(const uint32_t *g2, uint4 *table, uint32_t stride, uint32_t *q_inf, uint32_t n) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    if (pair >= n) pair = n - 1;
+    const uint32_t *w2 = g2 + 48u * pair;
+    if ((threadIdx.x & 1u) == 0) q_inf[pair] = words_all_zero(w2 + 32, 16) ? 1u : 0u;
+    G2Aff<F2> q = g2_to_affine(f2_load((const F2 *)nullptr, w2), f2_load((const F2 *)nullptr, w2 + 16), f2_load((const F2 *)nullptr, w2 + 32));
+    NativeTableMem st = {table, 2u * pair + (threadIdx.x & 1u), stride};
+    precompute_native(q, st);
+}
+// f[i] = Miller value of (p[i], Q) over the native table (pairing.hpp miller_loop_native): only ever meets a final exponentiation.
+// shared != 0: every pairing reads column pair 0; else pairing i reads the table of Q number q_lo + i.
+// Per pairing in LDS ([dword][lane], like the fused loop's parked state): sigma, tau, 9 tau, -+tau = 36 dwords per lane, 9 KB per wave.
+struct NativeLineMem {
+    const uint4 *base;
+    uint32_t col, stride;
+    uint32_t *lds;           // this lane's column of the block's LDS array
+    int line;
+    mutable Fe xbu, xbv;     // fetched together with A (same 16-byte groups)
+    __device__ __forceinline__ Fe ld_lds(int slot) const {
+        Fe v;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v.l[i] = lds[(slot * 9 + i) * BLOCK];
+        return v;
+    }
+    __device__ __forceinline__ void st_lds(int slot, const Fe &v) const {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) lds[(slot * 9 + i) * BLOCK] = v.l[i];
+    }
+    __device__ __forceinline__ void set_line(int i) { line = i; }
+    __device__ __forceinline__ Fq2BPrep<Fe> x0() const {
+        const NativeTableMem t = {const_cast<uint4 *>(base), col, stride};
+        Fe v[3];
+        t.ld_n<3, 0>(line, v);
+        xbu = v[1]; xbv = v[2];
+        return f2b_prepare(F2{fe_mul(v[0], ld_lds(0))});
+    }
+    __device__ __forceinline__ Fq2BPrep<Fe> xb() const { return {xbu, xbv}; }
+    __device__ __forceinline__ Fq2BPrep<Fe> b() const {
+        const NativeTableMem t = {const_cast<uint4 *>(base), col, stride};
+        Fe v[2];
+        t.ld_n<2, 7>(line, v);
+        return {v[0], v[1]};
+    }
+    __device__ __forceinline__ Fe tau() const { return ld_lds(1); }
+    __device__ __forceinline__ Fe tau9() const { return ld_lds(2); }
+    __device__ __forceinline__ Fe taum() const { return ld_lds(3); }
+};
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_native_B(const uint32_t *g1, const uint4 *table, uint32_t stride, uint32_t q_lo, int shared, const uint32_t *q_inf, uint32_t *f_out, uint32_t n) {
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t pair = t >> 1;
+    bool live = pair < n;
+    if (!live) pair = n - 1;
+    const uint32_t *w1 = g1 + 24u * pair;
+    const uint32_t qi = shared ? 0u : q_lo + pair;
+    const bool inf = words_all_zero(w1 + 16, 8) || q_inf[qi] != 0u;                 // groups/mod.rs:766
+    __shared__ uint32_t park[36 * BLOCK];
+    NativeLineMem src = {table, 2u * qi + (threadIdx.x & 1u), stride, park + threadIdx.x, 0, {}, {}};
+    {
+        const PNative<Fe> pn = p_native(f2_scalar_load((const F2 *)nullptr, w1), f2_scalar_load((const F2 *)nullptr, w1 + 8), f2_scalar_load((const F2 *)nullptr, w1 + 16));
+        src.st_lds(0, pn.sigma); src.st_lds(1, pn.tau); src.st_lds(2, pn.tau9); src.st_lds(3, pn.taum);
+    }
+    Fq12<F2> f = miller_loop_native<F2>(src);
+    Fq12<F2> one = f12_one<F2>();
+    f.c0.c0 = f2_select(inf, f.c0.c0, one.c0.c0); f.c0.c1 = f2_select(inf, f.c0.c1, one.c0.c1); f.c0.c2 = f2_select(inf, f.c0.c2, one.c0.c2);
+    f.c1.c0 = f2_select(inf, f.c1.c0, one.c1.c0); f.c1.c1 = f2_select(inf, f.c1.c1, one.c1.c1); f.c1.c2 = f2_select(inf, f.c1.c2, one.c1.c2);
+    if (live) f12_store(f, f_out + 96u * pair);
+}
+
 // out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
         uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
@@ -432,6 +551,21 @@ int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(bn254_miller_prepared_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint32_t *)coeffs,
                        (uint32_t)(shared ? 0 : NCOEFF * COEFF_WORDS), (uint32_t *)f, (uint32_t)n);
+    return (int)hipGetLastError();
+}
+size_t bn254_native_table_bytes_B(size_t nq) { return nq * (size_t)NATIVE_LINES * NATIVE_GROUPS * 2 * sizeof(uint4); }
+int bn254_native_lines_B(void) { return NATIVE_LINES; }
+// table: bn254_native_table_bytes_B(nq) bytes for nq points, q_inf: nq words
+int bn254_launch_g2_prepare_native_B(const void *q, void *table, void *q_inf, size_t nq, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * nq + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_g2_prepare_native_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)q, (uint4 *)table, (uint32_t)(2 * nq), (uint32_t *)q_inf, (uint32_t)nq);
+    return (int)hipGetLastError();
+}
+// nq: points in the table (its stride); shared: every p[i] against point 0, else p[i] against point q_lo + i
+int bn254_launch_miller_native_B(const void *p, const void *table, const void *q_inf, size_t nq, size_t q_lo, int shared, void *f, size_t n, hipStream_t s) {
+    unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(bn254_miller_native_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint4 *)table, (uint32_t)(2 * nq), (uint32_t)q_lo, shared ? 1 : 0,
+                       (const uint32_t *)q_inf, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
 int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s) {

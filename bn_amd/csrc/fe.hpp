@@ -751,6 +751,57 @@ BN_FN Fe fe_mul6(const Fe &a1, const Fe &u1, const Fe &c1, const Fe &v1, const F
     return r;
 }
 
+// (a1 u1 + c1 v1 + a2 u2 + c2 v2 + a3 u3) / R with ONE reduction: 405 + 81 mads.  Two Fq2 products of the lane-pair mapping plus ONE product of
+// this lane's component by a scalar from Fq (replicated in both lanes of the pair): an output coefficient of the NATIVE prepared line
+// product (tower.hpp f12_mul_by_line_native), whose v w coefficient is y_P / x_P in Fq.  Same column bound as fe_mul6 (54 terms here).
+BN_FN Fe fe_mul5(const Fe &a1, const Fe &u1, const Fe &c1, const Fe &v1, const Fe &a2, const Fe &u2, const Fe &c2, const Fe &v2,
+                 const Fe &a3, const Fe &u3) {
+#if !defined(BN_HOSTSIM)
+    return fe_mul5_asm(a1, u1, c1, v1, a2, u2, c2, v2, a3, u3);
+#endif
+    BN_COUNT(mul2); BN_COUNT(mul2); BN_COUNT(mul);
+    const Fe *x[5] = {&a1, &c1, &a2, &c2, &a3}, *y[5] = {&u1, &v1, &u2, &v2, &u3};
+#if defined(BN_BOUNDS)
+    unsigned vsum = 0;
+    for (int k = 0; k < 5; ++k) {
+        BN_REQUIRE(!x[k]->sg && !y[k]->sg, "fe_mul5 on a signed lazy value");
+        BN_REQUIRE(x[k]->lb == 1 && y[k]->lb == 1, "fe_mul5 needs normalized limbs in every operand (54 column terms)");
+        vsum += x[k]->vb * y[k]->vb;
+    }
+    BN_REQUIRE(vsum <= 338, "fe_mul5 value bound");                       // <= 169: result < 2q;  <= 338: result < 3q
+#endif
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fe r;
+#pragma unroll
+    for (int col = 0; col < 9; ++col) {
+#pragma unroll
+        for (int i = 0; i <= col; ++i)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc += (uint64_t)x[k]->l[i] * y[k]->l[col - i];
+#pragma unroll
+        for (int i = 0; i < col; ++i) acc += (uint64_t)m[i] * k::Q[col - i];
+        m[col] = ((uint32_t)acc * k::QINV) & MASK29;
+        acc += (uint64_t)m[col] * k::Q[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int col = 9; col < 17; ++col) {
+#pragma unroll
+        for (int i = col - 8; i <= 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc += (uint64_t)x[k]->l[i] * y[k]->l[col - i];
+#pragma unroll
+        for (int i = col - 8; i <= 8; ++i) acc += (uint64_t)m[i] * k::Q[col - i];
+        r.l[col - 9] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    BN_SETB(r, 1, (vsum <= 169 ? 2 : 3));
+    BN_VERIFY(r, "fe_mul5");
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // boundary conversions: the C ABI speaks the reference's format (8 x u32 = [u64;4] little endian, a*2^256 mod q, < q)
 BN_FN Fe fe_unpack_u32x8(const uint32_t *w) {     // raw 256-bit integer -> 29-bit limbs (no Montgomery change)

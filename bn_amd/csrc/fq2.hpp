@@ -310,6 +310,11 @@ template <class T>
 BN_FN Fq2B<T> f2b_mul3(const Fq2B<T> &a1, const Fq2BPrep<T> &b1, const Fq2B<T> &a2, const Fq2BPrep<T> &b2, const Fq2B<T> &a3, const Fq2BPrep<T> &b3) {
     return {fe_mul6(a1.v, b1.u, lane_partner(a1.v), b1.v, a2.v, b2.u, lane_partner(a2.v), b2.v, a3.v, b3.u, lane_partner(a3.v), b3.v)};
 }
+// reduce(a1 b1 + a2 b2 + a3 s), s in Fq replicated in both lanes of the pair (fe_mul5: the third product is this lane's component times s)
+template <class T>
+BN_FN Fq2B<T> f2b_mul3s(const Fq2B<T> &a1, const Fq2BPrep<T> &b1, const Fq2B<T> &a2, const Fq2BPrep<T> &b2, const Fq2B<T> &a3, const T &s) {
+    return {fe_mul5(a1.v, b1.u, lane_partner(a1.v), b1.v, a2.v, b2.u, lane_partner(a2.v), b2.v, a3.v, s)};
+}
 template <class T> BN_FN Fq2B<T> f2_add(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_add(a.v, b.v)}; }
 template <class T> BN_FN Fq2B<T> f2_dbl(const Fq2B<T> &a) { return {fe_dbl(a.v)}; }
 template <int LB, int K, class T> BN_FN Fq2B<T> f2_sub(const Fq2B<T> &a, const Fq2B<T> &b) { return {fe_sub<LB, K>(a.v, b.v)}; }

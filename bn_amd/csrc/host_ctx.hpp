@@ -101,6 +101,15 @@ struct bn254_ctx {
     std::map<std::string, std::pair<double, uint64_t>> folded;     // totals of records already consumed (events recycled)
 };
 
+// bn254_g2_prepare: the native line table of `nq` G2 points (bn254_kernels_b.hip NativeTableMem) and their infinity flags, in device memory
+struct bn254_g2_prepared {
+    int device = 0;
+    size_t nq = 0;
+    void *table = nullptr;
+    void *inf = nullptr;
+    size_t bytes = 0;
+};
+
 // lease of pipeline slots for one host-buffer call (see bn254_ctx::slot_busy)
 struct BnSlotLease {
     bn254_ctx *c; unsigned mask; int first;
@@ -163,6 +172,10 @@ int bn254_launch_final_exp_B(const void *f, void *out, size_t n, void *table, hi
 size_t bn254_final_exp_table_bytes_B(size_t n);
 int bn254_launch_g2_precompute_B(const void *q, void *coeffs, size_t n, hipStream_t s);
 int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared, void *f, size_t n, hipStream_t s);
+size_t bn254_native_table_bytes_B(size_t nq);
+int bn254_native_lines_B(void);
+int bn254_launch_g2_prepare_native_B(const void *q, void *table, void *q_inf, size_t nq, hipStream_t s);
+int bn254_launch_miller_native_B(const void *p, const void *table, const void *q_inf, size_t nq, size_t q_lo, int shared, void *f, size_t n, hipStream_t s);
 int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
 size_t bn254_gt_pow_table_bytes_B(size_t n);
 int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, int mode, hipStream_t s);

@@ -248,6 +248,112 @@ BN_FN Fq12<F2> miller_loop_prepared(const PStore &pstore, Source &source) {
     return f;
 }
 
+// ---- NATIVE prepared-G2 mode: the device's own counterpart of G2Precomp (groups/mod.rs:472-483) for workloads that pair many P against
+// the same Q (or re-use a set of Q).  Not the reference image (that is precompute_lines / miller_loop_prepared above, kept for the
+// reference's known answers) but what the lane-pair kernels consume without any per-pairing conversion:
+//   * the schedule is this engine's - 6u+2 in non-adjacent form on the isomorphic curve (miller_loop_sched<true>): NATIVE_LINES = 88 lines
+//     (65 doublings, 21 additions of +-Q, pi(Q), -pi^2(Q)) instead of the reference's 102;
+//   * every line is divided by ell_vw t^3 (t: the isomorphism's parameter, folded in here so that P stays on the original curve):
+//         A = ell_0 / (ell_vw t^3),   B = ell_vv t^2 / (ell_vw t^3)          - ONE inversion per table (Montgomery's trick over the 88 lines)
+//     and stored in the radix-2^261 limbs as the multiplier operands of the lane-pair product: this lane's component of A, and B, xi B each as
+//     (u, v) = (own, partner's with the even lane's negated) - canonical field elements, so a table is a function of Q alone;
+//   * per pairing the kernel computes sigma = 1 / x_P and tau = y_P / x_P behind ONE inversion (of X Z, for a Jacobian P) and multiplies f by
+//     A sigma + tau v w + B v^2 (tower.hpp f12_mul_by_line_native) - equal to the reference's line up to a factor in Fq2.  (x_P != 0 on every
+//     point of G1: 3 is a non-residue mod q, so y^2 = x^3 + 3 has no point with x = 0.)
+// The Miller value differs from the reference's by factors the final exponentiation kills; pairing() is bit-identical.
+constexpr int native_line_count() {
+    int n = 2;
+    for (int j = 0; j < k::ATE_NAF_LEN - 1; ++j) n += 1 + (k::ATE_NAF[j] != 0 ? 1 : 0);
+    return n;
+}
+constexpr int NATIVE_LINES = native_line_count();
+static_assert(NATIVE_LINES == 88, "line count of the NAF schedule");
+template <class T> BN_FN T fe_canon(const T &x) { return fe_canonical(fe_mul(x, lane_bcast((const T *)nullptr, fe_one()))); }
+// (u, v) of a multiplier as canonical field elements (f2b_prepare's v is a lazy negation: fine for a value that lives for one line product,
+// not for a table that should depend on Q alone)
+template <class T>
+BN_FN Fq2BPrep<T> f2b_prepare_canonical(const Fq2B<T> &b) {
+    const T own = fe_canon(b.v), pb = lane_partner(own);
+    return {lane_pick(own, pb), lane_pick(fe_canon(fe_neg<1, 4>(pb)), own)};
+}
+// `st`: put_raw(i, ell_0, d, c, prefix) / get_raw(i, ell_0, d, c) / get_prefix(i) park four Fq2 per line between the passes (the kernel uses
+// the line's own table record), put_final(i, a_own, b, xi_b) writes the record
+template <class F2, class Store>
+BN_FN void precompute_native(const G2Aff<F2> &q_in, Store &st) {
+    typedef typename F2::Scalar S;
+    constexpr int ND = k::ATE_NAF_LEN - 1;
+    const S t2 = f2_scalar_const(F2P, k::ISO_T2), t3 = f2_scalar_const(F2P, k::ISO_T3);
+    G2Aff<F2> base = {f2_scale(q_in.x, t2), f2_scale(q_in.y, t3)};
+    G2Proj<F2> r = {base.x, base.y, f2_one(F2P)};
+    F2 pref = f2_one(F2P);
+    int idx = 0;
+#pragma unroll 1
+    for (int j = 0; j < ND + 2; ++j) {
+        const bool tail = j >= ND;
+        const int digit = tail ? 1 : k::ATE_NAF[ND - 1 - j];
+        if (j == ND) base = mul_by_q(base);                                                 // pi(Q)      groups/mod.rs:578
+        if (j == ND + 1) { base = mul_by_q(base); base.y = f2_neg(base.y); }                // -pi^2(Q)   :579
+#pragma unroll 1
+        for (int pass = tail ? 1 : 0; pass < (digit != 0 ? 2 : 1); ++pass) {
+            Line<F2> l;
+            if (pass == 0) {
+                l = doubling_step<true>(r);
+            } else {
+                G2Aff<F2> b = base;
+                if (digit < 0) b.y = f2_neg(b.y);
+                l = addition_step(r, b);
+            }
+            const F2 d = f2_scale(l.ell_vw, t3), c = f2_scale(l.ell_vv, t2);
+            pref = f2_mul(pref, d);
+            st.put_raw(idx, l.ell_0, d, c, pref);
+            ++idx;
+        }
+    }
+    F2 inv = f2_inverse(pref);                                                              // 1 / (d_0 ... d_87)
+#pragma unroll 1
+    for (idx = NATIVE_LINES - 1; idx >= 0; --idx) {
+        F2 e0, d, c;
+        st.get_raw(idx, e0, d, c);
+        F2 dinv = inv;
+        if (idx > 0) { dinv = f2_mul(inv, st.get_prefix(idx - 1)); inv = f2_mul(inv, d); }
+        const F2 a = f2_mul(e0, dinv), b = f2_mul(c, dinv);
+        st.put_final(idx, fe_canon(a.v), f2b_prepare_canonical(b), f2b_prepare_canonical(f2_mul_xi(b)));
+    }
+}
+// what a pairing needs of P in native mode, from its Jacobian coordinates (x = X / Z^2, y = Y / Z^3): ONE inversion
+template <class T> struct PNative { T sigma, tau, tau9, taum; };
+template <class T>
+BN_FN PNative<T> p_native(const T &x, const T &y, const T &z) {
+    const T inv = fe_inverse(fe_mul(x, z));                          // 1 / (X Z)
+    PNative<T> p;
+    p.sigma = fe_mul(fe_mul(fe_sqr(z), z), inv);                     // Z^2 / X = 1 / x_P
+    p.tau = fe_mul(y, inv);                                          // Y / (Z X) = y_P / x_P
+    p.tau9 = fe_lc3<9, 0, 0>(p.tau, p.tau, p.tau);                   // xi z tau = own (9 tau) + partner (-+ tau)
+    p.taum = lane_pick(fe_lc3<-1, 0, 0>(p.tau, p.tau, p.tau), p.tau);
+    return p;
+}
+// `src.set_line(i)` selects line i; the rest of its interface is f12_mul_by_line_native's
+template <class F2, class Src>
+BN_FN Fq12<F2> miller_loop_native(Src &src) {
+    Fq12<F2> f = f12_one<F2>();
+    constexpr int ND = k::ATE_NAF_LEN - 1;
+    int idx = 0;
+#pragma unroll 1
+    for (int j = 0; j < ND + 2; ++j) {
+        const bool tail = j >= ND;
+        const int digit = tail ? 1 : k::ATE_NAF[ND - 1 - j];
+#pragma unroll 1
+        for (int pass = tail ? 1 : 0; pass < (digit != 0 ? 2 : 1); ++pass) {
+            BN_MILLER_HOOK(2 * j + pass, 2 * (ND + 2));
+            if (pass == 0 && j != 0) f = f12_sqr(f);                                    // f == 1 in the first step
+            BN_COMPILER_FENCE();                                                        // the line is fetched AFTER the squaring
+            src.set_line(idx++);
+            f = f12_mul_by_line_native(f, src);
+        }
+    }
+    return f;
+}
+
 // Table of the exponentiation machine below: EXP_SLOTS Fq12 values per pairing.  Default: ordinary variables (host
 // simulation, one-lane mapping); the lane-pair kernel keeps it in global memory (54 dwords per lane and slot, coalesced), which
 // also takes the multiplier of the loop out of the register file.

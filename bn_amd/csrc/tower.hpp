@@ -269,6 +269,44 @@ BN_COARSE Fq12<Fq2B<T>> f12_mul_by_024(const Fq12<Fq2B<T>> &f, const Fq2B<T> &el
     return r;
 }
 
+// The sparse line product of the NATIVE prepared-G2 mode (pairing.hpp miller_loop_native).  A line ell_0 + (ell_vw y_P) v w + (ell_vv x_P) v^2
+// may be scaled by any element of a proper subfield of Fq12 - the final exponentiation kills it - so the prepared table holds every line
+// divided by ell_vw (Q only, one inversion per table) and the kernel divides by x_P (P only, the pairing's one inversion):
+//     line' = (A sigma) + tau v w + B v^2,     A = ell_0 / ell_vw,  B = ell_vv / ell_vw  in Fq2 (table),   sigma = 1 / x_P,  tau = y_P / x_P  in Fq
+// With the lazily reduced form of f12_mul_by_024 above (x0 = A sigma, x2 = B, x4 = tau):
+//     c0' = (z0 x0 + xi z1 B + xi z4 tau) + (z1 x0 + xi z2 B + xi z5 tau) v + (z2 x0 + z0 B + z3 tau) v^2
+//     c1' = (z3 x0 + xi z4 B + xi z2 tau) + (z4 x0 + xi z5 B + z0 tau) v + (z5 x0 + z3 B + z1 tau) v^2
+// B and xi B arrive PREPARED from the table (no conversion, no xi-multiplication, no operand set-up per pairing), a product by tau is 81
+// instead of 162 multiply-adds per lane (fe_mul5), xi z tau is the dual product own * (9 tau) + partner * (-+ tau) with both multipliers
+// made once per pairing, and the ONE per-line scaling left is x0 = A sigma (one product per lane + the operand set-up).  2673 + 486 + 171
+// multiply-adds per line and lane against 3402 + 342 + the conversions of the reference-image coefficients (miller_loop_prepared).
+//   src.x0(): prepared A sigma;  src.xb() / src.b(): prepared xi B / B;  src.tau(), src.tau9() (9 tau, normalized), src.taum() (-tau on the even
+//   lane, tau on the odd lane)
+template <class T, class Src>
+BN_COARSE Fq12<Fq2B<T>> f12_mul_by_line_native(const Fq12<Fq2B<T>> &f, const Src &src) {
+    typedef Fq2B<T> F2;
+    const F2 &z0 = f.c0.c0, &z1 = f.c0.c1, &z2 = f.c0.c2, &z3 = f.c1.c0, &z4 = f.c1.c1, &z5 = f.c1.c2;
+    Fq12<F2> r;
+    const Fq2BPrep<T> x0 = src.x0();
+    {
+        const Fq2BPrep<T> xb = src.xb();
+        {
+            const Fq2BPrep<T> xt = {src.tau9(), src.taum()};
+            r.c0.c0 = f2b_mul3(z0, x0, z1, xb, z4, xt);
+            r.c0.c1 = f2b_mul3(z1, x0, z2, xb, z5, xt);
+            r.c1.c0 = f2b_mul3(z3, x0, z4, xb, z2, xt);
+        }
+        BN_COMPILER_FENCE();
+        r.c1.c1 = f2b_mul3s(z4, x0, z5, xb, z0, src.tau());
+    }
+    BN_COMPILER_FENCE();
+    const Fq2BPrep<T> b = src.b();
+    const T tau = src.tau();
+    r.c0.c2 = f2b_mul3s(z2, x0, z0, b, z3, tau);
+    r.c1.c2 = f2b_mul3s(z5, x0, z3, b, z1, tau);
+    return r;
+}
+
 // one Fp4 squaring of Granger-Scott, fused with the "times three, plus/minus twice the old coefficient" that follows it:
 //   tmp = a b,  t_even = (a + b)(a + xi b) - tmp - xi tmp = a^2 + xi b^2
 //   out_even = 3 t_even - 2 z_even          (ONE reduction: 3 m - 3 tmp - 3 xi tmp - 2 z_even)

@@ -157,6 +157,33 @@ class Engine:
         _native.check(self._lib.bn254_pairing_prepared_batch(self._h, _p(p), _p(coeffs), 1 if shared else 0, _p(out), p.shape[0]))
         return out
 
+    # ---- native prepared-G2 mode (include/bn254_hip.h bn254_g2_prepare ...)
+    def g2_prepare(self, q):
+        """(n,24) G2 points (or one (24,) point) -> PreparedG2: the device-resident native line tables (one point: shared by every P)"""
+        q = _arr(q, G2_WORDS)
+        h = C.c_void_p()
+        _native.check(self._lib.bn254_g2_prepare(self._h, _p(q), q.shape[0], C.byref(h)))
+        return PreparedG2(self, h)
+
+    def g2_prepare_dev(self, d_q, n, stream=0):
+        h = C.c_void_p()
+        _native.check(self._lib.bn254_g2_prepare_dev(self._h, d_q, n, C.byref(h), stream))
+        return PreparedG2(self, h)
+
+    def pairing_prepared_native_batch(self, p, prepared, out=None):
+        """out[i] = pairing(p[i], Q) for a one-point handle, pairing(p[i], Q[i]) otherwise"""
+        p = _arr(p, G1_WORDS)
+        if out is None:
+            out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        _native.check(self._lib.bn254_pairing_prepared_native_batch(self._h, _p(p), prepared._h, _p(out), p.shape[0]))
+        return out
+
+    def miller_prepared_native_dev(self, d_p, prepared, d_f, n, q_first=0, stream=0):
+        _native.check(self._lib.bn254_miller_prepared_native_dev(self._h, d_p, prepared._h, q_first, d_f, n, stream))
+
+    def pairing_prepared_native_dev(self, d_p, prepared, d_out, n, q_first=0, stream=0):
+        _native.check(self._lib.bn254_pairing_prepared_native_batch_dev(self._h, d_p, prepared._h, q_first, d_out, n, stream))
+
     # ---- wire format (fixed-size records: G1 65 bytes, G2 129 bytes)
     def fr_encode_batch(self, k):
         k = _arr(k, 4); out = np.empty((k.shape[0], 32), np.uint8)
@@ -303,6 +330,46 @@ class Engine:
         ms = C.c_double(); cnt = C.c_uint64()
         _native.check(self._lib.bn254_kernel_stats(self._h, kernel.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+
+class PreparedG2:
+    """opaque handle of bn254_g2_prepare: the native line tables of `count` G2 points in device memory (33 792 B each)"""
+
+    def __init__(self, engine, handle):
+        self._eng = engine
+        self._p = handle
+
+    @property
+    def _h(self):
+        if self._p is None:
+            raise _native.Bn254Error("this PreparedG2 is closed")
+        return self._p
+
+    @property
+    def count(self):
+        return int(self._eng._lib.bn254_g2_prepared_count(self._h))
+
+    @property
+    def device_bytes(self):
+        return int(self._eng._lib.bn254_g2_prepared_bytes(self._h))
+
+    def export(self):
+        """the table as (88 lines, 12 groups, 2 x count columns, 4) uint32 - for tests"""
+        n = self.count
+        out = np.empty((88, 12, 2 * n, 4), np.uint32)
+        _native.check(self._eng._lib.bn254_g2_prepared_export(self._eng._h, self._h, _p(out), out.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, "_p", None) and getattr(self._eng, "_ctx", None):
+            self._eng._lib.bn254_g2_prepared_destroy(self._p)
+        self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MultiEngine:

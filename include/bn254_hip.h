@@ -154,6 +154,28 @@ int bn254_g2_add_batch(bn254_ctx *ctx, const bn_g2 *a, const bn_g2 *b, bn_g2 *ou
    set (102 entries) is used for every p[i]; otherwise coeffs holds n sets, set i for p[i]. */
 int bn254_g2_precompute(bn254_ctx *ctx, const bn_g2 *q, bn_ell_coeffs *coeffs, size_t n);
 int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_coeffs *coeffs, int shared, bn_gt *out, size_t n);
+/* NATIVE prepared-G2 mode: the device's own counterpart of the reference's internal G2Precomp (groups/mod.rs:472-483) for callers that pair
+   many P against the same Q - a verification key - or re-use a set of Q.  bn254_g2_prepare runs precompute (groups/mod.rs:557-588) ONCE per
+   point and keeps the result in device memory behind an opaque handle, in the form the kernels consume: the engine's own schedule (6u+2 in
+   non-adjacent form: 88 lines instead of 102), every line normalised by its ell_vw coefficient (a factor in Fq2, which the final
+   exponentiation kills) and stored as multiplier operands in the 9 x 29-bit limbs of the device arithmetic - 33 792 bytes per point, a
+   function of the point alone.  bn254_pairing_prepared_native_batch then computes
+       out[i] = final_exponentiation(prepared.miller_loop(p[i]))  =  bn::pairing(p[i], q)          groups/mod.rs:486-519,764-771
+   bit-identical to the reference (the Miller VALUE differs by subfield factors; the reference-image coefficients, for the reference's own
+   known answers, are bn254_g2_precompute / bn_ell_coeffs above).  A handle made from ONE point is shared by all p[i]; a handle made from nq
+   points pairs p[i] with point q_first + i (q_first + n <= nq; the host-buffer entry point uses q_first = 0).  A point at infinity in either
+   argument gives Gt::one() (groups/mod.rs:766).  The handle belongs to the context's device; it is immutable after creation, so any
+   number of threads / streams may use it concurrently; destroy it after the last call that uses it has completed. */
+typedef struct bn254_g2_prepared bn254_g2_prepared;
+#define BN254_PREPARED_NATIVE_LINES 88
+#define BN254_PREPARED_NATIVE_BYTES 33792    /* device bytes per prepared point: 88 lines x 2 lanes x 12 x 16 B */
+int bn254_g2_prepare(bn254_ctx *ctx, const bn_g2 *q, size_t nq, bn254_g2_prepared **out);
+void bn254_g2_prepared_destroy(bn254_g2_prepared *prep);
+size_t bn254_g2_prepared_count(const bn254_g2_prepared *prep);           /* points in the handle */
+size_t bn254_g2_prepared_bytes(const bn254_g2_prepared *prep);           /* device memory it holds */
+/* copies the table to the host ([line][16-byte group][2 x point + lane] x 4 u32; for tests and inspection): bytes = BN254_PREPARED_NATIVE_BYTES x count */
+int bn254_g2_prepared_export(bn254_ctx *ctx, const bn254_g2_prepared *prep, void *host_table, size_t bytes);
+int bn254_pairing_prepared_native_batch(bn254_ctx *ctx, const bn_g1 *p, const bn254_g2_prepared *prep, bn_gt *out, size_t n);
 int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n);
 /* Gt::pow (lib.rs:171).  a[i] are Gt VALUES - what the reference's type holds: Gt::one, pairing() and products, powers, inverses of
    such (the Fq12 inside Gt is private and Gt has no decoder), all of order r.  On those the device exponentiates through the
@@ -241,6 +263,12 @@ int bn254_gt_product_final_exp_dev(bn254_ctx *ctx, const void *d_in, size_t m, v
 int bn254_miller_product_dev(bn254_ctx *ctx, const void *d_p, const void *d_q, size_t n, void *d_partial, void *stream);
 int bn254_g2_precompute_dev(bn254_ctx *ctx, const void *d_q, void *d_coeffs, size_t n, void *stream);
 int bn254_miller_prepared_dev(bn254_ctx *ctx, const void *d_p, const void *d_coeffs, int shared, void *d_f, size_t n, void *stream);
+/* native prepared-G2 mode on device-resident inputs.  bn254_g2_prepare_dev allocates the handle's table (that part synchronises with the
+   device) and enqueues the precompute kernel on `stream`; the other two are asynchronous like the rest of this section.
+   bn254_miller_prepared_native_dev returns the un-exponentiated Miller values (only meaningful in front of a final exponentiation). */
+int bn254_g2_prepare_dev(bn254_ctx *ctx, const void *d_q, size_t nq, bn254_g2_prepared **out, void *stream);
+int bn254_miller_prepared_native_dev(bn254_ctx *ctx, const void *d_p, const bn254_g2_prepared *prep, size_t q_first, void *d_f, size_t n, void *stream);
+int bn254_pairing_prepared_native_batch_dev(bn254_ctx *ctx, const void *d_p, const bn254_g2_prepared *prep, size_t q_first, void *d_out, size_t n, void *stream);
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
 int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream);
 int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, size_t n, void *stream);
@@ -262,7 +290,7 @@ int bn254_tile_dev(bn254_ctx *ctx, const void *d_record, size_t record_bytes, si
    accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
 int bn254_profile_enable(bn254_ctx *ctx, int on);
 int bn254_profile_reset(bn254_ctx *ctx);
-/* kernel: "miller", "miller_shared", "miller_wave", "miller_quad", "pairing_wave", "final_exp", "final_exp_wave", "final_exp_quad", "exp_by_neg_z", "gt_product", "gt_tail", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
+/* kernel: "miller", "miller_shared", "miller_wave", "miller_quad", "pairing_wave", "final_exp", "final_exp_wave", "final_exp_quad", "exp_by_neg_z", "gt_product", "gt_tail", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "g2_prepare_native", "miller_native", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
    Synchronises and consumes the recorded events (totals accumulate until bn254_profile_reset). */
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 /* issue-rate ceiling of v_mad_u64_u32 (the 32x32+64 multiply-accumulate every field product is built from) at

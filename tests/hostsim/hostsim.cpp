@@ -243,6 +243,67 @@ EXPORT void hsb_prepared_pairing(const uint32_t *g1, const uint32_t *g2, uint32_
     };
     f12_store(final_exponentiation(miller_loop_prepared<F2B>(ps, source)), o);
 }
+// NATIVE prepared-G2 mode as the kernels run it (pairing.hpp precompute_native -> table -> miller_loop_native -> final exponentiation).
+// table: [88 lines][2 lanes][48 words] in the kernel's record layout: A own (9), xi B u (9), xi B v (9), pad, B u (9), B v (9), pad 2
+struct NativeTableSim {
+    uint32_t *t;                         // [line][lane][48]
+    FeP raw[NATIVE_LINES][4];
+    static void put(uint32_t *w, const Fe &x) { for (int i = 0; i < 9; ++i) w[i] = x.l[i]; }
+    static Fe get(const uint32_t *w) { Fe x; for (int i = 0; i < 9; ++i) x.l[i] = w[i]; BN_SETB(x, 1, 1); return x; }
+    void put_raw(int i, const F2B &e0, const F2B &d, const F2B &c, const F2B &pref) { raw[i][0] = e0.v; raw[i][1] = d.v; raw[i][2] = c.v; raw[i][3] = pref.v; }
+    void get_raw(int i, F2B &e0, F2B &d, F2B &c) const { e0.v = raw[i][0]; d.v = raw[i][1]; c.v = raw[i][2]; }
+    F2B get_prefix(int i) const { return {raw[i][3]}; }
+    void put_final(int i, const FeP &a, const Fq2BPrep<FeP> &b, const Fq2BPrep<FeP> &xb) {
+        for (int lane = 0; lane < 2; ++lane) {
+            uint32_t *w = t + (i * 2 + lane) * 48;
+            for (int j = 0; j < 48; ++j) w[j] = 0;
+            put(w, a.v[lane]); put(w + 9, xb.u.v[lane]); put(w + 18, xb.v.v[lane]); put(w + 28, b.u.v[lane]); put(w + 37, b.v.v[lane]);
+        }
+    }
+};
+struct NativeLineSim {
+    const uint32_t *t;
+    PNative<FeP> p;
+    int line = 0;
+    void set_line(int i) { line = i; }
+    FeP ld(int off) const { return {{NativeTableSim::get(t + (line * 2 + 0) * 48 + off), NativeTableSim::get(t + (line * 2 + 1) * 48 + off)}}; }
+    Fq2BPrep<FeP> x0() const { return f2b_prepare(F2B{fe_mul(ld(0), p.sigma)}); }
+    Fq2BPrep<FeP> xb() const { return {ld(9), ld(18)}; }
+    Fq2BPrep<FeP> b() const { return {ld(28), ld(37)}; }
+    FeP tau() const { return p.tau; }
+    FeP tau9() const { return p.tau9; }
+    FeP taum() const { return p.taum; }
+};
+EXPORT int hsb_native_lines() { return NATIVE_LINES; }
+EXPORT void hsb_native_precompute(const uint32_t *g2, uint32_t *table) {
+    G2Aff<F2B> q = g2_to_affine(f2_load((F2B *)0, g2), f2_load((F2B *)0, g2 + 16), f2_load((F2B *)0, g2 + 32));
+    static NativeTableSim st;
+    st.t = table;
+    precompute_native(q, st);
+}
+// miller: 1 = the un-exponentiated Miller value (differs from the reference's by subfield factors), 0 = the pairing
+EXPORT void hsb_native_pairing(const uint32_t *g1, const uint32_t *table, int miller, uint32_t *o) {
+    const bool inf = words_all_zero(g1 + 16, 8);
+    NativeLineSim src;
+    src.t = table;
+    src.p = p_native(f2_scalar_load((F2B *)0, g1), f2_scalar_load((F2B *)0, g1 + 8), f2_scalar_load((F2B *)0, g1 + 16));
+    Fq12<F2B> f = miller_loop_native<F2B>(src);
+    if (!miller) f = final_exponentiation(f);
+    if (inf) f = f12_one<F2B>();
+    f12_store(f, o);
+}
+// bn254_miller_prepared_B alone (the reference-image coefficients already computed): what that kernel executes per pairing
+EXPORT void hsb_prepared_miller(const uint32_t *g1, const uint32_t *coeffs, uint32_t *o) {
+    FeP zi = fe_inverse(f2_scalar_load((F2B *)0, g1 + 16)), zi2 = fe_sqr(zi);
+    G1Aff<FeP> p = {fe_mul(f2_scalar_load((F2B *)0, g1), zi2), fe_mul(f2_scalar_load((F2B *)0, g1 + 8), fe_mul(zi2, zi))};
+    struct PStore { G1Aff<FeP> p_; G1Aff<FeP> get_p() const { return p_; } } ps = {p};
+    auto source = [&](int idx) {
+        const uint32_t *c = coeffs + idx * 48;
+        Line<F2B> l = {f2_load((F2B *)0, c), f2_load((F2B *)0, c + 16), f2_load((F2B *)0, c + 32)};
+        return l;
+    };
+    f12_store(miller_loop_prepared<F2B>(ps, source), o);
+}
 // the product tree step of the multi-pairing: acc = acc * x repeatedly (bn254_gt_product_B)
 EXPORT void hsb_gt_product(const uint32_t *in, int n, uint32_t *o) {
     Fq12<F2B> acc = f12_load<F2B>(in);

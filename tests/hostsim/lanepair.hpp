@@ -54,6 +54,11 @@ BN_FN FeP fe_mul6(const FeP &a1, const FeP &u1, const FeP &c1, const FeP &v1, co
     return {{fe_mul6(a1.v[0], u1.v[0], c1.v[0], v1.v[0], a2.v[0], u2.v[0], c2.v[0], v2.v[0], a3.v[0], u3.v[0], c3.v[0], v3.v[0]),
              fe_mul6(a1.v[1], u1.v[1], c1.v[1], v1.v[1], a2.v[1], u2.v[1], c2.v[1], v2.v[1], a3.v[1], u3.v[1], c3.v[1], v3.v[1])}};
 }
+BN_FN FeP fe_mul5(const FeP &a1, const FeP &u1, const FeP &c1, const FeP &v1, const FeP &a2, const FeP &u2, const FeP &c2, const FeP &v2, const FeP &a3, const FeP &u3) {
+    return {{fe_mul5(a1.v[0], u1.v[0], c1.v[0], v1.v[0], a2.v[0], u2.v[0], c2.v[0], v2.v[0], a3.v[0], u3.v[0]),
+             fe_mul5(a1.v[1], u1.v[1], c1.v[1], v1.v[1], a2.v[1], u2.v[1], c2.v[1], v2.v[1], a3.v[1], u3.v[1])}};
+}
+BN_FN FeP fe_canonical(const FeP &a) { return {{fe_canonical(a.v[0]), fe_canonical(a.v[1])}}; }
 struct Fe;
 BN_FN Fe fe_cneg(bool flag, const Fe &z);         // wave.hpp
 BN_FN FeP fe_cneg(bool flag, const FeP &a) { return {{fe_cneg(flag, a.v[0]), fe_cneg(flag, a.v[1])}}; }

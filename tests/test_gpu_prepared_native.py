@@ -1,0 +1,179 @@
+"""GPU parity tests of the NATIVE prepared-G2 mode (include/bn254_hip.h bn254_g2_prepare / bn254_pairing_prepared_native_batch):
+the device-native counterpart of the reference's G2Precomp (groups/mod.rs:472-520,557-588) against the CPU oracle, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bn_model as M
+from bn_oracle import FQ, FR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import bn_amd
+    return bn_amd.Engine(0)
+
+
+def _scalars(rng, n):
+    return [int.from_bytes(rng.bytes(64), "little") % M.R_ORD for _ in range(n)]
+
+
+def _fr(oracle, vals):
+    return np.stack([oracle.fp_from_int(FR, v) for v in vals])
+
+
+def _g1(oracle, vals):
+    return oracle.g1_mul_batch_jacobian(np.tile(oracle.g1_one(), (len(vals), 1)), _fr(oracle, vals))
+
+
+def _g2(oracle, vals):
+    return oracle.g2_mul_batch_jacobian(np.tile(oracle.g2_one(), (len(vals), 1)), _fr(oracle, vals))
+
+
+def test_reference_known_answer_through_the_native_table(oracle, kats, eng):
+    """groups/mod.rs:773-796 (test_reduced_pairing): pairing(k1 G1, k2 G2) with Q = k2 G2 prepared natively equals the reference's twelve
+    field elements; and the Q of test_prepared_g2 (groups/mod.rs:637-762) paired natively equals pairing() on the same inputs"""
+    k = kats["test_reduced_pairing"]
+    P = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_decimal(FR, k["k1"])); Q = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, k["k2"]))
+    prep = eng.g2_prepare(Q)
+    assert prep.count == 1 and prep.device_bytes == 33792 + 4
+    assert oracle.fq12_to_ints(eng.pairing_prepared_native_batch(P, prep)[0]) == [int(x) for x in k["expected"]]
+    Q2 = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, kats["test_prepared_g2"]["k2"]))
+    prep2 = eng.g2_prepare(Q2)
+    assert np.array_equal(eng.pairing_prepared_native_batch(P, prep2)[0], oracle.pairing(P, Q2))
+    prep.close(); prep2.close()
+
+
+def test_shared_q_ragged_batch_matches_oracle(oracle, eng):
+    """200 P (ragged: not a multiple of the 32 pairings of a wave) against ONE prepared Q: random Jacobian points, the generator with z = 1,
+    small and edge scalars, points at infinity - every output equals the oracle's pairing()"""
+    rng = np.random.default_rng(601)
+    n = 200
+    Q = _g2(oracle, _scalars(rng, 1))[0]
+    vals = _scalars(rng, n)
+    vals[:6] = [1, 2, 3, M.R_ORD - 1, M.R_ORD - 2, 1 << 200]
+    P = _g1(oracle, vals)
+    P[7] = oracle.g1_one()                    # affine input, z = 1
+    P[11] = oracle.g1_zero(); P[n - 1] = oracle.g1_zero()
+    prep = eng.g2_prepare(Q)
+    got = eng.pairing_prepared_native_batch(P, prep)
+    assert np.array_equal(got, oracle.pairing_batch(P, np.tile(Q, (n, 1))))
+    assert np.array_equal(got[11], oracle.fq12_one()) and np.array_equal(got[n - 1], oracle.fq12_one())
+    # a prepared point at infinity: every pairing is one (groups/mod.rs:766)
+    pz = eng.g2_prepare(oracle.g2_zero())
+    one = eng.pairing_prepared_native_batch(P[:5], pz)
+    assert np.array_equal(one, oracle.pairing_batch(P[:5], np.tile(oracle.g2_zero(), (5, 1))))
+    prep.close(); pz.close()
+
+
+def test_one_table_per_pairing_matches_oracle(oracle, eng):
+    """per-P coefficients: 200 distinct Q prepared in ONE handle, p[i] against Q[i]; infinity on either side; q_first offsets through the
+    device entry point; wrong counts are rejected"""
+    import torch
+    import bn_amd
+    from bn_amd import _native
+    from bn_amd import distributed as D
+    rng = np.random.default_rng(602)
+    n = 200
+    P = _g1(oracle, _scalars(rng, n)); Q = _g2(oracle, _scalars(rng, n))
+    Q[3] = oracle.g2_zero(); P[9] = oracle.g1_zero(); Q[n - 1] = oracle.g2_one()
+    prep = eng.g2_prepare(Q)
+    assert prep.count == n
+    want = oracle.pairing_batch(P, Q)
+    assert np.array_equal(eng.pairing_prepared_native_batch(P, prep), want)
+    # fewer P than points: the first ones
+    assert np.array_equal(eng.pairing_prepared_native_batch(P[:70], prep), want[:70])
+    # more P than points: rejected, nothing runs
+    with pytest.raises(_native.Bn254Error):
+        eng.pairing_prepared_native_batch(np.concatenate([P, P[:1]]), prep)
+    # q_first: p[i] against point 50 + i
+    dev = torch.device("cuda", 0)
+    te = D.TorchEngine(eng, dev)
+    dp = torch.from_numpy(P[50:150].view(np.int64)).to(dev)
+    out = te.empty(100, 48)
+    eng.pairing_prepared_native_dev(dp.data_ptr(), prep, out.data_ptr(), 100, q_first=50, stream=te._stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want[50:150])
+    with pytest.raises(_native.Bn254Error):
+        eng.pairing_prepared_native_dev(dp.data_ptr(), prep, out.data_ptr(), 100, q_first=150, stream=te._stream())
+    prep.close()
+
+
+def test_table_is_a_function_of_the_point_alone(oracle, eng, kats):
+    """the native table holds canonical field elements: two Jacobian representations of one point (z = 1 and z != 1) give byte-identical
+    tables; the device's table equals the host simulation's (the same templates compiled for the CPU with every bound enforced); and every
+    record holds canonical limbs, B and xi B in the (u, v) operand form with xi B = (9 + i) B"""
+    import hostsim_lib
+    Qj = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, kats["test_prepared_g2"]["k2"]))
+    Qa = oracle.g2_normalize(Qj)
+    assert not np.array_equal(Qa, Qj)
+    pj = eng.g2_prepare(Qj); pa = eng.g2_prepare(Qa)
+    tj = pj.export(); ta = pa.export()
+    assert tj.shape == (88, 12, 2, 4) and np.array_equal(tj, ta)
+    hs = hostsim_lib.HostSim(bounds=True)
+    U32 = C.POINTER(C.c_uint32)
+    sim = np.zeros((88, 2, 48), np.uint32)
+    hs.lib.hsb_native_precompute(np.ascontiguousarray(Qj).ctypes.data_as(U32), sim.ctypes.data_as(U32))
+    dev_tab = tj.transpose(0, 2, 1, 3).reshape(88, 2, 48)            # [line][lane][12 groups x 4 words]
+    assert np.array_equal(dev_tab, sim)
+    # limbs -> integers (radix 2^29, Montgomery radix 2^261)
+    rinv = pow(1 << 261, -1, M.Q)
+    def val(w):
+        return sum(int(x) << (29 * i) for i, x in enumerate(w)) * rinv % M.Q
+    for line in (0, 1, 40, 87):
+        even, odd = dev_tab[line, 0], dev_tab[line, 1]
+        for w in (even, odd):
+            for off in (0, 9, 18, 28, 37):
+                assert sum(int(x) << (29 * i) for i, x in enumerate(w[off:off + 9])) < M.Q           # canonical
+        # a prepared multiplier (u, v): this lane's component of z * b is own_z * u + partner_z * v, i.e. u = b0 in both lanes, v = -b1 | b1
+        def unprep(off):
+            b0, b1 = val(even[off:off + 9]), val(odd[off + 9:off + 18])
+            assert val(odd[off:off + 9]) == b0 and val(even[off + 9:off + 18]) == (-b1) % M.Q
+            return b0, b1
+        b = unprep(28); xb = unprep(9)
+        assert xb == ((9 * b[0] - b[1]) % M.Q, (9 * b[1] + b[0]) % M.Q)                              # xi B = (9 + i) B
+    pj.close(); pa.close()
+
+
+def test_full_size_shared_and_per_pairing(oracle):
+    """BASELINE configs[1] size: 2^16 P against one prepared Q and 2^16 (P, Q) pairs with one table each - the whole batches equal the fused
+    kernels' pairing_batch (an independent device path: lines computed on the fly, other schedule bookkeeping, other line normalisation) and an
+    oracle sample; sub-launches (round of 2^14) return the same bytes"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    n = 1 << 16
+    e = bn_amd.Engine(0)
+    te = D.TorchEngine(e, dev)
+    P, Q = D.synthetic_points(te, 0, n)
+    # one table per pairing (2.2 GB of tables)
+    prep = e.g2_prepare_dev(Q.data_ptr(), n, te._stream())
+    assert prep.count == n and prep.device_bytes == n * (33792 + 4)
+    out = te.empty(n, 48)
+    e.pairing_prepared_native_dev(P.data_ptr(), prep, out.data_ptr(), n, stream=te._stream())
+    ref = D.pairing_batch_sharded(te, P, Q)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    idx = np.random.default_rng(11).choice(n, 512, replace=False)
+    Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn[idx], Qn[idx]))
+    with e.options(round_pairs=1 << 14):
+        out2 = te.empty(n, 48)
+        e.pairing_prepared_native_dev(P.data_ptr(), prep, out2.data_ptr(), n, stream=te._stream())
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out)
+    prep.close()
+    # one shared Q
+    q0 = Q[12345:12346].contiguous()
+    prep1 = e.g2_prepare_dev(q0.data_ptr(), 1, te._stream())
+    e.pairing_prepared_native_dev(P.data_ptr(), prep1, out.data_ptr(), n, stream=te._stream())
+    ref1 = D.pairing_batch_sharded(te, P, q0.expand(n, 24).contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref1)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn[idx], np.tile(Qn[12345], (len(idx), 1))))
+    prep1.close()
+    e.close()

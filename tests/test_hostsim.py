@@ -342,8 +342,21 @@ def executed_chain_lengths(oracle, hs):
         hs.call(fn, *args, out_words=out_words)
         a = (C.c_ulong * 8)(); hs.lib.hs_counts_get(a)
         return int(a[0] + 1.5 * a[1])
+    U32 = C.POINTER(C.c_uint32)
+    def count_raw(fn, *args):
+        hs.lib.hs_counts_reset()
+        fn(*args)
+        a = (C.c_ulong * 8)(); hs.lib.hs_counts_get(a)
+        return int(a[0] + 1.5 * a[1])
+    # prepared-G2 mode: the Miller kernels alone, over the native table resp. the reference-image coefficients (both lanes of the pair)
+    tab = np.zeros(88 * 2 * 48, np.uint32); coeffs = np.zeros(102 * 24, np.uint64); o = np.zeros(48, np.uint64)
+    prep_native = count_raw(hs.lib.hsb_native_precompute, Q.ctypes.data_as(U32), tab.ctypes.data_as(U32))
+    native = count_raw(hs.lib.hsb_native_pairing, P.ctypes.data_as(U32), tab.ctypes.data_as(U32), C.c_int(1), o.ctypes.data_as(U32))
+    hs.lib.hsb_prepared_pairing(P.ctypes.data_as(U32), Q.ctypes.data_as(U32), coeffs.ctypes.data_as(U32), o.ctypes.data_as(U32))
+    prepared = count_raw(hs.lib.hsb_prepared_miller, P.ctypes.data_as(U32), coeffs.ctypes.data_as(U32), o.ctypes.data_as(U32))
     return {"g1_mul": count("hs_g1_mul_glv", P, k2, out_words=24), "g2_mul": count("hsb_g2_mul_gls", Q, k2, out_words=48),
-            "gt_pow": count("hsb_gt_pow_auto", g, k2, out_words=96)}             # a pairing value: membership test + cyclotomic chain
+            "gt_pow": count("hsb_gt_pow_auto", g, k2, out_words=96),             # a pairing value: membership test + cyclotomic chain
+            "miller_native": native, "miller_prepared": prepared, "g2_prepare_native": prep_native}
 
 
 def test_executed_chain_lengths(oracle, hs):
