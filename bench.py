@@ -49,7 +49,15 @@ ALGO_BYTES_PER_PAIRING = 672
 # `roofline.frac` of a side kernel is over (b) - what the hardware is asked to do - and `frac_vs_reference_chain` over (a); (a) can
 # exceed the peak when the kernel's chain is shorter than the reference's, (b) cannot.
 FQMUL_REF = {"g1_mul": 3817, "g2_mul": 9541, "gt_pow": 16128}
-FQMUL_OWN = json.loads((ROOT / "profiles" / "executed_chain_lengths.json").read_text())["fq_products_per_unit"]
+_CHAINS = json.loads((ROOT / "profiles" / "executed_chain_lengths.json").read_text())
+FQMUL_OWN = _CHAINS["fq_products_per_unit"]
+# multiply instructions ONE LANE issues per unit (exact, from the host simulation) x the lanes a unit occupies = the EXECUTED multiply-adds
+# behind `roofline.frac_executed`
+MAC_INSTR = _CHAINS["mac_instructions_per_lane_and_unit"]
+LANES_PER_UNIT = {"g1_mul": 1}                                    # every other kernel of these lines runs a unit on a lane pair
+# the latest committed one-GPU bench line: where an N > 1 run, which measures no side workloads itself, takes the one-GPU shard times of its
+# scaling prediction from (expected_scaling)
+SCALING_SOURCE = ROOT / "profiles" / "r06z_bench_line.json"
 
 
 def _barrier(dist, dev):
@@ -101,6 +109,116 @@ def kernel_times(eng, dev, fn, names, steps):
     return {k: v for k, v in st.items() if v[1]}
 
 
+class PowerSampler:
+    """Socket power and shader clock of ONE GPU, sampled from the amdgpu driver while kernels run: a thread reads the hwmon files of the
+    device (power1_input in microwatts, freq1_input = sclk in Hz; found through the PCI address torch reports) every ~2 ms, and the
+    ROCm-SMI energy accumulator (rsmi_dev_energy_count_get, 15.3 uJ resolution) is read before and after the leg.  Everything is optional:
+    `why` says what was missing when a field comes back None."""
+
+    def __init__(self, torch, dev):
+        import glob
+        self.why = None
+        self.power_f = self.freq_f = self.cap_w = None
+        self.rsmi = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            cands = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if not cands:                                        # containers may hide the PCI tree: a single amdgpu hwmon node is unambiguous
+                cands = [h for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.exists(h + "/power1_input")]
+                if len(cands) != 1:
+                    cands = []
+            if cands:
+                h = cands[0]
+                self.power_f = h + "/power1_input" if os.path.exists(h + "/power1_input") else (h + "/power1_average" if os.path.exists(h + "/power1_average") else None)
+                self.freq_f = h + "/freq1_input" if os.path.exists(h + "/freq1_input") else None
+                if os.path.exists(h + "/power1_cap"):
+                    self.cap_w = int(open(h + "/power1_cap").read()) / 1e6
+            if not self.power_f:
+                self.why = f"no readable hwmon power node for {bdf}"
+        except Exception as e:                                   # noqa: BLE001 - measurement is best effort, the bench line must still appear
+            self.why = f"hwmon lookup failed: {e!r}"
+        try:
+            import ctypes as C
+            l = C.CDLL("/opt/rocm/lib/librocm_smi64.so")
+            if l.rsmi_init(C.c_uint64(0)) == 0:
+                n = C.c_uint32()
+                l.rsmi_num_monitor_devices(C.byref(n))
+                want = None
+                pr = torch.cuda.get_device_properties(dev)
+                want = (pr.pci_domain_id << 32) | (pr.pci_bus_id << 8) | (pr.pci_device_id << 3)
+                for i in range(n.value):
+                    b = C.c_uint64()
+                    if l.rsmi_dev_pci_id_get(i, C.byref(b)) == 0 and (b.value & 0xffffffff0000fff8) == want or n.value == 1:
+                        self.rsmi = (l, C, i)
+                        break
+        except Exception:                                        # noqa: BLE001
+            self.rsmi = None
+
+    def _energy_uj(self):
+        if not self.rsmi:
+            return None
+        l, C, i = self.rsmi
+        e = C.c_uint64(); res = C.c_float(); ts = C.c_uint64()
+        if l.rsmi_dev_energy_count_get(i, C.byref(e), C.byref(res), C.byref(ts)) != 0:
+            return None
+        return e.value * float(res.value)
+
+    def run(self, torch, dev, step, units_per_step, min_seconds=1.2, est_ms_per_step=None):
+        """loops `step` for at least `min_seconds` (outside any timed region), sampling; returns the fields of the roofline object"""
+        import threading
+        if est_ms_per_step is None:
+            est_ms_per_step = 10.0
+        k = max(10, int(min_seconds * 1e3 / est_ms_per_step) + 1)
+        samples = []
+        stop = threading.Event()
+
+        def rd(f):
+            with open(f) as fh:
+                return int(fh.read())
+
+        def loop():
+            while not stop.is_set():
+                t = time.perf_counter()
+                try:
+                    samples.append((t, rd(self.power_f) / 1e6 if self.power_f else None, rd(self.freq_f) / 1e6 if self.freq_f else None))
+                except Exception:                                # noqa: BLE001
+                    pass
+                time.sleep(0.002)
+        torch.cuda.synchronize(dev)
+        th = threading.Thread(target=loop, daemon=True)
+        e0 = self._energy_uj()
+        t0 = time.perf_counter()
+        if self.power_f or self.freq_f:
+            th.start()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        e1 = self._energy_uj()
+        stop.set()
+        if th.is_alive():
+            th.join()
+        # the first 0.2 s are the ramp (clocks and the power average settle), the tail after the last kernel is idle
+        body = [x for x in samples if t0 + 0.2 <= x[0] <= t1 - 0.005]
+        pw = [x[1] for x in body if x[1] is not None]; fq = [x[2] for x in body if x[2] is not None]
+        out = {"power_W": sum(pw) / len(pw) if pw else None, "power_W_max": max(pw) if pw else None, "sclk_MHz": sum(fq) / len(fq) if fq else None,
+               "power_cap_W": self.cap_w, "power_samples": len(pw),
+               "power_leg": f"{k} more steps of this line's workload ({(t1 - t0):.2f} s, outside the timed region), hwmon power1_input / freq1_input every ~2 ms, first 0.2 s dropped",
+               "power_source": (self.power_f or self.why)}
+        if e0 is not None and e1 is not None and e1 > e0:
+            out["energy_uJ_per_unit"] = (e1 - e0) / (k * units_per_step)
+            out["energy_source"] = "rsmi_dev_energy_count_get before / after the leg (whole socket, idle share included)"
+            out["power_W_from_energy_counter"] = (e1 - e0) / 1e6 / (t1 - t0)
+        elif pw:
+            out["energy_uJ_per_unit"] = (sum(pw) / len(pw)) * (t1 - t0) / (k * units_per_step) * 1e6
+            out["energy_source"] = "mean sampled power x wall time of the leg"
+        else:
+            out["energy_uJ_per_unit"] = None
+        out["units_per_s_during_leg"] = k * units_per_step / (t1 - t0)
+        return out
+
+
 _PEAK = {}
 
 
@@ -145,6 +263,10 @@ def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=No
         share = shares.get(k, 1.0) if shares else 1.0
         ach = unit_count * steps * mac32_per_unit * share / (ms * 1e-3) / 1e12
         per[k] = {"avg_launch_ms": ms / cnt, "launches": cnt, "ms_per_step": ms / steps, "achieved": ach, "frac": ach / peak8}
+        mk = {"final_exp_quad": None, "miller_quad": None, "pairing_wave": None, "final_exp_wave": None}.get(k, k)     # (other mappings execute other chains)
+        if mk in MAC_INSTR:
+            ex = unit_count * steps * MAC_INSTR[mk] * LANES_PER_UNIT.get(mk, 2) / (ms * 1e-3) / 1e12
+            per[k].update({"executed_TMAC_per_s": ex, "frac_executed": ex / peak8, "frac_executed_of_occupancy_peak": ex / peak2})
         t = traffic_of(k, unit_count * steps / cnt)                       # EVERY kernel of the line carries its traffic story, per launch
         if t:
             per[k].update({"traffic": t["traffic"], "algorithmic_bytes": t["algorithmic_bytes"], "traffic_ratio": t["traffic_ratio"],
@@ -152,9 +274,14 @@ def roofline(eng, stats, unit_count, mac32_per_unit, shares=None, traffic_key=No
     td = traffic_of(dom, unit_count * steps / stats[dom][1])
     traffic, src = (td["traffic"], td["traffic_source"]) if td else (None, None)
     d = per[dom]
-    out = {"bound": "valu-int32-mac at the socket power cap (neither hbm nor mfma: SURVEY.md 8d; 1388 of 1400 W under these kernels: profiles/r05_power_probe.txt)", "kernel": dom, "achieved": d["achieved"], "peak": peak8,
+    out = {"bound": "valu-int32-mac (neither hbm nor mfma: SURVEY.md 8d); see power_W / power_cap_W / sclk_MHz of this object where the line carries them: the socket's power cap is what limits the multiplier",
+           "kernel": dom, "achieved": d["achieved"], "peak": peak8,
            "unit": "TMAC32/s", "frac": d["frac"],
            "achieved_is": "Fq products of the chain x 136 MAC32 (an 8 x 32-bit-limb Montgomery product) / measured kernel time",
+           "frac_executed": d.get("frac_executed"), "executed_TMAC_per_s": d.get("executed_TMAC_per_s"),
+           "frac_executed_of_occupancy_peak": d.get("frac_executed_of_occupancy_peak"),
+           "frac_executed_is": "multiply instructions the kernel EXECUTES (v_mad_u64_u32 / v_mad_i64_i32 / v_mul_lo / v_mul_hi per lane, counted by the host simulation of the device code: "
+                               "profiles/executed_chain_lengths.json) x lanes / measured kernel time / peak - how full the multiplier is, where `frac` prices the reference's formulas",
            "peak_source": "bn254_ubench_mac32 in this run: pure v_mad_u64_u32 stream, 8 waves/SIMD",
            "peak_at_kernel_occupancy": peak2, "kernel_occupancy_waves_per_simd": 2, "frac_of_occupancy_peak": d["achieved"] / peak2,
            "peak_at_kernel_occupancy_is": "the same stream at 2 waves/SIMD on random 29-bit operands (the engine's limbs)",
@@ -314,7 +441,7 @@ def bench_product(args, eng, dev, world, rank):
         print(json.dumps(_line("BN254 pairs/sec folded into one multi-pairing product (bit-exact vs ref)", "pairs/s",
                                PRODUCT_TOTAL * args.steps / elapsed, world, args, elapsed, "strong",
                                f"product of 2^18 pairs -> 1 Gt, {hi - lo} pairs per GPU (BASELINE.json configs[3]); all_gather of 384 B per rank",
-                               {"kernel_ms_per_step": kms, "kernel_traffic": ktr, "expected_scaling": expected_scaling("product", world)}, {"process_group": (dist.get_backend() if dist.is_initialized() else None)})), flush=True)
+                               {"kernel_ms_per_step": kms, "kernel_traffic": ktr, "expected_scaling": expected_scaling("product", world, scaling_inputs())}, {"process_group": (dist.get_backend() if dist.is_initialized() else None)})), flush=True)
 
 
 def run_prepared(eng, dev, dist, P, Q, n, mode, steps, warmup):
@@ -371,8 +498,23 @@ def side_object(eng, dev, dist, P16, Q16):
     side["g1mul_2_20"] = {"config": "BASELINE.json configs[4]: 2^20 G1 scalar muls by random Fr, 1 MI355X", "value": n * 6 / elapsed, "unit": "scalar muls/s",
                           "ms_per_step": elapsed / 6 * 1e3, "roofline": dict({k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "frac_vs_reference_chain", "avg_launch_ms", "traffic", "traffic_source")},
                                            **{k: rf["kernels"]["g1_mul"].get(k) for k in ("algorithmic_bytes", "traffic_ratio", "hbm_GBps")})}
+    # prepared-G2 mode: 2^16 P against ONE natively prepared Q - the second roofline point of the path (the table is the one
+    # operand every lane streams: 33.8 KB per Q, read 2^16 times per step out of the caches)
+    elapsed, prf, kms = run_prepared(eng, dev, dist, P16, Q16, BATCH, "native", 6, 2)
+    side["prepared_2_16"] = {"config": "SURVEY 8f-2: 2^16 random P against ONE prepared G2 point (bn254_g2_prepare: device-native table, 88 lines x 384 B), 1 MI355X",
+                             "value": BATCH * 6 / elapsed, "unit": "pairings/s", "ms_per_step": elapsed / 6 * 1e3, "kernel_ms": kms,
+                             "roofline": dict({k: prf[k] for k in ("kernel", "achieved", "peak", "frac", "frac_executed", "frac_executed_of_occupancy_peak", "frac_vs_reference_chain",
+                                                                   "avg_launch_ms", "traffic", "traffic_source")},
+                                              **{k: prf["kernels"]["miller_native"].get(k) for k in ("algorithmic_bytes", "traffic_ratio", "hbm_GBps")},
+                                              frac_is="over the chain miller_native EXECUTES (7000 Fq-product equivalents per pairing: profiles/executed_chain_lengths.json); "
+                                                      "frac_vs_reference_chain over the reference's miller_loop (11 952 multiplications, groups/mod.rs:486-519)",
+                                              table_bytes_per_q=33792)}
+    _, _, kms_ref = run_prepared(eng, dev, dist, P16, Q16, BATCH, "reference", 3, 1)
+    side["prepared_2_16"]["reference_image_kernel_ms"] = dict(kms_ref, what="the same step over the reference-image coefficients (bn254_g2_precompute, 102 x 192 B): the mode kept for the reference's known answers")
     P, Q = D.synthetic_points(eng, 0, PRODUCT_TOTAL)
     for tag, m, what in (("product_2_18", PRODUCT_TOTAL, "BASELINE.json configs[3] on ONE GPU: multi-pairing product of 2^18 pairs -> 1 Gt"),
+                         ("product_2_17", PRODUCT_TOTAL // 2, "the per-GPU shard of configs[3] at 2 GPUs: 2^17 pairs -> 1 Gt"),
+                         ("product_2_16", PRODUCT_TOTAL // 4, "the per-GPU shard of configs[3] at 4 GPUs: 2^16 pairs -> 1 Gt"),
                          ("product_2_15", PRODUCT_TOTAL // 8, "the per-GPU shard of configs[3] at 8 GPUs: 2^15 pairs -> 1 Gt (Miller loops, one-launch product tree, one final exponentiation)")):
         elapsed, kms, ktr = run_product(eng, dev, dist, P[:m], Q[:m], 3, 1)
         side[tag] = {"config": what, "value": m * 3 / elapsed, "unit": "pairs/s", "ms_per_step": elapsed / 3 * 1e3, "kernel_ms_per_step": kms, "kernel_traffic": ktr}
@@ -385,27 +527,44 @@ def side_object(eng, dev, dist, P16, Q16):
     return side
 
 
-def expected_scaling(workload, world):
-    """The prediction the first multi-GPU run tests, from ONE-GPU measurements only - nothing here was measured on
-    more than one GPU.  configs[2] (independent pairings) has no exchange: a per-GPU shard of 2^20/N is 16/N machine rounds of 2^16
-    pairings at the one-GPU rate, so the model is linear.  configs[3] (one product) is NOT: the per-GPU shard shrinks below what fills
-    the machine - 2^17 pairs still run two pairs per lane pair on a shared accumulator, 2^16 is one plain round, 2^15 is ONE wave per
-    SIMD (0.57 of the two-wave issue rate) - and the product tree, the 384-byte all-gather and the single final exponentiation do
-    not shrink at all."""
-    if workload == "pairing":
-        round_ms = 6.47                                          # one round of 2^16 pairings: profiles/r04z_bench_line.json
-        ms = (TOTAL_MULTI // world) / BATCH * round_ms
-        return {"ms_per_step": ms, "speedup_vs_1_gpu": float(world), "model": f"{TOTAL_MULTI // world // BATCH} rounds of 2^16 pairings x {round_ms} ms (one-GPU measurement), no exchange: linear",
-                "measured_on": "1 GPU only"}
-    if workload == "product":
-        # Miller part of the shard + one-launch product tree + tail (world-1 products, ONE final exponentiation); all-gather ~0.05 ms
-        parts = {1: (11.70, 0.21, 0.47), 2: (6.5, 0.20, 0.47), 4: (3.45, 0.20, 0.47), 8: (2.18, 0.15, 0.45)}.get(world)
-        if not parts:
+def scaling_inputs(line=None):
+    """the ONE-GPU measurements the scaling prediction is made of: the headline's milliseconds per round of 2^16 pairings and the whole-step
+    times of the configs[3] shards (2^18 / 2^17 / 2^16 / 2^15 pairs -> 1 Gt on one GPU).  From `line` (a bench line of THIS run that carries
+    the side object) or else from the latest committed one-GPU line (SCALING_SOURCE); None when neither has them."""
+    src = "this run"
+    if line is None or "side" not in line:
+        if not SCALING_SOURCE.exists():
             return None
-        ms = sum(parts) + (0.05 if world > 1 else 0.0)
-        return {"ms_per_step": ms, "speedup_vs_1_gpu": (11.70 + 0.21 + 0.47) / ms,
-                "model": "shard Miller loops %.2f ms (2^18/N pairs: 4, 2, 1 pairs per lane pair at N = 1, 2, 4; one wave per SIMD at N = 8) + product tree %.2f + tail %.2f + all-gather 0.05 "
-                         "(profiles/r04z_bench_line.json side.product_2_18 / product_2_15 and the headline's Miller kernel; N = 2: two pairs per lane pair, r03j_ab_shared_miller.txt scaled)" % parts, "measured_on": "1 GPU only"}
+        line = json.loads(SCALING_SOURCE.read_text().splitlines()[0]); src = str(SCALING_SOURCE.relative_to(ROOT))
+    side = line.get("side", {})
+    shards = {k: side[k]["ms_per_step"] for k in ("product_2_18", "product_2_17", "product_2_16", "product_2_15") if k in side}
+    if len(shards) != 4:
+        return None
+    return {"round_ms": line["ms_per_step"] * BATCH / line["config"]["pairings_per_gpu"], "product_ms": shards, "source": src}
+
+
+def expected_scaling(workload, world, inputs):
+    """The prediction the first multi-GPU run tests, made ONLY of one-GPU measurements (`inputs` = scaling_inputs()):
+    nothing here was measured on more than one GPU and nothing is a literal.  configs[2] (independent pairings) has no exchange: a per-GPU
+    shard of 2^20/N is 16/N machine rounds of 2^16 pairings at the one-GPU rate - linear.  configs[3] (one product) is NOT: the per-GPU shard
+    (2^18/N pairs -> one partial Fq12, measured as a whole step on one GPU: Miller loops + product tree + the single final exponentiation)
+    shrinks below what fills the machine, and the tree, the 384-byte all-gather and the final exponentiation do not shrink at all."""
+    if inputs is None:
+        return None
+    if workload == "pairing":
+        ms = (TOTAL_MULTI // world) / BATCH * inputs["round_ms"]
+        return {"ms_per_step": ms, "speedup_vs_1_gpu": float(world), "model": f"{TOTAL_MULTI // world // BATCH} rounds of 2^16 pairings x {inputs['round_ms']:.3f} ms (one-GPU measurement), no exchange: linear",
+                "inputs_from": inputs["source"], "measured_on": "1 GPU only"}
+    if workload == "product":
+        key = {1: "product_2_18", 2: "product_2_17", 4: "product_2_16", 8: "product_2_15"}.get(world)
+        if not key:
+            return None
+        allgather_ms = 0.05 if world > 1 else 0.0          # an ESTIMATE (3 KiB over xGMI: latency only); the one term not measured on one GPU
+        ms = inputs["product_ms"][key] + allgather_ms
+        return {"ms_per_step": ms, "speedup_vs_1_gpu": inputs["product_ms"]["product_2_18"] / ms,
+                "model": f"one-GPU step of the 2^18/{world}-pair shard ({key}: {inputs['product_ms'][key]:.3f} ms, incl. product tree and the one final exponentiation) + all-gather {allgather_ms} ms (estimate)"
+                         f" against {inputs['product_ms']['product_2_18']:.3f} ms for 2^18 pairs on one GPU",
+                "inputs_from": inputs["source"], "measured_on": "1 GPU only"}
     return None
 
 
@@ -441,7 +600,7 @@ def bench_multi_c(args):
     for _ in range(args.steps):
         step()
     elapsed = time.perf_counter() - t0
-    exp = expected_scaling("product" if product else "pairing", n_gpus) if total in (TOTAL_MULTI, PRODUCT_TOTAL) else None
+    exp = expected_scaling("product" if product else "pairing", n_gpus, scaling_inputs()) if total in (TOTAL_MULTI, PRODUCT_TOTAL) else None
     line = _line(("BN254 pairs/sec folded into one multi-pairing product" if product else "BN254 optimal-ate pairings/sec") + " (bit-exact vs ref)",
                  "pairs/s" if product else "pairings/s", total * args.steps / elapsed, n_gpus, args, elapsed, "strong" if n_gpus > 1 else "weak",
                  (f"product of 2^18 pairs -> 1 Gt (BASELINE.json configs[3])" if product else f"{total} independent pairings per step (BASELINE.json configs[{1 if n_gpus == 1 else 2}])")
@@ -471,6 +630,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="pairings per GPU per step (default: 2^16 at N = 1, 2^20/N at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the sampled power leg (1.2 s more of the headline step after the timed region)")
     ap.add_argument("--no-side", action="store_true", help="skip the `side` object (configs[3], configs[4], single-pairing latency) of the default line")
     ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product"], default="pairing",
                     help="pairing: the headline metric (default); the others are side metrics with their own line")
@@ -565,8 +725,17 @@ def main():
                 rf["hbm_GBps_of_8000"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
             if "traffic_per_step_all_kernels" in rf:
                 rf["traffic_ratio_whole_step"] = rf["traffic_per_step_all_kernels"] / (n * ALGO_BYTES_PER_PAIRING)
+            # the power-cap bound as a MEASUREMENT of this run: >= 1.2 s more of the same step, outside the timed region, sampled
+            if not args.no_power:
+                pw = PowerSampler(torch, dev).run(torch, dev, step, n, est_ms_per_step=elapsed / args.steps * 1e3)
+                pw["energy_uJ_per_pairing"] = pw.pop("energy_uJ_per_unit")
+                rf.update(pw)
+                if pw["power_W"] is not None:
+                    rf["bound"] = ("valu-int32-mac at the socket power cap (neither hbm nor mfma: SURVEY.md 8d): %.0f W of the %s W cap at sclk %s MHz under these kernels IN THIS RUN "
+                                   "(power_W / power_cap_W / sclk_MHz / energy_uJ_per_pairing of this object)"
+                                   % (pw["power_W"], "%.0f" % pw["power_cap_W"] if pw["power_cap_W"] else "?", "%.0f" % pw["sclk_MHz"] if pw["sclk_MHz"] else "?"))
             line = _line("BN254 optimal-ate pairings/sec (bit-exact vs ref)", "pairings/s", total * args.steps / elapsed, world, args, elapsed,
-                         scaling, workload, {"roofline": rf, **({"expected_scaling": expected_scaling("pairing", world)} if world > 1 and args.batch is None else {})},
+                         scaling, workload, {"roofline": rf, **({"expected_scaling": expected_scaling("pairing", world, scaling_inputs())} if world > 1 and args.batch is None else {})},
                          {"pairings_per_gpu": n, "inputs": "r*G1 / s*G2 (Jacobian, z != 1) resident in HBM", "parallelism": f"dp{world} (sharded, no collective)",
                           "number_system": "exact integer: 9 x 29-bit limbs in u32, v_mad_u64_u32 accumulation, Montgomery radix 2^261",
                           "mapping": 1,
@@ -578,6 +747,10 @@ def main():
                 Pn = P.cpu().numpy().view(np.uint64); Qn = Q.cpu().numpy().view(np.uint64)
                 if not args.no_side:
                     line["side"] = side_object(eng, dev, dist, P, Q)
+                    si = scaling_inputs(line)
+                    line["expected_scaling"] = {"what": "predicted whole-step time at N GPUs from THIS run's one-GPU measurements (what the first multi-GPU run is compared with)",
+                                                "configs[2]": {str(w): expected_scaling("pairing", w, si) for w in (2, 4, 8)},
+                                                "configs[3]": {str(w): expected_scaling("product", w, si) for w in (1, 2, 4, 8)}}
                 if not args.no_host_api:
                     line["host_api"] = host_api_rate(gpu_index, Pn, Qn)
                 if not args.no_cpu_baseline:

@@ -24,6 +24,12 @@ extern "C" {
     // prepared-G2 mode (the crate's internal G2Precomp, src/groups/mod.rs:472-483): 102 line coefficients per Q, then many P against them
     fn bn254_g2_precompute(ctx: *mut c_void, q: *const G2, coeffs: *mut EllCoeffs, n: usize) -> c_int;
     fn bn254_pairing_prepared_batch(ctx: *mut c_void, p: *const G1, coeffs: *const EllCoeffs, shared: c_int, out: *mut Gt, n: usize) -> c_int;
+    // native prepared-G2 mode: the device-resident counterpart of G2Precomp behind an opaque handle (include/bn254_hip.h bn254_g2_prepare)
+    fn bn254_g2_prepare(ctx: *mut c_void, q: *const G2, nq: usize, out: *mut *mut c_void) -> c_int;
+    fn bn254_g2_prepared_destroy(prep: *mut c_void);
+    fn bn254_g2_prepared_count(prep: *const c_void) -> usize;
+    fn bn254_g2_prepared_bytes(prep: *const c_void) -> usize;
+    fn bn254_pairing_prepared_native_batch(ctx: *mut c_void, p: *const G1, prep: *const c_void, out: *mut Gt, n: usize) -> c_int;
     // wire format of the crate's Encodable / Decodable impls (src/groups/mod.rs:143-205, src/fields/fp.rs:24-36), fixed-size records and the stream
     fn bn254_fr_encode_batch(ctx: *mut c_void, k: *const Fr, out: *mut u8, n: usize) -> c_int;
     fn bn254_fr_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut Fr, status: *mut i32, n: usize) -> c_int;
@@ -41,6 +47,7 @@ extern "C" {
     // tunables of a context (NULL = the default context of the current device): BN254_OPT_* of include/bn254_hip.h; value < 0 = default
     fn bn254_ctx_set_option(ctx: *mut c_void, key: c_int, value: c_long) -> c_int;
     fn bn254_ctx_get_option(ctx: *mut c_void, key: c_int, value: *mut c_long) -> c_int;
+    fn bn254_ctx_get_option_raw(ctx: *mut c_void, key: c_int, value: *mut c_long) -> c_int;
     fn bn254_multi_destroy(m: *mut c_void);
     fn bn254_pairing_batch_multi(m: *mut c_void, p: *const G1, q: *const G2, out: *mut Gt, n: usize) -> c_int;
     fn bn254_pairing_product_multi(m: *mut c_void, p: *const G1, q: *const G2, n: usize, out: *mut Gt) -> c_int;
@@ -53,6 +60,9 @@ extern "C" {
 pub struct EllCoeffs { pub ell_0: [u64; 8], pub ell_vw: [u64; 8], pub ell_vv: [u64; 8] }
 /// `BN254_PREPARED_COEFFS` of include/bn254_hip.h: coefficients per prepared point (G2Precomp.coeffs, src/groups/mod.rs:478-483)
 pub const PREPARED_COEFFS: usize = 102;
+/// `BN254_PREPARED_NATIVE_LINES` / `BN254_PREPARED_NATIVE_BYTES`: lines and device bytes per point of a `PreparedG2`
+pub const PREPARED_NATIVE_LINES: usize = 88;
+pub const PREPARED_NATIVE_BYTES: usize = 33792;
 /// `BN254_FR_WIRE_BYTES` / `BN254_G1_WIRE_BYTES` / `BN254_G2_WIRE_BYTES`
 pub const FR_WIRE_BYTES: usize = 32;
 pub const G1_WIRE_BYTES: usize = 65;
@@ -73,6 +83,12 @@ pub enum GpuOption {
 /// sets an option of the process-wide default context of the current HIP device; `None` restores the default
 pub fn set_option(key: GpuOption, value: Option<i64>) -> Result<(), GpuError> {
     check(unsafe { bn254_ctx_set_option(std::ptr::null_mut(), key as c_int, value.unwrap_or(-1) as c_long) })
+}
+/// the explicitly set value of an option of the default context, `None` while its default is in effect
+pub fn get_option_raw(key: GpuOption) -> Result<Option<i64>, GpuError> {
+    let mut v: c_long = 0;
+    check(unsafe { bn254_ctx_get_option_raw(std::ptr::null_mut(), key as c_int, &mut v) })?;
+    Ok(if v < 0 { None } else { Some(v as i64) })
 }
 /// the effective value of an option of the default context
 pub fn get_option(key: GpuOption) -> Result<i64, GpuError> {
@@ -183,6 +199,35 @@ pub fn pairing_prepared_batch(p: &[G1], coeffs: &[EllCoeffs]) -> Result<Vec<Gt>,
     let mut out = vec![Gt::one(); p.len()];
     check(unsafe { bn254_pairing_prepared_batch(std::ptr::null_mut(), p.as_ptr(), coeffs.as_ptr(), shared as c_int, out.as_mut_ptr(), p.len()) })?;
     Ok(out)
+}
+
+/// G2 points prepared ONCE for many pairings (a verification key): the device-native counterpart of the crate's internal `G2Precomp`
+/// (src/groups/mod.rs:472-483, `precompute` :557-588) - the line functions of the Miller loop in the form the kernels consume, resident in GPU
+/// memory (33 792 bytes per point) on the default context's device.  Immutable after creation, hence `Sync`.
+pub struct PreparedG2(*mut c_void);
+unsafe impl Send for PreparedG2 {}
+unsafe impl Sync for PreparedG2 {}
+
+impl PreparedG2 {
+    /// `q.len() == 1`: one point for every `p`; otherwise point `i` is paired with `p[i]`
+    pub fn new(q: &[G2]) -> Result<PreparedG2, GpuError> {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { bn254_g2_prepare(std::ptr::null_mut(), q.as_ptr(), q.len(), &mut h) })?;
+        Ok(PreparedG2(h))
+    }
+    pub fn len(&self) -> usize { unsafe { bn254_g2_prepared_count(self.0) } }
+    pub fn device_bytes(&self) -> usize { unsafe { bn254_g2_prepared_bytes(self.0) } }
+    /// `out[i] = bn::pairing(p[i], q)` for a one-point handle, `bn::pairing(p[i], q[i])` otherwise (src/lib.rs:181-183 through
+    /// src/groups/mod.rs:486-519: `precompute` happened in `new`)
+    pub fn pairing_batch(&self, p: &[G1]) -> Result<Vec<Gt>, GpuError> {
+        assert!(self.len() == 1 || p.len() <= self.len());
+        let mut out = vec![Gt::one(); p.len()];
+        check(unsafe { bn254_pairing_prepared_native_batch(std::ptr::null_mut(), p.as_ptr(), self.0, out.as_mut_ptr(), p.len()) })?;
+        Ok(out)
+    }
+}
+impl Drop for PreparedG2 {
+    fn drop(&mut self) { unsafe { bn254_g2_prepared_destroy(self.0) } }
 }
 
 /// the crate's `Encodable for Fr` (src/fields/fp.rs:24-36): 32 big-endian bytes per scalar

@@ -27,6 +27,7 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_ctx_set_mapping": [_VP, C.c_int],
     "bn254_ctx_set_option": [_VP, C.c_int, C.c_long],
     "bn254_ctx_get_option": [_VP, C.c_int, C.POINTER(C.c_long)],
+    "bn254_ctx_get_option_raw": [_VP, C.c_int, C.POINTER(C.c_long)],
     "bn254_pairing_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_pairing_product": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_g1_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
@@ -101,6 +102,8 @@ def build(force=False, verbose=False):
     hdrs = sorted((HERE / "csrc").glob("*.hpp")) + [HERE.parent / "include" / "bn254_hip.h"]
     hdr_m = max(h.stat().st_mtime for h in hdrs)
     extra = os.environ.get("BN254_EXTRA_HIPCC_FLAGS", "").split()           # experiments only
+    if any("dpp-combine" in f for f in extra):                              # appended AFTER DEVICE_FLAGS, so it could turn the combiner back on
+        raise RuntimeError("BN254_EXTRA_HIPCC_FLAGS must not touch -amdgpu-dpp-combine: the library is only correct with the combiner off (DEVICE_FLAGS)")
     flags = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + DEVICE_FLAGS + extra
     OBJ_DIR.mkdir(exist_ok=True)
     stamp = OBJ_DIR / "flags.txt"

@@ -431,6 +431,14 @@ int bn254_ctx_get_option(bn254_ctx *ctx, int key, long *value) {
     return BN254_OK;
 }
 
+int bn254_ctx_get_option_raw(bn254_ctx *ctx, int key, long *value) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (key < 1 || key >= BN254_OPT_COUNT_ || !value) return BN254_E_BAD_ARG;
+    const long v = ctx->opt[key].load(std::memory_order_relaxed);
+    *value = v < 0 ? -1 : v;
+    return BN254_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- device-resident API
 constexpr size_t BN_N_MAX = (size_t)1 << 40;          // sanity bound on a batch; launches are cut to size internally
 #define BN_DEV_PROLOGUE(null_check, limit)                                           \

@@ -96,11 +96,11 @@ __device__ __forceinline__ void miller_B_body(const uint32_t *g1, const uint32_t
 
 // reference schedule: the Miller VALUES equal the reference's (bn254_miller_batch_dev, prepared-mode cross checks)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
-        miller_B_body<false>(g1, g2, f_out, n);
+    miller_B_body<false>(g1, g2, f_out, n);
 }
 // NAF schedule (pairing.hpp miller_loop_sched<true>): used wherever a final exponentiation follows
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_naf_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n) {
-        miller_B_body<true>(g1, g2, f_out, n);
+    miller_B_body<true>(g1, g2, f_out, n);
 }
 
 // Table of the exponentiation machine (pairing.hpp ExpTableVars) in global memory.  One Fq6 half of a slot is 27 dwords per lane,
@@ -149,7 +149,7 @@ struct ExpTableMem {
 constexpr size_t EXP_TABLE_DWORDS_PER_LANE = (size_t)k::EXP_SLOTS * 2 * 7 * 4;
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_final_exp_B(const uint32_t *f_in, uint32_t *out, uint32_t n, uint32_t *table) {
-        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -246,16 +246,16 @@ __device__ __forceinline__ void miller_shared_body(const uint32_t *g1, const uin
     if (live) f12_store(f, f_out + 96u * lp);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_shared2_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n, uint4 *state) {
-        miller_shared_body<2>(g1, g2, f_out, n, state);
+    miller_shared_body<2>(g1, g2, f_out, n, state);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_shared4_B(const uint32_t *g1, const uint32_t *g2, uint32_t *f_out, uint32_t n, uint4 *state) {
-        miller_shared_body<4>(g1, g2, f_out, n, state);
+    miller_shared_body<4>(g1, g2, f_out, n, state);
 }
 
 // ---- prepared-G2 mode: 102 line coefficients per Q, 48 u32 each (ell_0, ell_vw, ell_vv as Fq2 in the reference image)
 constexpr int NCOEFF = 102, COEFF_WORDS = 48;
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_g2_precompute_B(const uint32_t *g2, uint32_t *coeffs, uint32_t n) {
-        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 }
 // f[i] = miller_loop(coeffs, P[i])  (groups/mod.rs:486-519); coeff_stride = 0 shares one coefficient set among all P
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_prepared_B(const uint32_t *g1, const uint32_t *coeffs, uint32_t coeff_stride, uint32_t *f_out, uint32_t n) {
-        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 
 // out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
-        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -487,7 +487,7 @@ __device__ __noinline__ void gt_pow_gls_table_cold(const Fq12<F2> *base, const P
     gt_pow_gls_table(*base, t);
 }
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_pow_B(const uint32_t *a, const uint32_t *k, uint32_t *out, uint32_t n, uint32_t *table, int mode) {
-        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 }
 // out[i] = a[i]^-1   (Gt::inverse, lib.rs:172 -> fq12.rs:284-292; one Fq inversion per element, constant-time divsteps)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_inverse_B(const uint32_t *a, uint32_t *out, uint32_t n) {
-        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
 // cyclotomic elements, which is all a pairing ever feeds it; this kernel exists so that the reference's known answer for the function
 // (fields/mod.rs:171-201, an element OFF the subgroup) runs on the device literally.
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_exp_by_neg_z_B(const uint32_t *a, uint32_t *out, uint32_t n) {
-        uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t pair = t >> 1;
     bool live = pair < n;
     if (!live) pair = n - 1;

@@ -60,6 +60,8 @@
 // of every step of the Miller loop resp. of the three exponentiation loops of the final exponentiation, with the step number and the count
 #ifndef BN_MILLER_HOOK
 #define BN_MILLER_HOOK(step, total) ((void)0)
+#endif
+#ifndef BN_EXP_HOOK
 #define BN_EXP_HOOK(step, total) ((void)0)
 #endif
 #include "bn254_constants.hpp"
@@ -78,13 +80,17 @@
     } while (0)
 #define BN_SETB(x, LBV, VBV) ((x).lb = (LBV), (x).vb = (VBV), (x).sg = false)
 #define BN_IFB(...) __VA_ARGS__
-namespace bn254 { struct OpCounts { unsigned long mul, mul2, lc3, lc3w, norm, addsub, reduce, select; }; inline OpCounts &op_counts() { static OpCounts c{}; return c; } }
+// `macs`: the multiply instructions the GPU leaf issues for the operation (v_mad_u64_u32 / v_mad_i64_i32 / v_mul_lo / v_mul_hi): the EXECUTED
+// multiply-adds behind bench.py's roofline.frac_executed (profiles/executed_chain_lengths.json "mac_instructions_per_unit")
+namespace bn254 { struct OpCounts { unsigned long mul, mul2, lc3, lc3w, norm, addsub, reduce, select, macs; }; inline OpCounts &op_counts() { static OpCounts c{}; return c; } }
 #define BN_COUNT(f) (++bn254::op_counts().f)
+#define BN_COUNT_MACS(n) (bn254::op_counts().macs += (unsigned long)(n))
 #else
 #define BN_REQUIRE(cond, what) ((void)0)
 #define BN_SETB(x, LBV, VBV) ((void)0)
 #define BN_IFB(...)
 #define BN_COUNT(f) ((void)0)
+#define BN_COUNT_MACS(n) ((void)0)
 #endif
 
 namespace bn254 {
@@ -382,6 +388,7 @@ BN_FN Fe fe_lc4_core(const Fe &x, const Fe &y, const Fe &z, const Fe &w, bool ne
     constexpr bool K1 = !WIDE && C1 != 0 && A1 <= 2, K2 = !WIDE && !SIGN2 && C2 != 0 && A2 <= 2, K3 = !WIDE && C3 != 0 && A3 <= 2, K4 = !WIDE && C4 != 0 && A4 <= 2;
     constexpr bool LONE = (int)K1 + (int)K2 + (int)K3 + (int)K4 == 1;
     constexpr bool N1 = K1 && !(LONE && C1 != 1), N2 = K2 && !(LONE && C2 != 1), N3 = K3 && !(LONE && C3 != 1), N4 = K4 && !(LONE && C4 != 1);
+    BN_COUNT_MACS(1 + 9 * (1 + (C1 != 0 && !N1) + (C2 != 0 && !N2) + (C3 != 0 && !N3) + (C4 != 0 && !N4) + ((N1 || N2 || N3 || N4) ? 1 : 0)));   // v_mul_hi_i32 (quotient), then per limb: kq x (-q_i), one per wide term, one for the narrow sum
     BN_IFB(if (!((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4) && (C4 == 0 || w.lb <= 4)))
                std::fprintf(stderr, "fe_lc<%d,%d,%d,%d> lbs %u %u %u %u\n", C1, C2, C3, C4, x.lb, y.lb, z.lb, w.lb);)
     BN_REQUIRE((C1 == 0 || x.lb <= 4) && (C2 == 0 || y.lb <= 4) && (C3 == 0 || z.lb <= 4) && (C4 == 0 || w.lb <= 4), "fe_lc: input limbs must fit int32");
@@ -534,7 +541,7 @@ BN_FN Fe fe_mul_body(const Fe &a, const Fe &b) {
 #if !defined(BN_HOSTSIM)
     return fe_mul_asm(a, b);
 #endif
-    BN_COUNT(mul);
+    BN_COUNT(mul); BN_COUNT_MACS(171);
     BN_REQUIRE(!a.sg && !b.sg, "fe_mul on a signed lazy value");
     BN_REQUIRE(a.lb * b.lb <= 6, "fe_mul column overflow");
     BN_REQUIRE(a.vb * b.vb <= 169, "fe_mul value bound");
@@ -572,7 +579,7 @@ BN_FN Fe fe_sqr_body(const Fe &a) {
 #if !defined(BN_HOSTSIM)
     return fe_sqr_asm(a);
 #endif
-    BN_COUNT(mul);
+    BN_COUNT(mul); BN_COUNT_MACS(45 + 81 + 9);
     BN_REQUIRE(!a.sg, "fe_sqr on a signed lazy value");
     BN_REQUIRE(a.lb * a.lb <= 6, "fe_sqr column overflow");
     BN_REQUIRE(a.vb * a.vb <= 169, "fe_sqr value bound");
@@ -615,7 +622,7 @@ BN_FN Fe fe_mul2(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
 #if !defined(BN_HOSTSIM)
     return fe_mul2_asm(a, u, c, v);
 #endif
-    BN_COUNT(mul2);
+    BN_COUNT(mul2); BN_COUNT_MACS(252);
     BN_REQUIRE(!a.sg && !u.sg && !c.sg && !v.sg, "fe_mul2 on a signed lazy value");
     BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 6, "fe_mul2 column overflow");
     BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 338, "fe_mul2 value bound");           // <= 169: result < 2q;  <= 338: result < 3q
@@ -662,7 +669,7 @@ BN_FN Fe fe_mul2s(const Fe &a, const Fe &u, const Fe &c, const Fe &v) {
 #if !defined(BN_HOSTSIM)
     return fe_mul2s_asm(a, u, c, v);
 #endif
-    BN_COUNT(mul2);
+    BN_COUNT(mul2); BN_COUNT_MACS(252);
     BN_REQUIRE(a.lb * u.lb + c.lb * v.lb <= 2, "fe_mul2s column overflow (signed columns hold 27 terms of 2^58)");
     BN_REQUIRE(a.vb * u.vb + c.vb * v.vb <= 169, "fe_mul2s value bound");
     int64_t acc = 0;
@@ -709,6 +716,7 @@ BN_FN Fe fe_mul6(const Fe &a1, const Fe &u1, const Fe &c1, const Fe &v1, const F
     return fe_mul6_asm(a1, u1, c1, v1, a2, u2, c2, v2, a3, u3, c3, v3);
 #endif
     BN_COUNT(mul2); BN_COUNT(mul2); BN_COUNT(mul2);           // (counted as three dual products: the executed-chain figures stay comparable)
+    BN_COUNT_MACS(486 + 81 + 9);
     const Fe *x[6] = {&a1, &c1, &a2, &c2, &a3, &c3}, *y[6] = {&u1, &v1, &u2, &v2, &u3, &v3};
 #if defined(BN_BOUNDS)
     unsigned vsum = 0;
@@ -760,6 +768,7 @@ BN_FN Fe fe_mul5(const Fe &a1, const Fe &u1, const Fe &c1, const Fe &v1, const F
     return fe_mul5_asm(a1, u1, c1, v1, a2, u2, c2, v2, a3, u3);
 #endif
     BN_COUNT(mul2); BN_COUNT(mul2); BN_COUNT(mul);
+    BN_COUNT_MACS(405 + 81 + 9);
     const Fe *x[5] = {&a1, &c1, &a2, &c2, &a3}, *y[5] = {&u1, &v1, &u2, &v2, &u3};
 #if defined(BN_BOUNDS)
     unsigned vsum = 0;

@@ -53,6 +53,12 @@ class Engine:
         _native.check(self._lib.bn254_ctx_get_option(self._h, _native.OPTIONS[name], C.byref(v)))
         return v.value
 
+    def get_option_raw(self, name):
+        """the explicitly set value of an option, or None while its default is in effect"""
+        v = C.c_long()
+        _native.check(self._lib.bn254_ctx_get_option_raw(self._h, _native.OPTIONS[name], C.byref(v)))
+        return None if v.value < 0 else v.value
+
     def options(self, **kw):
         """context manager: set the given options, restore the previous RAW state (default or explicit) on exit"""
         eng = self
@@ -63,13 +69,8 @@ class Engine:
                     eng.set_option(k, raw)
 
             def __enter__(self_):
-                self_.saved = {}                   # name -> the RAW state to return to: None = default, else the explicit value
+                self_.saved = {k: eng.get_option_raw(k) for k in kw}          # name -> None (default) or the explicit value: read, never written
                 try:
-                    for k in kw:                   # is the current value the default?  (read, set -1, read, compare, put it back)
-                        old = eng.get_option(k); eng.set_option(k, None)
-                        raw = None if eng.get_option(k) == old else old
-                        self_.saved[k] = raw
-                        eng.set_option(k, raw)
                     for k, v in kw.items():
                         eng.set_option(k, v)
                 except Exception:                  # a rejected value (BN254_E_BAD_ARG) must not leave the context half-configured

@@ -138,6 +138,8 @@ enum {
 };
 int bn254_ctx_set_option(bn254_ctx *ctx, int key, long value);
 int bn254_ctx_get_option(bn254_ctx *ctx, int key, long *value);
+/* the RAW state of an option: the explicitly set value, or -1 while the default is in effect (what a scoped set / restore must save) */
+int bn254_ctx_get_option_raw(bn254_ctx *ctx, int key, long *value);
 
 /* ---- host-buffer entry points (what a binding of the reference's API calls) ------------------------------------------ */
 /* ctx == NULL uses a process-wide default context on the current HIP device. */

@@ -312,7 +312,15 @@ EXPORT void hsb_gt_product(const uint32_t *in, int n, uint32_t *o) {
 }
 #ifdef BN_BOUNDS
 EXPORT void hs_counts_reset() { op_counts() = OpCounts{}; }
-EXPORT void hs_counts_get(unsigned long *o) { OpCounts c = op_counts(); o[0] = c.mul; o[1] = c.mul2; o[2] = c.lc3; o[3] = c.lc3w; o[4] = c.norm; o[5] = c.addsub; o[6] = c.reduce; o[7] = c.select; }
+EXPORT void hs_counts_get(unsigned long *o) { OpCounts c = op_counts(); o[0] = c.mul; o[1] = c.mul2; o[2] = c.lc3; o[3] = c.lc3w; o[4] = c.norm; o[5] = c.addsub; o[6] = c.reduce; o[7] = c.select; o[8] = c.macs; }
+// the fused NAF Miller loop alone, as bn254_miller_naf_B runs it (prologue included): the executed-chain count of the headline kernel
+EXPORT void hsb_miller_naf(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
+    G1Aff<FeP> p; G2Aff<F2B> q;
+    pair_prologue<FeP>(f2_scalar_load((F2B *)0, g1), f2_scalar_load((F2B *)0, g1 + 8), f2_scalar_load((F2B *)0, g1 + 16),
+                       f2_load((F2B *)0, g2), f2_load((F2B *)0, g2 + 16), f2_load((F2B *)0, g2 + 32), p, q);
+    MillerStateVars<F2B, FeP> st;
+    f12_store(miller_loop_sched<true>(p, q, st), o);
+}
 EXPORT void hsb_miller_only(const uint32_t *g1, const uint32_t *g2, uint32_t *o) {
     G1Aff<FeP> p; G2Aff<F2B> q;
     pair_prologue<FeP>(f2_scalar_load((F2B *)0, g1), f2_scalar_load((F2B *)0, g1 + 8), f2_scalar_load((F2B *)0, g1 + 16),

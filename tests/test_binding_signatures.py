@@ -3,7 +3,7 @@
 165-167,181).  Every `fn bn254_*` declared in an `extern "C"` block of bindings/rust/src/lib.rs and in the Rust snippets of
 INTEGRATION.md is parsed and compared with its declaration in include/bn254_hip.h: name, arity, argument ORDER, pointer depth and
 const-ness per level, and the integer kinds (usize <-> size_t, c_long <-> long, c_int <-> int, i32 <-> int32_t, u8 <-> uint8_t,
-u64 <-> uint64_t, f64 <-> double); G1/G2/Gt/Fr <-> bn_g1/bn_g2/bn_gt/bn_fr; the opaque handles (bn254_ctx, bn254_multi) <-> c_void.
+u64 <-> uint64_t, f64 <-> double); G1/G2/Gt/Fr <-> bn_g1/bn_g2/bn_gt/bn_fr; the opaque handles (bn254_ctx, bn254_multi, bn254_g2_prepared) <-> c_void.
 The enum GpuOption is compared with BN254_OPT_*, the exchange kinds used by MultiGpu::with_exchange with BN254_EXCHANGE_*.
 The checker itself is tested: a swapped argument pair, a dropped `const`, a wrong integer kind and a wrong discriminant must all be
 reported."""
@@ -17,7 +17,7 @@ HEADER = ROOT / "include" / "bn254_hip.h"
 RUST_LIB = ROOT / "bindings" / "rust" / "src" / "lib.rs"
 INTEGRATION = ROOT / "INTEGRATION.md"
 
-C_BASE = {"void": "void", "bn254_ctx": "void", "bn254_multi": "void", "bn_g1": "g1", "bn_g2": "g2", "bn_gt": "gt", "bn_fr": "fr",
+C_BASE = {"void": "void", "bn254_ctx": "void", "bn254_multi": "void", "bn254_g2_prepared": "void", "bn_g1": "g1", "bn_g2": "g2", "bn_gt": "gt", "bn_fr": "fr",
           "bn_ell_coeffs": "ell", "uint8_t": "u8", "int32_t": "i32", "uint64_t": "u64", "size_t": "usize", "int": "int", "long": "long",
           "double": "f64", "char": "char"}
 RUST_BASE = {"c_void": "void", "G1": "g1", "G2": "g2", "Gt": "gt", "Fr": "fr", "EllCoeffs": "ell", "u8": "u8", "i32": "i32", "u64": "u64",
@@ -183,7 +183,13 @@ def test_option_and_exchange_discriminants():
     # record sizes and the coefficient count the wrappers carry as constants
     sizes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define BN254_(\w+?)(?:_WIRE_BYTES)? (\d+)", HEADER.read_text())}
     consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (\w+): usize = (\d+);", txt)}
-    assert consts == {"PREPARED_COEFFS": sizes["PREPARED_COEFFS"], "FR_WIRE_BYTES": sizes["FR"], "G1_WIRE_BYTES": sizes["G1"], "G2_WIRE_BYTES": sizes["G2"]}, (consts, sizes)
+    assert consts == {"PREPARED_COEFFS": sizes["PREPARED_COEFFS"], "PREPARED_NATIVE_LINES": sizes["PREPARED_NATIVE_LINES"], "PREPARED_NATIVE_BYTES": sizes["PREPARED_NATIVE_BYTES"],
+                      "FR_WIRE_BYTES": sizes["FR"], "G1_WIRE_BYTES": sizes["G1"], "G2_WIRE_BYTES": sizes["G2"]}, (consts, sizes)
+    # ... and the device code agrees with the header on the native table's shape (exported without a GPU)
+    import ctypes as C
+    lib = _native.lib()
+    lib.bn254_native_table_bytes_B.restype = C.c_size_t; lib.bn254_native_table_bytes_B.argtypes = [C.c_size_t]
+    assert lib.bn254_native_lines_B() == sizes["PREPARED_NATIVE_LINES"] and lib.bn254_native_table_bytes_B(3) == 3 * sizes["PREPARED_NATIVE_BYTES"]
     # the binding's own EllCoeffs mirrors bn_ell_coeffs: three arrays of 8 u64, in the header's order
     m = re.search(r"pub struct EllCoeffs \{([^}]*)\}", txt)
     assert m and re.findall(r"pub (\w+): \[u64; 8\]", m.group(1)) == re.search(r"typedef struct \{ uint64_t ([^;]*); \} bn_ell_coeffs", HEADER.read_text()).group(1).replace("[8]", "").split(", ")

@@ -20,7 +20,7 @@ ROOT = pathlib.Path(__file__).resolve().parents[1]
 def test_c_abi_exports_every_declared_symbol():
     from bn_amd import _native
     hdr = (ROOT / "include" / "bn254_hip.h").read_text()
-    declared = set(re.findall(r"^(?:int|void|const char \*|bn254_ctx \*)\s*\*?(bn254_\w+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|void|size_t|const char \*|bn254_ctx \*)\s*\*?(bn254_\w+)\s*\(", hdr, re.M))
     assert len(declared) >= 45
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
     _native.build()

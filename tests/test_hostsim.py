@@ -215,6 +215,34 @@ def test_prepared_mode_and_product_chain(oracle, hs, kats):
     assert np.array_equal(got, want)
 
 
+def test_native_prepared_mode(oracle, hs, kats):
+    """the NATIVE prepared-G2 kernels' code path (pairing.hpp precompute_native -> table -> miller_loop_native -> final exponentiation) with
+    every limb / value bound enforced: the reference's known answer (groups/mod.rs:773-796) through the table of its Q, random P incl. the
+    generator with z = 1 and infinity against the oracle's pairing(), the table's records canonical, and two Jacobian representations of one
+    Q giving the same table"""
+    import ctypes as C
+    U32 = C.POINTER(C.c_uint32)
+    lib = hs.lib
+    assert lib.hsb_native_lines() == 88
+    k = kats["test_reduced_pairing"]
+    P = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_decimal(FR, k["k1"])); Q = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, k["k2"]))
+    tab = np.zeros((88, 2, 48), np.uint32); out = np.zeros(48, np.uint64)
+    lib.hsb_native_precompute(Q.ctypes.data_as(U32), tab.ctypes.data_as(U32))
+    lib.hsb_native_pairing(P.ctypes.data_as(U32), tab.ctypes.data_as(U32), C.c_int(0), out.ctypes.data_as(U32))
+    assert oracle.fq12_to_ints(out) == [int(x) for x in k["expected"]]
+    tab2 = np.zeros_like(tab)
+    lib.hsb_native_precompute(oracle.g2_normalize(Q).ctypes.data_as(U32), tab2.ctypes.data_as(U32))
+    assert np.array_equal(tab, tab2)
+    for off in (0, 9, 18, 28, 37):                     # every stored operand is a canonical field element in 29-bit limbs
+        limbs = tab[:, :, off:off + 9].astype(object)
+        vals = sum(limbs[:, :, i] * (1 << (29 * i)) for i in range(9))
+        assert (vals < M.Q).all() and (tab[:, :, off:off + 8] < (1 << 29)).all()
+    rng = np.random.default_rng(33)
+    for Pi in (oracle.g1_one(), oracle.g1_zero(), oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)), oracle.g1_mul(oracle.g1_one(), oracle.fp_from_int(FR, M.R_ORD - 1))):
+        lib.hsb_native_pairing(np.ascontiguousarray(Pi).ctypes.data_as(U32), tab.ctypes.data_as(U32), C.c_int(0), out.ctypes.data_as(U32))
+        assert np.array_equal(out, oracle.pairing(Pi, Q))
+
+
 def test_gt_pow_windowed_chain(oracle, hs):
     """Gt::pow as bn254_gt_pow_B computes it (4-bit windows, general squarings), every limb/value bound enforced: pairing values, an
     element outside the cyclotomic subgroup (a raw Miller value) and edge exponents against the oracle's bit-serial pow"""
@@ -330,40 +358,48 @@ def test_group_addition_branches(oracle, hs):
 
 
 def executed_chain_lengths(oracle, hs):
-    """Fq-product equivalents (fe_mul + 1.5 x fe_mul2, both lanes of a lane pair) of the chains the side kernels execute, counted by
-    the host simulation of the device code on one unit (the control flow is data independent)"""
+    """(Fq-product equivalents, multiply instructions) per unit of the chains the kernels execute, counted by the host simulation of the
+    device code on one unit (the control flow is data independent).  Fq-product equivalents: fe_mul + 1.5 x fe_mul2, both lanes of a lane
+    pair - the scale of `roofline.frac` of the side kernels.  Multiply instructions: what the GPU leaves issue (v_mad_u64_u32, v_mad_i64_i32,
+    v_mul_lo, v_mul_hi: 171 per product, 252 per dual product, 576 / 495 per lazily reduced chain of six / five, the fused reductions' own),
+    PER LANE - the scale of `roofline.frac_executed`"""
     import ctypes as C
     rng = np.random.default_rng(77)
     k1, k2 = (oracle.fp_from_int(FR, int.from_bytes(rng.bytes(40), "little") % M.R_ORD) for _ in range(2))
     P = oracle.g1_mul(oracle.g1_one(), k1); Q = oracle.g2_mul(oracle.g2_one(), k1)
     g = oracle.pairing(P, Q)
-    def count(fn, *args, out_words):
-        hs.lib.hs_counts_reset()
-        hs.call(fn, *args, out_words=out_words)
-        a = (C.c_ulong * 8)(); hs.lib.hs_counts_get(a)
-        return int(a[0] + 1.5 * a[1])
     U32 = C.POINTER(C.c_uint32)
-    def count_raw(fn, *args):
+    prods, macs = {}, {}
+    def count_raw(name, lanes, fn, *args):
         hs.lib.hs_counts_reset()
         fn(*args)
-        a = (C.c_ulong * 8)(); hs.lib.hs_counts_get(a)
-        return int(a[0] + 1.5 * a[1])
-    # prepared-G2 mode: the Miller kernels alone, over the native table resp. the reference-image coefficients (both lanes of the pair)
+        a = (C.c_ulong * 16)(); hs.lib.hs_counts_get(a)
+        prods[name] = int(a[0] + 1.5 * a[1]); macs[name] = int(a[8]) // lanes
+    def count(name, lanes, fn, *args, out_words):
+        count_raw(name, lanes, lambda: hs.call(fn, *args, out_words=out_words))
+    count("g1_mul", 1, "hs_g1_mul_glv", P, k2, out_words=24)
+    count("g2_mul", 2, "hsb_g2_mul_gls", Q, k2, out_words=48)
+    count("gt_pow", 2, "hsb_gt_pow_auto", g, k2, out_words=96)                   # a pairing value: membership test + cyclotomic chain
+    # the headline kernels: the fused NAF Miller loop (prologue included) and the final exponentiation
+    count("miller", 2, "hsb_miller_naf", P, Q, out_words=96)
+    count("final_exp", 2, "hsb_final_exponentiation", oracle.miller_only(P, Q), out_words=96)
+    # prepared-G2 mode: the Miller kernels alone, over the native table resp. the reference-image coefficients
     tab = np.zeros(88 * 2 * 48, np.uint32); coeffs = np.zeros(102 * 24, np.uint64); o = np.zeros(48, np.uint64)
-    prep_native = count_raw(hs.lib.hsb_native_precompute, Q.ctypes.data_as(U32), tab.ctypes.data_as(U32))
-    native = count_raw(hs.lib.hsb_native_pairing, P.ctypes.data_as(U32), tab.ctypes.data_as(U32), C.c_int(1), o.ctypes.data_as(U32))
+    count_raw("g2_prepare_native", 2, hs.lib.hsb_native_precompute, Q.ctypes.data_as(U32), tab.ctypes.data_as(U32))
+    count_raw("miller_native", 2, hs.lib.hsb_native_pairing, P.ctypes.data_as(U32), tab.ctypes.data_as(U32), C.c_int(1), o.ctypes.data_as(U32))
     hs.lib.hsb_prepared_pairing(P.ctypes.data_as(U32), Q.ctypes.data_as(U32), coeffs.ctypes.data_as(U32), o.ctypes.data_as(U32))
-    prepared = count_raw(hs.lib.hsb_prepared_miller, P.ctypes.data_as(U32), coeffs.ctypes.data_as(U32), o.ctypes.data_as(U32))
-    return {"g1_mul": count("hs_g1_mul_glv", P, k2, out_words=24), "g2_mul": count("hsb_g2_mul_gls", Q, k2, out_words=48),
-            "gt_pow": count("hsb_gt_pow_auto", g, k2, out_words=96),             # a pairing value: membership test + cyclotomic chain
-            "miller_native": native, "miller_prepared": prepared, "g2_prepare_native": prep_native}
+    count_raw("miller_prepared", 2, hs.lib.hsb_prepared_miller, P.ctypes.data_as(U32), coeffs.ctypes.data_as(U32), o.ctypes.data_as(U32))
+    return prods, macs
 
 
 def test_executed_chain_lengths(oracle, hs):
-    """bench.py prices the side kernels' `roofline.frac` over the chain they EXECUTE: the committed figures are the simulation's"""
+    """bench.py prices `roofline.frac` of the side kernels over the chain they EXECUTE and `roofline.frac_executed` of every kernel over
+    the multiply instructions it issues: the committed figures are the simulation's"""
     import json, pathlib
-    want = json.loads((pathlib.Path(__file__).resolve().parents[1] / "profiles" / "executed_chain_lengths.json").read_text())["fq_products_per_unit"]
-    assert executed_chain_lengths(oracle, hs) == want
+    want = json.loads((pathlib.Path(__file__).resolve().parents[1] / "profiles" / "executed_chain_lengths.json").read_text())
+    prods, macs = executed_chain_lengths(oracle, hs)
+    assert prods == want["fq_products_per_unit"]
+    assert macs == want["mac_instructions_per_lane_and_unit"]
 
 
 def test_gt_pow_cyclotomic_chain(oracle, hs):

@@ -58,21 +58,31 @@ class OneLaneEngine:
     def close(self):
         pass
 
+    def _call(self, fn, *args):
+        """the bntd_* entry points launch on the process's CURRENT HIP device: make that this engine's device for the call"""
+        import torch
+        with torch.cuda.device(self._dev):
+            _check(fn(*args))
+
+    def _cur_stream(self):
+        import torch
+        return torch.cuda.current_stream(self._dev).cuda_stream
+
     # ---- device-pointer entry points (names and argument order of bn_amd.Engine)
     def miller_batch_dev(self, d_p, d_q, d_f, n, stream=0):
-        _check(self._lib.bntd_miller(d_p, d_q, d_f, n, stream))
+        self._call(self._lib.bntd_miller, d_p, d_q, d_f, n, stream)
 
     def final_exp_batch_dev(self, d_f, d_out, n, stream=0):
-        _check(self._lib.bntd_final_exp(d_f, d_out, n, stream))
+        self._call(self._lib.bntd_final_exp, d_f, d_out, n, stream)
 
     def pairing_batch_dev(self, d_p, d_q, d_out, n, stream=0):
-        _check(self._lib.bntd_miller(d_p, d_q, d_out, n, stream)); _check(self._lib.bntd_final_exp(d_out, d_out, n, stream))
+        self._call(self._lib.bntd_miller, d_p, d_q, d_out, n, stream); self._call(self._lib.bntd_final_exp, d_out, d_out, n, stream)
 
     def g1_mul_dev(self, d_p, d_k, d_out, n, stream=0, normalize=True):
-        _check(self._lib.bntd_g1_mul(d_p, d_k, d_out, n, 1 if normalize else 0, stream))
+        self._call(self._lib.bntd_g1_mul, d_p, d_k, d_out, n, 1 if normalize else 0, stream)
 
     def g2_mul_dev(self, d_p, d_k, d_out, n, stream=0, normalize=True):
-        _check(self._lib.bntd_g2_mul(d_p, d_k, d_out, n, 1 if normalize else 0, stream))
+        self._call(self._lib.bntd_g2_mul, d_p, d_k, d_out, n, 1 if normalize else 0, stream)
 
     def synthetic_scalars_dev(self, *a, **k):
         raise NotImplementedError("inputs are generated with the product engine")
@@ -92,7 +102,7 @@ class OneLaneEngine:
         import torch
         dp, dq = self._up(p, 12), self._up(q, 24)
         out = torch.empty(dp.shape[0], 48, dtype=torch.int64, device=self._dev)
-        self.pairing_batch_dev(dp.data_ptr(), dq.data_ptr(), out.data_ptr(), dp.shape[0])
+        self.pairing_batch_dev(dp.data_ptr(), dq.data_ptr(), out.data_ptr(), dp.shape[0], self._cur_stream())
         return self._down(out)
 
     def pairing_product(self, p, q):
@@ -103,16 +113,17 @@ class OneLaneEngine:
         f = torch.empty(n, 48, dtype=torch.int64, device=self._dev)
         tmp = torch.empty(2 * ((n + 3) // 4) + 1, 48, dtype=torch.int64, device=self._dev)
         one = torch.empty(1, 48, dtype=torch.int64, device=self._dev)
-        _check(self._lib.bntd_miller(dp.data_ptr(), dq.data_ptr(), f.data_ptr(), n, 0))
-        _check(self._lib.bntd_gt_product(f.data_ptr(), n, one.data_ptr(), tmp.data_ptr(), 0))
-        _check(self._lib.bntd_final_exp(one.data_ptr(), one.data_ptr(), 1, 0))
+        st = self._cur_stream()
+        self._call(self._lib.bntd_miller, dp.data_ptr(), dq.data_ptr(), f.data_ptr(), n, st)
+        self._call(self._lib.bntd_gt_product, f.data_ptr(), n, one.data_ptr(), tmp.data_ptr(), st)
+        self._call(self._lib.bntd_final_exp, one.data_ptr(), one.data_ptr(), 1, st)
         return self._down(one)[0]
 
     def _mul(self, fn, width, p, k):
         import torch
         dp, dk = self._up(p, width), self._up(k, 4)
         out = torch.empty_like(dp)
-        fn(dp.data_ptr(), dk.data_ptr(), out.data_ptr(), dp.shape[0])
+        fn(dp.data_ptr(), dk.data_ptr(), out.data_ptr(), dp.shape[0], self._cur_stream())
         return self._down(out)
 
     def g1_mul_batch(self, p, k):

@@ -19,6 +19,8 @@ KERNELS = {
     "bn254_miller_shared2_B": ("miller_shared2", lambda g: g // 2 * 2, 96 + 192 + 384 / 2),
     "bn254_miller_shared4_B": ("miller_shared", lambda g: g // 2 * 4, 96 + 192 + 384 / 4),
     "bn254_miller_prepared_B": ("miller_prepared", lambda g: g // 2, 96 + 384),
+    # one SHARED native table (33 792 B per Q, read by every lane): its algorithmic share per pairing is the table once per launch
+    "bn254_miller_native_B": ("miller_native", lambda g: g // 2, 96 + 384 + 33792 / 65536),
     "bn254_gt_pow_B": ("gt_pow", lambda g: g // 2, 384 + 32 + 384),
     "bn254_gt_mul_B": ("gt_mul", lambda g: g // 2, 3 * 384),
     "bn254_g1_mul_M": ("g1_mul", lambda g: g, 96 + 32 + 96),
