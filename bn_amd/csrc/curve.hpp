@@ -13,6 +13,13 @@
 
 namespace bn254 {
 
+// true when the predicate holds in ANY lane of the wave (a wave-uniform guard around work that almost no lane needs)
+#if defined(BN_HOSTSIM)
+BN_FN bool bn_any(bool b) { return b; }
+#else
+BN_FN bool bn_any(bool b) { return __any(b) != 0; }
+#endif
+
 // ---- field adaptors: the same generic point code runs over Fe (G1) and over an Fq2 mapping (G2) -------------------------
 struct FqField {
     using T = Fe;
@@ -196,6 +203,45 @@ BN_COARSE Jac<FqField> jac_madd_flags(const Jac<FqField> &p, const Aff<FqField> 
     }
     r.x = F::select(pz, r.x, q.x); r.y = F::select(pz, r.y, q.y); r.z = F::select(pz, r.z, F::one());
     r.x = F::select(qz, r.x, p.x); r.y = F::select(qz, r.y, p.y); r.z = F::select(qz, r.z, p.z);
+    return r;
+}
+// The mixed addition of the G1 window loop (scalar_mul_glv) with its bookkeeping fused in - same field elements X3, Y3, Z3 as above for
+// p + (q.x, +-q.y):
+//   * the table entry's sign (Booth digit, GLV half) is applied where y FIRST meets the accumulator: sd = +-S2 - Y1 is one fused reduction
+//     with a per-lane coefficient (fe_lc3_core SIGN2) instead of a full negation of q.y (a reduction of its own) and a select;
+//   * "the accumulator is at infinity afterwards" is read off H: Z3 = 2 Z1 H vanishes exactly when H does (Z1 != 0), which was tested anyway
+//     for the equal-points branch - instead of testing Z3 again in the caller;
+//   * S2 - Y1 == 0 is only evaluated when H == 0 in some lane of the wave (never, for valid inputs), and the signed y that an accumulator
+//     at infinity adopts only when some lane's accumulator is at infinity (the first one or two windows).
+// `pz`: the accumulator is at infinity; `qz`: the operand is (digit 0); returns the sum and updates `pz`.
+BN_COARSE Jac<FqField> jac_madd_signed(const Jac<FqField> &p, const Aff<FqField> &q, bool negate, bool &pz, bool qz) {
+    using F = FqField;
+    const Fe z1s = fe_sqr(p.z);
+    const Fe u2 = fe_mul(q.x, z1s), s2 = fe_mul(q.y, fe_mul(p.z, z1s));
+    const Fe h = fe_lc3<1, -1, 0>(u2, p.x, p.x), sd = fe_lc3_core<-1, 1, 0, true>(p.y, s2, s2, negate);
+    const bool hz = fe_is_zero_std(h);
+    bool same = false;
+    if (bn_any(hz)) same = hz && fe_is_zero_std(sd) && !pz && !qz;
+    Jac<F> r;
+    { const Fe zh = fe_mul(p.z, h); r.z = fe_norm(fe_add(zh, zh)); }
+    const Fe i = fe_sqr(fe_norm(fe_add(h, h)));
+    const Fe j = fe_mul(h, i);
+    const Fe v = fe_mul(p.x, i);
+    const Fe rr = fe_norm(fe_add(sd, sd));
+    r.x = fe_lc3<1, -1, -2>(fe_sqr(rr), j, v);
+    const Fe ny = fe_neg<1, 4>(p.y);                                             // -Y1, lazy (Y1 < 3q)
+    r.y = fe_mul2(rr, fe_sub<1, 3>(v, r.x), fe_norm(fe_add(ny, ny)), j);
+    if (same) {
+        const Jac<F> pc = p;
+        Jac<F> d = jac_double_cold(pc);
+        r.x = F::select(same, r.x, d.x); r.y = F::select(same, r.y, d.y); r.z = F::select(same, r.z, d.z);
+    }
+    if (bn_any(pz)) {                                                            // infinity + q = q, with q's sign
+        const Fe qy = F::select(negate, q.y, fe_lc3<-1, 0, 0>(q.y, q.y, q.y));
+        r.x = F::select(pz, r.x, q.x); r.y = F::select(pz, r.y, qy); r.z = F::select(pz, r.z, F::one());
+    }
+    r.x = F::select(qz, r.x, p.x); r.y = F::select(qz, r.y, p.y); r.z = F::select(qz, r.z, p.z);     // p + infinity = p, also when p is infinite
+    pz = qz ? pz : (!pz && hz && !same);                                         // opposite points (H == 0, S2 != Y1) sum to infinity
     return r;
 }
 // Window table -> COMMON z without an inversion.  Entry i = (X_i : Y_i : Z_i) is rescaled by s_i = prod_{j != i} Z_j to
@@ -428,6 +474,30 @@ BN_FN int booth_digit(const uint32_t *mag, int i) {
     return (int)((x >> 1) & 7u) + (int)(x & 1u) - (int)((x >> 4) << 3);
 }
 constexpr int GLV_WINDOWS = 33;          // 4 * 33 = 132 bits >= 129 + the Booth sign bit
+// The same digits as a STREAM, most significant window first: the magnitude is kept shifted so that the five bits of the current window
+// are the top bits of its top word - reading a digit is a shift of one register and moving on is NW funnel shifts (v_alignbit).
+// booth_digit above indexes the word array with the (wave-uniform but run-time) window number, which the compiler turns into a select
+// chain over the registers: 120 instructions per digit in the G1 window loop (round 6: tools/energy_mix.py bn254_g1_mul_ME, run 20).
+template <int NW, int WINDOWS>
+struct BoothStream {
+    uint32_t s[NW];
+    BN_FN void init(const uint32_t *mag) {                     // magnitude below 2^(4 WINDOWS - 1): window WINDOWS-1 to the top
+        constexpr int SH = 32 * NW - 4 * WINDOWS;
+        static_assert(SH > 0 && SH < 32, "BoothStream shift");
+#pragma unroll
+        for (int i = NW - 1; i >= 1; --i) s[i] = (mag[i] << SH) | (mag[i - 1] >> (32 - SH));
+        s[0] = mag[0] << SH;
+    }
+    BN_FN int digit() const {                                  // -8 b3 + 4 b2 + 2 b1 + b0 + b(-1) of the current window
+        const uint32_t x = s[NW - 1] >> 27;
+        return (int)((x >> 1) & 7u) + (int)(x & 1u) - (int)((x >> 4) << 3);
+    }
+    BN_FN void next() {
+#pragma unroll
+        for (int i = NW - 1; i >= 1; --i) s[i] = (s[i] << 4) | (s[i - 1] >> 28);
+        s[0] <<= 4;
+    }
+};
 
 template <class Tab>
 BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw, Tab &aff) {
@@ -447,6 +517,8 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw, 
     const Fe beta = fe_const(k::GLV_BETA);
     Jac<F> res = {F::zero(), F::one(), F::zero()};
     bool res_inf = true;
+    BoothStream<5, GLV_WINDOWS> d1, d2;
+    d1.init(g.m1); d2.init(g.m2);
 #pragma unroll 1
     for (int w = GLV_WINDOWS - 1; w >= 0; --w) {
         if (w != GLV_WINDOWS - 1) {
@@ -455,18 +527,17 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw, 
         }
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
-            const int d = booth_digit(half ? g.m2 : g.m1, w);
+            const int d = half ? d2.digit() : d1.digit();
             const int ad = d < 0 ? -d : d;
             const bool negate = (d < 0) != (half ? g.neg2 : g.neg1);
             Aff<F> q = aff.get(ad ? ad : 1);                      // digit 0: the operand is ignored (q_inf)
             if (half) q.x = fe_mul(q.x, beta);                    // phi(j P): the endomorphism commutes with the isomorphism
-            q.y = F::select(negate, q.y, F::template lc3<-1, 0, 0>(q.y, q.y, q.y));
             const bool q_inf = p_inf || ad == 0;
-            res = jac_madd_flags(res, q, res_inf, q_inf);
-            // the sum of two finite points may be infinity (opposite points: z = 2 Z1 H = 0), and partial sums of the two
-            // interleaved scalars can cancel for crafted inputs - so the flag is read off z (a carry-propagated sum of two products)
-            res_inf = F::is_zero_std(res.z);
+            // the sum of two finite points may be infinity (opposite points), and partial sums of the two interleaved scalars can cancel
+            // for crafted inputs - the flag follows the arithmetic (jac_madd_signed), it is not assumed
+            res = jac_madd_signed(res, q, negate, res_inf, q_inf);
         }
+        d1.next(); d2.next();
     }
     res.z = fe_mul(res.z, zc);                                    // back from the isomorphic curve
     return res;

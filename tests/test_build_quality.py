@@ -64,7 +64,8 @@ SPILL_CEILING = {
     "bn254_miller_B": 3, "bn254_miller_naf_B": 0, "bn254_final_exp_B": 7, "bn254_miller_shared2_B": 19, "bn254_miller_shared4_B": 19,
     "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 0, "bn254_g2_prepare_native_B": 0, "bn254_miller_native_B": 0, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 11, "bn254_gt_inverse_B": 4,
     "bn254_exp_by_neg_z_B": 4, "bn254_miller_naf_Q": 0, "bn254_final_exp_Q": 0,
-    "bn254_g1_mul_M": 0, "bn254_g1_mul_chain_M": 0,      # (outside the window loop: test_scalar_multiplication_loops_do_not_store_to_scratch)
+    "bn254_g1_mul_M": 7, "bn254_g1_mul_chain_M": 0,      # (round 6: 7, all in the loop's preheader - the digit streams and the GLV halves are set up there -
+                                                         #  and the epilogue; the window loop itself: test_scalar_multiplication_loops_do_not_store_to_scratch)
     "bn254_g2_mul_M": 0, "bn254_g2_mul_chain_M": 0, "bn254_g1_add_M": 0, "bn254_g2_add_M": 0,
     "bn254_final_exp_W": 0, "bn254_pairing_W": 0, "bn254_gt_tail_W": 0, "bn254_wave_ubench_W": 0, "bn254_gt_reduce_W": 2,
     "bn254_g1_encode_k": 0, "bn254_g2_encode_k": 0, "bn254_g1_decode_k": 0, "bn254_g2_decode_k": 18, "bn254_fr_encode_k": 0, "bn254_fr_decode_k": 0,
