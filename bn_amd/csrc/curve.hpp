@@ -488,10 +488,11 @@ struct BoothStream {
         for (int i = NW - 1; i >= 1; --i) s[i] = (mag[i] << SH) | (mag[i - 1] >> (32 - SH));
         s[0] = mag[0] << SH;
     }
-    BN_FN int digit() const {                                  // -8 b3 + 4 b2 + 2 b1 + b0 + b(-1) of the current window
-        const uint32_t x = s[NW - 1] >> 27;
+    static BN_FN int digit_of(uint32_t top_word) {             // -8 b3 + 4 b2 + 2 b1 + b0 + b(-1) of the window in the top five bits
+        const uint32_t x = top_word >> 27;
         return (int)((x >> 1) & 7u) + (int)(x & 1u) - (int)((x >> 4) << 3);
     }
+    BN_FN int digit() const { return digit_of(s[NW - 1]); }
     BN_FN void next() {
 #pragma unroll
         for (int i = NW - 1; i >= 1; --i) s[i] = (s[i] << 4) | (s[i - 1] >> 28);
@@ -607,6 +608,9 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
     const F2 zn = f2_mul(zc, f2_conj(zc));
     Jac<F> res = {F::zero(), F::one(), F::zero()};
     bool res_inf = true;
+    BoothStream<3, GLS_WINDOWS> ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ds[j].init(g.m[j]);
 #pragma unroll 1
     for (int w = GLS_WINDOWS - 1; w >= 0; --w) {
         if (w != GLS_WINDOWS - 1) {
@@ -615,7 +619,7 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
         }
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
-            const int d = booth_digit<3>(g.m[j], w);
+            const int d = BoothStream<3, GLS_WINDOWS>::digit_of(j == 0 ? ds[0].s[2] : j == 1 ? ds[1].s[2] : j == 2 ? ds[2].s[2] : ds[3].s[2]);
             const int ad = d < 0 ? -d : d;
             const bool negate = ((d < 0) != g.neg[j]) != (j >= 2);            // psi^2, psi^3 carry a minus sign on y
             Aff<F> q = aff.get(ad ? ad : 1);                       // digit 0: the operand is ignored (q_inf)
@@ -631,6 +635,8 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
             res = jac_madd_flags(res, q, res_inf, q_inf);
             res_inf = F::is_zero_std(res.z);                       // partial sums of the four interleaved parts can cancel
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ds[j].next();
     }
     res.z = F::mul(res.z, zn);                                     // back from the isomorphic curve
     return res;
@@ -680,11 +686,16 @@ BN_FN Fq12<F2> gt_pow_gls_loop(const uint32_t *k_raw, Tbl &tbl) {
         }
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
+            // (the digit STREAM of scalar_mul_gls is neutral here - 18.0 M pows/s either way - and costs the register allocation of the product
+            //  blocks 11 more spilled VGPRs: profiles/r06_ab_gtpow_mapped_table.txt)
             const int d = booth_digit<3>(g.m[j], w);
             const int ad = d < 0 ? -d : d;
             const bool neg = (d < 0) != g.neg[j];
             // res * conj(t) = conj(conj(res) * t): the sign goes on the running value, the table operand takes the plain path
             res.c1 = f6_cond_neg(neg, res.c1);
+            // (forming the Frobenius image when an entry is USED instead of storing 24 images per element - 9 table entries instead of 33, 0.75 GB of
+            //  stores less per 2^16 - was built and measured 11 % SLOWER: 54 maps of five Fq2 products by constants per element against 24, and the
+            //  stores were never the cost.  profiles/r06_ab_gtpow_mapped_table.txt)
             res = f12_mul_src(res, Fq12Slot<F2, Tbl>{tbl, ad ? 8 * j + ad : 0}, false);
             res.c1 = f6_cond_neg(neg, res.c1);
         }
