@@ -55,9 +55,9 @@ FQMUL_OWN = _CHAINS["fq_products_per_unit"]
 # behind `roofline.frac_executed`
 MAC_INSTR = _CHAINS["mac_instructions_per_lane_and_unit"]
 LANES_PER_UNIT = {"g1_mul": 1}                                    # every other kernel of these lines runs a unit on a lane pair
-# the latest committed one-GPU bench line: where an N > 1 run, which measures no side workloads itself, takes the one-GPU shard times of its
-# scaling prediction from (expected_scaling)
-SCALING_SOURCE = ROOT / "profiles" / "r06z_bench_line.json"
+# committed one-GPU bench lines, newest first: where an N > 1 run, which measures no side workloads itself, takes the one-GPU shard times of
+# its scaling prediction from (expected_scaling) - the first one that carries all four configs[3] shard sizes
+SCALING_SOURCES = sorted((ROOT / "profiles").glob("r[0-9][0-9]?_bench_line.json"), reverse=True)
 
 
 def _barrier(dist, dev):
@@ -531,16 +531,18 @@ def scaling_inputs(line=None):
     """the ONE-GPU measurements the scaling prediction is made of: the headline's milliseconds per round of 2^16 pairings and the whole-step
     times of the configs[3] shards (2^18 / 2^17 / 2^16 / 2^15 pairs -> 1 Gt on one GPU).  From `line` (a bench line of THIS run that carries
     the side object) or else from the latest committed one-GPU line (SCALING_SOURCE); None when neither has them."""
-    src = "this run"
-    if line is None or "side" not in line:
-        if not SCALING_SOURCE.exists():
-            return None
-        line = json.loads(SCALING_SOURCE.read_text().splitlines()[0]); src = str(SCALING_SOURCE.relative_to(ROOT))
-    side = line.get("side", {})
-    shards = {k: side[k]["ms_per_step"] for k in ("product_2_18", "product_2_17", "product_2_16", "product_2_15") if k in side}
-    if len(shards) != 4:
-        return None
-    return {"round_ms": line["ms_per_step"] * BATCH / line["config"]["pairings_per_gpu"], "product_ms": shards, "source": src}
+    keys = ("product_2_18", "product_2_17", "product_2_16", "product_2_15")
+    cands = [("this run", line)] if line is not None and "side" in line else []
+    for f in SCALING_SOURCES:
+        try:
+            cands.append((str(f.relative_to(ROOT)), json.loads(f.read_text().splitlines()[0])))
+        except (ValueError, IndexError):
+            continue
+    for src, ln in cands:
+        side = ln.get("side", {})
+        if all(k in side for k in keys) and ln.get("n_gpus") == 1:
+            return {"round_ms": ln["ms_per_step"] * BATCH / ln["config"]["pairings_per_gpu"], "product_ms": {k: side[k]["ms_per_step"] for k in keys}, "source": src}
+    return None
 
 
 def expected_scaling(workload, world, inputs):

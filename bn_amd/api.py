@@ -178,3 +178,28 @@ def pairing_product(ps, qs, engine=None):
     P = np.stack([p.limbs for p in ps]) if not isinstance(ps, np.ndarray) else ps
     Q = np.stack([q.limbs for q in qs]) if not isinstance(qs, np.ndarray) else qs
     return Gt(e.pairing_product(P, Q))
+
+
+class PreparedG2:
+    """G2 points prepared once for many pairings (the crate's internal G2Precomp, groups/mod.rs:472-483,557-588, as a device-resident
+    native table: Engine.g2_prepare).  One point: shared by every P; several: point i is paired with ps[i]."""
+
+    def __init__(self, qs, engine=None):
+        e = engine or default_engine()
+        Q = qs.limbs if isinstance(qs, G2) else (np.stack([q.limbs for q in qs]) if not isinstance(qs, np.ndarray) else qs)
+        self._e = e
+        self._h = e.g2_prepare(Q)
+
+    def __len__(self):
+        return self._h.count
+
+    def pairing(self, p):
+        """== pairing(p, q) for a one-point handle"""
+        return Gt(self._e.pairing_prepared_native_batch(p.limbs, self._h)[0])
+
+    def pairing_batch(self, ps):
+        P = np.stack([p.limbs for p in ps]) if not isinstance(ps, np.ndarray) else ps
+        return self._e.pairing_prepared_native_batch(P, self._h)
+
+    def close(self):
+        self._h.close()

@@ -93,6 +93,27 @@ inline Gt pairing_product(const std::vector<G1> &p, const std::vector<G2> &q) {
     return r;
 }
 
+// G2 points prepared ONCE for many pairings: the device-resident counterpart of the crate's internal G2Precomp (groups/mod.rs:472-483; `precompute`
+// :557-588 runs in the constructor, on the GPU).  One point: shared by every p; several: point i is paired with p[i].
+class PreparedG2 {
+    bn254_g2_prepared *h_ = nullptr;
+public:
+    explicit PreparedG2(const std::vector<G2> &q) { check(bn254_g2_prepare(nullptr, reinterpret_cast<const bn_g2 *>(q.data()), q.size(), &h_)); }
+    explicit PreparedG2(const G2 &q) { check(bn254_g2_prepare(nullptr, &q.v, 1, &h_)); }
+    ~PreparedG2() { bn254_g2_prepared_destroy(h_); }
+    PreparedG2(const PreparedG2 &) = delete;
+    PreparedG2 &operator=(const PreparedG2 &) = delete;
+    size_t size() const { return bn254_g2_prepared_count(h_); }
+    size_t device_bytes() const { return bn254_g2_prepared_bytes(h_); }
+    // out[i] == bn::pairing(p[i], q) (one prepared point) resp. bn::pairing(p[i], q[i])   (groups/mod.rs:486-519,764-771)
+    std::vector<Gt> pairing_batch(const std::vector<G1> &p) const {
+        std::vector<Gt> out(p.size());
+        check(bn254_pairing_prepared_native_batch(nullptr, reinterpret_cast<const bn_g1 *>(p.data()), h_, reinterpret_cast<bn_gt *>(out.data()), p.size()));
+        return out;
+    }
+    Gt pairing(const G1 &p) const { Gt r; check(bn254_pairing_prepared_native_batch(nullptr, &p.v, h_, &r.v, 1)); return r; }
+};
+
 // tunables of the default context (BN254_OPT_* of bn254_hip.h; value < 0 restores the default derived from the device)
 inline void set_option(int key, long value) { check(bn254_ctx_set_option(nullptr, key, value)); }
 inline long get_option(int key) { long v = 0; check(bn254_ctx_get_option(nullptr, key, &v)); return v; }

@@ -784,12 +784,17 @@ def test_bench_multi_c_mode(workload):
     assert d["mode"] == "multi_c" and d["pcie_inclusive"] is True and d["n_gpus"] == 2 and d["value"] > 0
     assert d["config"]["devices"] == [0, 0] and d["config"]["exchange"] == "peer" and len(d["config"]["rank_numa_nodes"]) == 2
     if workload == "product":
-        assert d["expected_scaling_kernels_only"]["speedup_vs_1_gpu"] > 1.5
+        es = d["expected_scaling_kernels_only"]
+        assert es["speedup_vs_1_gpu"] > 1.5
+        # the prediction is DERIVED from a committed one-GPU line (no literals in bench.py): it names the file and reproduces from it
+        src = json.loads((root / es["inputs_from"]).read_text().splitlines()[0])["side"]
+        assert abs(es["ms_per_step"] - (src["product_2_17"]["ms_per_step"] + 0.05)) < 1e-9
+        assert abs(es["speedup_vs_1_gpu"] - src["product_2_18"]["ms_per_step"] / es["ms_per_step"]) < 1e-9
 
 
 def test_cpp_host_drives_multi_device_entry_points(oracle, tmp_path):
-    """a compiled host program (g++, no Python in the loop) on include/bn254.hpp: bn::pairing, Gt::inverse, and bn::MultiGpu with two
-    ranks on device 0 - pairing_batch and pairing_product equal the oracle's fold of shootout/main.rs:11-16"""
+    """a compiled host program (g++, no Python in the loop) on include/bn254.hpp: bn::pairing, Gt::inverse, bn::MultiGpu with two
+    ranks on device 0 - pairing_batch and pairing_product equal the oracle's fold of shootout/main.rs:11-16 - and bn::PreparedG2"""
     import pathlib, subprocess
     root = pathlib.Path(__file__).resolve().parents[1]
     src = tmp_path / "host.cpp"
@@ -810,6 +815,10 @@ int main() {
     Gt e = pairing(p[1], q[1]);
     dump(e.inverse() * e);
     std::printf("%d\n", m.uses_rccl() ? 1 : 0);
+    PreparedG2 vk(q[1]);                                   // the native prepared mode from C++: precompute once, pair many
+    for (auto &g : vk.pairing_batch(p)) dump(g);
+    PreparedG2 all(q);
+    for (auto &g : all.pairing_batch(p)) dump(g);
     return 0;
 }
 ''')
@@ -828,6 +837,9 @@ int main() {
     assert np.array_equal(got[5], oracle.pairing_product(P, Q))
     assert np.array_equal(got[6], oracle.fq12_one())
     assert lines[7].strip() == "0"                     # two ranks on one device: peer-copy exchange, not RCCL
+    more = [np.array([int(x) for x in l.split()], np.uint64) for l in lines[8:18]]
+    assert np.array_equal(np.stack(more[:5]), oracle.pairing_batch(P, np.tile(Q[1], (5, 1))))          # bn::PreparedG2 of one point
+    assert np.array_equal(np.stack(more[5:]), want)                                                    # ... and of one point per pairing
 
 
 def test_config3_whole_2_20_on_one_gpu(oracle):
