@@ -229,3 +229,30 @@ def test_bench_relaunches_itself_for_multi_gpu():
     # second rank existed is in torchrun's own failure report
     assert out.stderr.count("bench.py needs an MI355X") >= 1, out.stderr[-1500:]
     assert out.stderr.count("bench.py needs an MI355X") >= 2 or "local_rank: 1" in out.stderr, out.stderr[-1500:]
+
+
+def test_scaling_prediction_is_made_of_measurements_only():
+    """bench.py's expected_scaling: every number in the prediction comes from a one-GPU bench line (this run's, or the newest
+    committed profiles/r*_bench_line.json that carries the four configs[3] shard sizes) - no literals: scaling the inputs scales the outputs, the
+    committed source reproduces, and the round-4 constants are gone from the source"""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    src = (ROOT / "bench.py").read_text()
+    body = src[src.index("def expected_scaling"):src.index("def bench_multi_c")]
+    for stale in ("11.70", "6.47", "6.5,", "3.45", "2.18"):
+        assert stale not in body, stale
+    si = bench.scaling_inputs()
+    assert si is not None and si["source"].startswith("profiles/r") and set(si["product_ms"]) == {"product_2_18", "product_2_17", "product_2_16", "product_2_15"}
+    line = json.loads((ROOT / si["source"]).read_text().splitlines()[0])
+    assert line["n_gpus"] == 1 and abs(si["round_ms"] - line["ms_per_step"]) < 1e-9
+    for w, key in ((2, "product_2_17"), (4, "product_2_16"), (8, "product_2_15")):
+        e = bench.expected_scaling("product", w, si)
+        assert abs(e["ms_per_step"] - (line["side"][key]["ms_per_step"] + 0.05)) < 1e-9 and e["inputs_from"] == si["source"]
+        assert bench.expected_scaling("pairing", w, si)["speedup_vs_1_gpu"] == float(w)
+    twice = {"round_ms": 2 * si["round_ms"], "product_ms": {k: 2 * v for k, v in si["product_ms"].items()}, "source": "synthetic"}
+    assert abs(bench.expected_scaling("pairing", 8, twice)["ms_per_step"] - 2 * bench.expected_scaling("pairing", 8, si)["ms_per_step"]) < 1e-9
+    assert abs(bench.expected_scaling("product", 1, twice)["ms_per_step"] - 2 * bench.expected_scaling("product", 1, si)["ms_per_step"]) < 1e-9
+    assert bench.expected_scaling("product", 4, None) is None                         # no measurements, no prediction
+    # a line of THIS run that carries the side object takes precedence over the committed file
+    fake = {"n_gpus": 1, "ms_per_step": 7.0, "config": {"pairings_per_gpu": 65536}, "side": {k: {"ms_per_step": 1.0} for k in si["product_ms"]}}
+    assert bench.scaling_inputs(fake)["source"] == "this run" and bench.scaling_inputs(fake)["round_ms"] == 7.0

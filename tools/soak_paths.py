@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Cross-path soak ON THE GPU BOX: the same pairings through the wave machine, the four-lane kernels and the lane-pair kernels must give
-the same bytes - for batch sizes around every threshold and wave / workgroup boundary, with points at infinity sprinkled in -, the
-multi-pairing product through its three routes likewise, and a slice of every batch against the CPU oracle.
+"""Cross-path soak ON THE GPU BOX: the same pairings through the wave machine, the four-lane kernels, the lane-pair kernels and the native
+prepared-G2 kernels (one table per pairing; one shared table) must give the same bytes - for batch sizes around every threshold and wave /
+workgroup boundary, with points at infinity sprinkled in -, the multi-pairing product through its three routes likewise, and a slice of every batch against the CPU oracle.
 tests/test_gpu_soak.py runs soak() as a -m gpu test (so the driver's round-end run executes it); as a tool:
     python tools/soak_paths.py > gpurun_out/soak.txt"""
 import pathlib, sys, time
@@ -40,6 +40,25 @@ def soak(te, oracle, sizes=SIZES, log=print):
                 prod = te.final_exp(te.miller_product(p, q)).clone() if n <= 40000 else None     # (the Miller products differ by factors the exponentiation kills)
                 outs[name + "_product"] = prod
             torch.cuda.synchronize()
+        # the native prepared-G2 path on the same pairs: one table per pairing (infinite Q included: its flag makes the pairing one), and for
+        # some sizes ONE shared table against the general path on a tiled Q
+        prep = e.g2_prepare_dev(q.data_ptr(), n, te._stream())
+        nat = te.empty(n, 48)
+        e.pairing_prepared_native_dev(p.data_ptr(), prep, nat.data_ptr(), n, stream=te._stream())
+        torch.cuda.synchronize()
+        outs["native_per_q"] = nat
+        prep.close()
+        if n in (1, 33, 257, 1025, 16385, 65537):
+            qs = Q[7:8].contiguous()                                                            # one point for all (were it one of the infinite ones, both sides would be one)
+            prep1 = e.g2_prepare_dev(qs.data_ptr(), 1, te._stream())
+            nat1 = te.empty(n, 48)
+            e.pairing_prepared_native_dev(p.data_ptr(), prep1, nat1.data_ptr(), n, stream=te._stream())
+            with e.options(**PATHS["lane_pair"]):
+                want1 = te.pairing_batch(p, qs.expand(n, 24).contiguous())
+            torch.cuda.synchronize()
+            same = bool(torch.equal(nat1, want1)); checked += 1; bad += not same
+            if not same: log(f"MISMATCH n={n} path=native_shared")
+            prep1.close()
         ref = outs["lane_pair"]
         for name, o in outs.items():
             if o is None or name == "lane_pair": continue
