@@ -450,8 +450,9 @@ def run_prepared(eng, dev, dist, P, Q, n, mode, steps, warmup):
     102 x 192 B: groups/mod.rs:472-483) converted by every lane at every line - kept for the reference's known answers.  Returns the wall
     time of `steps` steps, the roofline object of the Miller kernel and the per-kernel milliseconds."""
     out = eng.empty(n, 48)
-    if mode == "native":
-        prep = eng.e.g2_prepare_dev(Q.data_ptr(), 1, eng._stream())
+    if mode in ("native", "native_per_q"):
+        # native_per_q: one table PER PAIRING (n distinct Q, 33.8 KB each: 2.2 GB at 2^16) - the flavour in which the tables are real HBM traffic
+        prep = eng.e.g2_prepare_dev(Q.data_ptr(), n if mode == "native_per_q" else 1, eng._stream())
         step = lambda: eng.e.pairing_prepared_native_dev(P.data_ptr(), prep, out.data_ptr(), n, stream=eng._stream())
         kname = "miller_native"
     else:
@@ -468,7 +469,18 @@ def run_prepared(eng, dev, dist, P, Q, n, mode, steps, warmup):
     # the Miller kernel priced over the chain it EXECUTES (host-simulation count, profiles/executed_chain_lengths.json) - the convention of
     # the side kernels; `frac_vs_reference_chain`: over the reference's miller_loop (groups/mod.rs:486-519: 11 952 multiplications as written)
     rf = roofline(eng, {kname: st[kname]}, n, FQMUL_OWN[kname] * MAC32_PER_FQMUL, steps=ks, ref_mac32_per_unit=11952 * MAC32_PER_FQMUL)
-    if mode == "native":
+    if mode == "native_per_q":                      # the same kernel on another workload: its traffic entry is keyed separately (tools/summarize_pmc_all.py)
+        t = traffic_of("miller_native_per_q", n)
+        k = rf["kernels"][kname]
+        for f in ("traffic", "algorithmic_bytes", "traffic_ratio", "hbm_GBps"):
+            k.pop(f, None)
+        rf["traffic"] = rf["traffic_source"] = None
+        if t:
+            k.update({"traffic": t["traffic"], "algorithmic_bytes": t["algorithmic_bytes"], "traffic_ratio": t["traffic_ratio"], "hbm_GBps": t["traffic"] / (k["avg_launch_ms"] * 1e-3) / 1e9})
+            rf["traffic"], rf["traffic_source"] = t["traffic"], t["traffic_source"]
+        k["table_bytes_read_per_launch"] = n * 33792
+        k["table_GBps"] = n * 33792 / (k["avg_launch_ms"] * 1e-3) / 1e9
+    if mode.startswith("native"):
         prep.close()
     return elapsed, rf, {k: v[0] / max(v[1], 1) for k, v in st.items()}
 
@@ -482,10 +494,11 @@ def bench_prepared(args, eng, dev, world, rank):
     mode = args.prepared_mode
     elapsed, rf, kms = run_prepared(eng, dev, dist, P, Q, n, mode, args.steps, args.warmup)
     if rank == 0:
-        what = ("one device-native table (88 lines x 384 B, bn254_g2_prepare) read by all lanes" if mode == "native"
-                else "102 x 192 B reference-image coefficients (bn254_g2_precompute) shared by all lanes")
-        print(json.dumps(_line("BN254 pairings/sec against one prepared G2 point (bit-exact vs ref)", "pairings/s", world * n * args.steps / elapsed,
-                               world, args, elapsed, "weak", f"{n} random P against one prepared Q: {what}",
+        what = {"native": "against ONE prepared Q: one device-native table (88 lines x 384 B, bn254_g2_prepare) read by all lanes",
+                "native_per_q": f"against {n} prepared Q, one device-native table each (33.8 KB per pairing streamed from HBM)",
+                "reference": "against ONE prepared Q: 102 x 192 B reference-image coefficients (bn254_g2_precompute) shared by all lanes"}[mode]
+        print(json.dumps(_line("BN254 pairings/sec against prepared G2 points (bit-exact vs ref)", "pairings/s", world * n * args.steps / elapsed,
+                               world, args, elapsed, "weak", f"{n} random P {what}",
                                {"roofline": rf, "kernel_ms": kms}, {"prepared_mode": mode})), flush=True)
 
 
@@ -509,6 +522,11 @@ def side_object(eng, dev, dist, P16, Q16):
                                               frac_is="over the chain miller_native EXECUTES (7000 Fq-product equivalents per pairing: profiles/executed_chain_lengths.json); "
                                                       "frac_vs_reference_chain over the reference's miller_loop (11 952 multiplications, groups/mod.rs:486-519)",
                                               table_bytes_per_q=33792)}
+    el_q, prf_q, kms_q = run_prepared(eng, dev, dist, P16, Q16, BATCH, "native_per_q", 4, 1)
+    kq = prf_q["kernels"]["miller_native"]
+    side["prepared_2_16"]["one_table_per_pairing"] = {"value": BATCH * 4 / el_q, "unit": "pairings/s", "ms_per_step": el_q / 4 * 1e3, "kernel_ms": kms_q,
+                                                      "what": "2^16 distinct prepared Q, p[i] against table i: 33.8 KB per pairing streamed from HBM (2.2 GB per launch)",
+                                                      **{k: kq.get(k) for k in ("frac", "frac_executed", "table_GBps", "traffic", "algorithmic_bytes", "traffic_ratio", "hbm_GBps")}}
     _, _, kms_ref = run_prepared(eng, dev, dist, P16, Q16, BATCH, "reference", 3, 1)
     side["prepared_2_16"]["reference_image_kernel_ms"] = dict(kms_ref, what="the same step over the reference-image coefficients (bn254_g2_precompute, 102 x 192 B): the mode kept for the reference's known answers")
     P, Q = D.synthetic_points(eng, 0, PRODUCT_TOTAL)
@@ -636,7 +654,7 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the `side` object (configs[3], configs[4], single-pairing latency) of the default line")
     ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product"], default="pairing",
                     help="pairing: the headline metric (default); the others are side metrics with their own line")
-    ap.add_argument("--prepared-mode", choices=["native", "reference"], default="native",
+    ap.add_argument("--prepared-mode", choices=["native", "native_per_q", "reference"], default="native",
                     help="--workload prepared: the device-native table of bn254_g2_prepare (default) or the reference-image coefficients")
     ap.add_argument("--mode", choices=["dist", "multi_c"], default="dist",
                     help="dist (default, what the driver runs): one process per GPU over torch.distributed/RCCL, inputs resident in HBM; "

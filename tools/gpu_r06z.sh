@@ -14,6 +14,7 @@ for s in ${@:-smoke tests bench prof sq latency}; do
            timeout 900 python bench.py > $out/${tag}_bench_default_flags.json 2>> $out/${tag}_bench.err; python tools/brief_line.py < $out/${tag}_bench_default_flags.json | tee -a $out/${tag}_summary.txt
            for w in g1mul g2mul gtpow product prepared; do timeout 300 python bench.py --workload $w --steps 10 --warmup 2 >> $out/${tag}_side.json 2>> $out/${tag}_bench.err; done
            timeout 300 python bench.py --workload prepared --prepared-mode reference --steps 10 --warmup 2 >> $out/${tag}_side.json 2>> $out/${tag}_bench.err
+           timeout 300 python bench.py --workload prepared --prepared-mode native_per_q --steps 10 --warmup 2 >> $out/${tag}_side.json 2>> $out/${tag}_bench.err
            python -c "
 import json
 for l in open('$out/${tag}_side.json'):
@@ -32,6 +33,7 @@ for l in open('$out/${tag}_side.json'):
             for w in g1mul g2mul gtpow product prepared; do
               timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_${w}_$c -- python $repo/bench.py --workload $w --steps 2 --warmup 1 > $out/${tag}_pmc_${w}_$c.log 2>&1
             done
+            timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_prepq_$c -- python $repo/bench.py --workload prepared --prepared-mode native_per_q --steps 2 --warmup 1 > $out/${tag}_pmc_prepq_$c.log 2>&1
           done
           find $out -name "*.db" -delete 2>/dev/null; cd $repo
           python tools/summarize_pmc_all.py $tag $out/${tag}_pmc_* --gt_product=65536 2>&1 | tee -a $out/${tag}_summary.txt
@@ -39,6 +41,7 @@ for l in open('$out/${tag}_side.json'):
     pmcprep) cd /tmp
           for c in FETCH_SIZE WRITE_SIZE; do
             timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_prepared_$c -- python $repo/bench.py --workload prepared --steps 2 --warmup 1 > $out/${tag}_pmc_prepared_$c.log 2>&1
+            timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_prepq_$c -- python $repo/bench.py --workload prepared --prepared-mode native_per_q --steps 2 --warmup 1 > $out/${tag}_pmc_prepq_$c.log 2>&1
           done
           find $out -name "*.db" -delete 2>/dev/null; cd $repo
           python tools/summarize_pmc_all.py $tag $out/${tag}_pmc_* 2>&1 | tee -a $out/${tag}_summary.txt
