@@ -49,6 +49,10 @@ extern "C" {
     fn bn254_ctx_get_option(ctx: *mut c_void, key: c_int, value: *mut c_long) -> c_int;
     fn bn254_ctx_get_option_raw(ctx: *mut c_void, key: c_int, value: *mut c_long) -> c_int;
     fn bn254_multi_destroy(m: *mut c_void);
+    fn bn254_g2_prepare_multi(m: *mut c_void, q: *const G2, nq: usize, out: *mut *mut c_void) -> c_int;
+    fn bn254_multi_prepared_destroy(prep: *mut c_void);
+    fn bn254_multi_prepared_count(prep: *const c_void) -> usize;
+    fn bn254_pairing_prepared_native_batch_multi(m: *mut c_void, p: *const G1, prep: *const c_void, out: *mut Gt, n: usize) -> c_int;
     fn bn254_pairing_batch_multi(m: *mut c_void, p: *const G1, q: *const G2, out: *mut Gt, n: usize) -> c_int;
     fn bn254_pairing_product_multi(m: *mut c_void, p: *const G1, q: *const G2, n: usize, out: *mut Gt) -> c_int;
 }
@@ -365,6 +369,27 @@ impl MultiGpu {
         check(unsafe { bn254_pairing_product_multi(self.0, p.as_ptr(), q.as_ptr(), p.len(), &mut out) })?;
         Ok(out)
     }
+}
+/// G2 points prepared on the GPUs of a `MultiGpu` (one point: on every GPU; several: sharded like the pairings they will meet)
+pub struct MultiPreparedG2<'a> { h: *mut c_void, gpus: &'a MultiGpu }
+impl MultiGpu {
+    pub fn prepare_g2(&self, q: &[G2]) -> Result<MultiPreparedG2, GpuError> {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { bn254_g2_prepare_multi(self.0, q.as_ptr(), q.len(), &mut h) })?;
+        Ok(MultiPreparedG2 { h, gpus: self })
+    }
+}
+impl<'a> MultiPreparedG2<'a> {
+    pub fn len(&self) -> usize { unsafe { bn254_multi_prepared_count(self.h) } }
+    /// `out[i] = bn::pairing(p[i], q)` (one prepared point) resp. `bn::pairing(p[i], q[i])` (`p.len() == self.len()`), sharded over the GPUs
+    pub fn pairing_batch(&self, p: &[G1]) -> Result<Vec<Gt>, GpuError> {
+        let mut out = vec![Gt::one(); p.len()];
+        check(unsafe { bn254_pairing_prepared_native_batch_multi(self.gpus.0, p.as_ptr(), self.h, out.as_mut_ptr(), p.len()) })?;
+        Ok(out)
+    }
+}
+impl<'a> Drop for MultiPreparedG2<'a> {
+    fn drop(&mut self) { unsafe { bn254_multi_prepared_destroy(self.h) } }
 }
 impl Drop for MultiGpu {
     fn drop(&mut self) { unsafe { bn254_multi_destroy(self.0) } }

@@ -70,6 +70,10 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_multi_exchange_kind": [_VP],
     "bn254_multi_rank_numa_node": [_VP, C.c_int],
     "bn254_multi_ctx": [_VP, C.c_int],
+    "bn254_g2_prepare_multi": [_VP, _VP, _SZ, C.POINTER(_VP)],
+    "bn254_multi_prepared_destroy": [_VP],
+    "bn254_multi_prepared_count": [_VP],
+    "bn254_pairing_prepared_native_batch_multi": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_pairing_batch_multi": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_pairing_product_multi": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_synthetic_scalars_dev": [_VP, C.c_uint64, C.c_uint64, _SZ, C.c_int, _VP, _VP],
@@ -176,6 +180,8 @@ def lib():
         l.bn254_ctx_destroy.restype = None
         l.bn254_multi_destroy.restype = None
         l.bn254_g2_prepared_destroy.restype = None
+        l.bn254_multi_prepared_destroy.restype = None
+        l.bn254_multi_prepared_count.restype = C.c_size_t
         l.bn254_g2_prepared_count.restype = C.c_size_t
         l.bn254_g2_prepared_bytes.restype = C.c_size_t
         l.bn254_multi_ctx.restype = C.c_void_p

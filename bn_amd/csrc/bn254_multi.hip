@@ -248,6 +248,13 @@ struct bn254_multi {
     std::mutex mu;                          // one multi-device call at a time per handle
 };
 
+// bn254_g2_prepare_multi: one native prepared handle per rank (the whole point for nq == 1, the rank's shard of the points otherwise)
+struct bn254_multi_prepared {
+    bn254_multi *owner = nullptr;
+    size_t nq = 0;
+    std::vector<bn254_g2_prepared *> h;
+};
+
 extern "C" {
 
 static int multi_create(const int *devices, int ndev, int exchange, bn254_multi **out);
@@ -351,6 +358,57 @@ static int pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, b
     }, true);
     for (int rc : rcs) if (rc) return rc;
     return BN254_OK;
+}
+
+void bn254_multi_prepared_destroy(bn254_multi_prepared *prep) {
+    if (!prep) return;
+    for (auto h : prep->h) bn254_g2_prepared_destroy(h);
+    delete prep;
+}
+size_t bn254_multi_prepared_count(const bn254_multi_prepared *prep) { return prep ? prep->nq : 0; }
+static int g2_prepare_multi(bn254_multi *m, const bn_g2 *q, size_t nq, bn254_multi_prepared **out) {
+    if (!out) return BN254_E_BAD_ARG;
+    *out = nullptr;
+    if (!m || !q || nq == 0) return BN254_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const size_t G = m->ctx.size();
+    if (nq != 1 && nq < G) return BN254_E_BAD_ARG;                       // every rank needs at least one point of a sharded set
+    bn254_multi_prepared *pr = new bn254_multi_prepared();
+    pr->owner = m; pr->nq = nq; pr->h.assign(G, nullptr);
+    std::vector<int> rcs(G, BN254_OK);
+    const std::thread::id caller = std::this_thread::get_id();
+    run_workers((int)G, [&](int g) {
+        BnAffinityScope pin(m->cpus[(size_t)g], caller);
+        const size_t lo = nq == 1 ? 0 : nq * (size_t)g / G, hi = nq == 1 ? 1 : nq * ((size_t)g + 1) / G;
+        rcs[g] = bn254_g2_prepare(m->ctx[g], q + lo, hi - lo, &pr->h[(size_t)g]);
+    }, true);
+    for (int rc : rcs) if (rc) { bn254_multi_prepared_destroy(pr); return rc; }
+    *out = pr;
+    return BN254_OK;
+}
+static int pairing_prepared_native_batch_multi(bn254_multi *m, const bn_g1 *p, const bn254_multi_prepared *prep, bn_gt *out, size_t n) {
+    if (!m || !prep || prep->owner != m) return BN254_E_BAD_ARG;
+    if (n == 0) return BN254_OK;
+    if (!p || !out || (prep->nq != 1 && n != prep->nq)) return BN254_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const size_t G = m->ctx.size();
+    std::vector<int> rcs(G, BN254_OK);
+    const std::thread::id caller = std::this_thread::get_id();
+    run_workers((int)G, [&](int g) {
+        BnAffinityScope pin(m->cpus[(size_t)g], caller);
+        const size_t lo = n * (size_t)g / G, hi = n * ((size_t)g + 1) / G;               // the rule the points were sharded by
+        rcs[g] = bn254_pairing_prepared_native_batch(m->ctx[g], p + lo, prep->h[(size_t)g], out + lo, hi - lo);
+    }, true);
+    for (int rc : rcs) if (rc) return rc;
+    return BN254_OK;
+}
+int bn254_g2_prepare_multi(bn254_multi *m, const bn_g2 *q, size_t nq, bn254_multi_prepared **out) {
+    BnDeviceGuard dev_guard;
+    return bn_no_throw([&] { return g2_prepare_multi(m, q, nq, out); });
+}
+int bn254_pairing_prepared_native_batch_multi(bn254_multi *m, const bn_g1 *p, const bn254_multi_prepared *prep, bn_gt *out, size_t n) {
+    BnDeviceGuard dev_guard;
+    return bn_no_throw([&] { return pairing_prepared_native_batch_multi(m, p, prep, out, n); });
 }
 
 static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {

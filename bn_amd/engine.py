@@ -435,3 +435,46 @@ class MultiEngine:
         out = np.empty(GT_WORDS, np.uint64)
         _native.check(self._lib.bn254_pairing_product_multi(self._h, _p(p), _p(q), p.shape[0], _p(out)))
         return out
+
+    def g2_prepare(self, q):
+        """one point: prepared on every rank's GPU; n points: sharded over the ranks (then paired with exactly n points p)"""
+        q = _arr(q, G2_WORDS)
+        h = C.c_void_p()
+        _native.check(self._lib.bn254_g2_prepare_multi(self._h, _p(q), q.shape[0], C.byref(h)))
+        return MultiPreparedG2(self, h)
+
+    def pairing_prepared_native_batch(self, p, prepared, out=None):
+        p = _arr(p, G1_WORDS)
+        if out is None:
+            out = np.empty((p.shape[0], GT_WORDS), np.uint64)
+        _native.check(self._lib.bn254_pairing_prepared_native_batch_multi(self._h, _p(p), prepared._h, _p(out), p.shape[0]))
+        return out
+
+
+class MultiPreparedG2:
+    """handle of bn254_g2_prepare_multi: per-rank native tables"""
+
+    def __init__(self, multi, handle):
+        self._m = multi
+        self._p = handle
+
+    @property
+    def _h(self):
+        if self._p is None:
+            raise _native.Bn254Error("this MultiPreparedG2 is closed")
+        return self._p
+
+    @property
+    def count(self):
+        return int(self._m._lib.bn254_multi_prepared_count(self._h))
+
+    def close(self):
+        if getattr(self, "_p", None) and getattr(self._m, "_m", None):
+            self._m._lib.bn254_multi_prepared_destroy(self._p)
+        self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

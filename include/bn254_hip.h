@@ -220,6 +220,15 @@ int bn254_pairing_batch_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, bn
    (BASELINE configs[3]).  Bit-identical to the fold: the final exponentiation is a homomorphism and Gt values are canonical. */
 int bn254_pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out);
 
+/* native prepared-G2 mode over the GPUs of the handle.  ONE point (nq == 1) is prepared on every rank's GPU and n pairings shard like
+   bn254_pairing_batch_multi; nq > 1 points are sharded by the same rule ([nq*g/G, nq*(g+1)/G) on rank g) and then pair with exactly n == nq
+   points p[i] (point i with p[i]), so that tables and inputs of a shard live on the same GPU.  No exchange. */
+typedef struct bn254_multi_prepared bn254_multi_prepared;
+int bn254_g2_prepare_multi(bn254_multi *m, const bn_g2 *q, size_t nq, bn254_multi_prepared **out);
+void bn254_multi_prepared_destroy(bn254_multi_prepared *prep);
+size_t bn254_multi_prepared_count(const bn254_multi_prepared *prep);
+int bn254_pairing_prepared_native_batch_multi(bn254_multi *m, const bn_g1 *p, const bn254_multi_prepared *prep, bn_gt *out, size_t n);
+
 /* wire format of the crate's Encodable/Decodable impls for G1/G2 (groups/mod.rs:143-205, fields/fp.rs:24-36, fields/fq2.rs:31-53,
    arith.rs:100-159), as fixed-size batch records: [tag][x][y] with tag 4 and big-endian canonical coordinates (Fq2 = the 512-bit
    integer c1*q + c0); infinity is tag 0 followed by zero padding (the crate's stream emits the lone byte 0).  Decoding validates

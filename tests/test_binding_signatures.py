@@ -17,7 +17,7 @@ HEADER = ROOT / "include" / "bn254_hip.h"
 RUST_LIB = ROOT / "bindings" / "rust" / "src" / "lib.rs"
 INTEGRATION = ROOT / "INTEGRATION.md"
 
-C_BASE = {"void": "void", "bn254_ctx": "void", "bn254_multi": "void", "bn254_g2_prepared": "void", "bn_g1": "g1", "bn_g2": "g2", "bn_gt": "gt", "bn_fr": "fr",
+C_BASE = {"void": "void", "bn254_ctx": "void", "bn254_multi": "void", "bn254_g2_prepared": "void", "bn254_multi_prepared": "void", "bn_g1": "g1", "bn_g2": "g2", "bn_gt": "gt", "bn_fr": "fr",
           "bn_ell_coeffs": "ell", "uint8_t": "u8", "int32_t": "i32", "uint64_t": "u64", "size_t": "usize", "int": "int", "long": "long",
           "double": "f64", "char": "char"}
 RUST_BASE = {"c_void": "void", "G1": "g1", "G2": "g2", "Gt": "gt", "Fr": "fr", "EllCoeffs": "ell", "u8": "u8", "i32": "i32", "u64": "u64",

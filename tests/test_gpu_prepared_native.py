@@ -177,3 +177,26 @@ def test_full_size_shared_and_per_pairing(oracle):
     assert np.array_equal(out.cpu().numpy().view(np.uint64)[idx], oracle.pairing_batch(Pn[idx], np.tile(Qn[12345], (len(idx), 1))))
     prep1.close()
     e.close()
+
+
+def test_multi_device_entry_points_of_the_native_mode(oracle):
+    """bn254_g2_prepare_multi / bn254_pairing_prepared_native_batch_multi with two and three ranks on the one GPU: one shared point prepared on
+    every rank (ragged n), and a sharded set of points (p[i] against point i) - equal to the oracle; mismatched counts are rejected"""
+    import bn_amd
+    from bn_amd import _native
+    rng = np.random.default_rng(603)
+    n = 101
+    P = _g1(oracle, _scalars(rng, n)); Q = _g2(oracle, _scalars(rng, n))
+    P[5] = oracle.g1_zero(); Q[50] = oracle.g2_zero()
+    want = oracle.pairing_batch(P, Q)
+    for devs in ([0, 0], [0, 0, 0]):
+        m = bn_amd.MultiEngine(devs)
+        one = m.g2_prepare(Q[1])
+        assert one.count == 1
+        assert np.array_equal(m.pairing_prepared_native_batch(P, one), oracle.pairing_batch(P, np.tile(Q[1], (n, 1))))
+        allq = m.g2_prepare(Q)
+        assert allq.count == n
+        assert np.array_equal(m.pairing_prepared_native_batch(P, allq), want)
+        with pytest.raises(_native.Bn254Error):
+            m.pairing_prepared_native_batch(P[:50], allq)                  # a sharded set pairs with exactly as many points
+        one.close(); allq.close(); m.close()
