@@ -200,3 +200,19 @@ def test_multi_device_entry_points_of_the_native_mode(oracle):
         with pytest.raises(_native.Bn254Error):
             m.pairing_prepared_native_batch(P[:50], allq)                  # a sharded set pairs with exactly as many points
         one.close(); allq.close(); m.close()
+
+
+def test_python_mirror_of_the_prepared_mode(oracle):
+    """bn_amd.PreparedG2 (bn_amd/api.py): the crate-style objects - pairing(p, q) == PreparedG2(q).pairing(p), bilinear in p"""
+    import bn_amd
+    rng = np.random.default_rng(604)
+    p = bn_amd.G1.random(rng); q = bn_amd.G2.random(rng); s = bn_amd.Fr.random(rng)
+    vk = bn_amd.PreparedG2(q)
+    assert len(vk) == 1
+    assert vk.pairing(p) == bn_amd.pairing(p, q)
+    assert vk.pairing(p * s) == bn_amd.pairing(p, q).pow(s)
+    assert vk.pairing(bn_amd.G1.zero()) == bn_amd.Gt.one()
+    both = bn_amd.PreparedG2([q, q * s])
+    got = both.pairing_batch([p, p])
+    assert bn_amd.Gt(got[0]) == bn_amd.pairing(p, q) and bn_amd.Gt(got[1]) == bn_amd.pairing(p, q).pow(s)
+    vk.close(); both.close()
