@@ -216,3 +216,16 @@ def test_python_mirror_of_the_prepared_mode(oracle):
     got = both.pairing_batch([p, p])
     assert bn_amd.Gt(got[0]) == bn_amd.pairing(p, q) and bn_amd.Gt(got[1]) == bn_amd.pairing(p, q).pow(s)
     vk.close(); both.close()
+
+
+def test_committed_goldens_through_the_native_tables(goldens, eng):
+    """tests/golden/pairing_goldens.npz (96 pairings with edge scalars, made by the KAT-pinned oracle): every (g1, g2) pair through a native
+    table of its own g2, and the first g2 as ONE shared table against the pairs that use it"""
+    g1, g2, gt = goldens["g1"], goldens["g2"], goldens["gt"]
+    prep = eng.g2_prepare(g2)
+    assert np.array_equal(eng.pairing_prepared_native_batch(g1, prep), gt)
+    prep.close()
+    same = [i for i in range(len(g2)) if np.array_equal(g2[i], g2[0])]
+    one = eng.g2_prepare(g2[0])
+    assert np.array_equal(eng.pairing_prepared_native_batch(g1[same], one), gt[same])
+    one.close()
