@@ -566,7 +566,19 @@ int bn254_g2_prepare_dev(bn254_ctx *ctx, const void *d_q, size_t nq, bn254_g2_pr
         BnScope sc(ctx, s, "g2_prepare_native");
         rc = bn254_launch_g2_prepare_native_B(d_q, h->table, h->inf, nq, s);
     }
-    if (rc) { hipFree(h->table); hipFree(h->inf); delete h; return rc; }
+    // the points themselves stay with the handle: a SMALL call is served by the general path's one-pairing-per-wave kernels (1.0 ms for up to
+    // 1024 pairings, 1.95 ms at 3072 - the native Miller loop is a lane-pair kernel and needs 1.7 ms however few pairings there are:
+    // tools/prepared_latency.py).  One shared point is repeated small_max times by doubling copies.
+    h->small_max = (size_t)12 * (size_t)(ctx->cus > 0 ? ctx->cus : 256);
+    const size_t qn = nq == 1 ? h->small_max : nq;
+    if (!rc && hipMalloc(&h->q, qn * sizeof(bn_g2)) != hipSuccess) rc = BN254_E_ALLOC;
+    if (!rc && hipMemcpyAsync(h->q, d_q, nq * sizeof(bn_g2), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = BN254_E_INTERNAL;
+    if (!rc && nq == 1)
+        for (size_t have = 1; have < qn && !rc; have *= 2) {
+            const size_t cnt = have < qn - have ? have : qn - have;
+            if (hipMemcpyAsync((char *)h->q + have * sizeof(bn_g2), h->q, cnt * sizeof(bn_g2), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = BN254_E_INTERNAL;
+        }
+    if (rc) { hipFree(h->table); hipFree(h->inf); if (h->q) hipFree(h->q); delete h; return rc; }
     *out = h;
     return BN254_OK;
 }
@@ -574,11 +586,11 @@ void bn254_g2_prepared_destroy(bn254_g2_prepared *h) {
     if (!h) return;
     BnDeviceGuard dev_guard;
     hipSetDevice(h->device);
-    hipFree(h->table); hipFree(h->inf);
+    hipFree(h->table); hipFree(h->inf); hipFree(h->q);
     delete h;
 }
 size_t bn254_g2_prepared_count(const bn254_g2_prepared *h) { return h ? h->nq : 0; }
-size_t bn254_g2_prepared_bytes(const bn254_g2_prepared *h) { return h ? h->bytes + h->nq * sizeof(uint32_t) : 0; }
+size_t bn254_g2_prepared_bytes(const bn254_g2_prepared *h) { return h ? h->bytes + h->nq * sizeof(uint32_t) + (h->nq == 1 ? h->small_max : h->nq) * sizeof(bn_g2) : 0; }
 // p[i] against point (nq == 1 ? 0 : q_first + i): sub-launches of at most one machine round, like the fused Miller loop
 static int bn_launch_miller_native(bn254_ctx *c, const void *p, const bn254_g2_prepared *h, size_t q_first, void *f, size_t n, hipStream_t s) {
     const int shared = h->nq == 1;
@@ -602,6 +614,9 @@ int bn254_pairing_prepared_native_batch_dev(bn254_ctx *ctx, const void *d_p, con
     BN_DEV_PROLOGUE(!d_p || !d_out, BN_N_MAX);
     BN_PREP_CHECK();
     BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
+    // small calls: the whole pairing per WAVE on the points kept with the handle (same bytes out; BN254_OPT_WAVE_PAIRING_MAX = 0 turns this off)
+    const size_t small = prep->small_max < bn_wave_pairing_max(ctx) ? prep->small_max : bn_wave_pairing_max(ctx);
+    if (n <= small) return bn_launch_pairing(ctx, d_p, (const char *)prep->q + (prep->nq == 1 ? 0 : q_first) * sizeof(bn_g2), d_out, n, s, nullptr);
     rc = bn_launch_miller_native(ctx, d_p, prep, q_first, d_out, n, s); if (rc) return rc;
     return bn_launch_final_exp(ctx, d_out, d_out, n, s, nullptr);
 }

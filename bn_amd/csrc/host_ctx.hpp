@@ -108,6 +108,10 @@ struct bn254_g2_prepared {
     void *table = nullptr;
     void *inf = nullptr;
     size_t bytes = 0;
+    // the points themselves (192 B each; ONE point: repeated `small_max` times), for calls small enough that the one-pairing-per-wave kernels of
+    // the general path beat the lane-pair latency of the native Miller loop (bn254_pairing_prepared_native_batch_dev)
+    void *q = nullptr;
+    size_t small_max = 0;
 };
 
 // lease of pipeline slots for one host-buffer call (see bn254_ctx::slot_busy)

@@ -166,7 +166,9 @@ int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_co
    bit-identical to the reference (the Miller VALUE differs by subfield factors; the reference-image coefficients, for the reference's own
    known answers, are bn254_g2_precompute / bn_ell_coeffs above).  A handle made from ONE point is shared by all p[i]; a handle made from nq
    points pairs p[i] with point q_first + i (q_first + n <= nq; the host-buffer entry point uses q_first = 0).  A point at infinity in either
-   argument gives Gt::one() (groups/mod.rs:766).  The handle belongs to the context's device; it is immutable after creation, so any
+   argument gives Gt::one() (groups/mod.rs:766).  Calls of up to 12 x CUs pairings (3072) are served by the general path's one-pairing-per-wave kernels
+   on the points kept with the handle (1.0 ms instead of the 1.7 ms a lane-pair Miller loop needs however few pairings there are; same bytes;
+   BN254_OPT_WAVE_PAIRING_MAX = 0 turns that off).  The handle belongs to the context's device; it is immutable after creation, so any
    number of threads / streams may use it concurrently; destroy it after the last call that uses it has completed. */
 typedef struct bn254_g2_prepared bn254_g2_prepared;
 #define BN254_PREPARED_NATIVE_LINES 88

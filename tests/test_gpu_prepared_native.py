@@ -13,8 +13,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def eng():
+    """an engine whose SMALL prepared calls run the native kernels too (by default calls of up to 12 x CUs pairings are served by the general path's
+    one-pairing-per-wave kernels on the points kept with the handle: test_small_calls_are_routed_to_the_wave_kernels)"""
     import bn_amd
-    return bn_amd.Engine(0)
+    e = bn_amd.Engine(0)
+    e.set_option("wave_pairing_max", 0)
+    return e
 
 
 def _scalars(rng, n):
@@ -39,7 +43,7 @@ def test_reference_known_answer_through_the_native_table(oracle, kats, eng):
     k = kats["test_reduced_pairing"]
     P = oracle.g1_mul(oracle.g1_one(), oracle.fp_from_decimal(FR, k["k1"])); Q = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, k["k2"]))
     prep = eng.g2_prepare(Q)
-    assert prep.count == 1 and prep.device_bytes == 33792 + 4
+    assert prep.count == 1 and prep.device_bytes >= 33792 + 4 + 192          # table, infinity flag, the point itself (repeated for small calls)
     assert oracle.fq12_to_ints(eng.pairing_prepared_native_batch(P, prep)[0]) == [int(x) for x in k["expected"]]
     Q2 = oracle.g2_mul(oracle.g2_one(), oracle.fp_from_decimal(FR, kats["test_prepared_g2"]["k2"]))
     prep2 = eng.g2_prepare(Q2)
@@ -152,7 +156,7 @@ def test_full_size_shared_and_per_pairing(oracle):
     P, Q = D.synthetic_points(te, 0, n)
     # one table per pairing (2.2 GB of tables)
     prep = e.g2_prepare_dev(Q.data_ptr(), n, te._stream())
-    assert prep.count == n and prep.device_bytes == n * (33792 + 4)
+    assert prep.count == n and prep.device_bytes == n * (33792 + 4 + 192)
     out = te.empty(n, 48)
     e.pairing_prepared_native_dev(P.data_ptr(), prep, out.data_ptr(), n, stream=te._stream())
     ref = D.pairing_batch_sharded(te, P, Q)
@@ -191,6 +195,7 @@ def test_multi_device_entry_points_of_the_native_mode(oracle):
     want = oracle.pairing_batch(P, Q)
     for devs in ([0, 0], [0, 0, 0]):
         m = bn_amd.MultiEngine(devs)
+        m.set_option("wave_pairing_max", 0)                                # the native kernels, not the small-call route
         one = m.g2_prepare(Q[1])
         assert one.count == 1
         assert np.array_equal(m.pairing_prepared_native_batch(P, one), oracle.pairing_batch(P, np.tile(Q[1], (n, 1))))
@@ -229,3 +234,36 @@ def test_committed_goldens_through_the_native_tables(goldens, eng):
     one = eng.g2_prepare(g2[0])
     assert np.array_equal(eng.pairing_prepared_native_batch(g1[same], one), gt[same])
     one.close()
+
+
+def test_small_calls_are_routed_to_the_wave_kernels(oracle):
+    """default options: a prepared call of up to 12 x CUs pairings runs the general path's one-pairing-per-wave kernel on the points kept with the
+    handle (1.0 ms instead of the 1.7 ms of a lane-pair Miller loop), a larger one the native kernels - same bytes either way, and equal to the
+    same call with the route switched off"""
+    import bn_amd
+    rng = np.random.default_rng(605)
+    n = 300
+    P = _g1(oracle, _scalars(rng, n)); Q = _g2(oracle, _scalars(rng, n))
+    P[2] = oracle.g1_zero(); Q[4] = oracle.g2_zero()
+    e = bn_amd.Engine(0)
+    cus = e.get_option("round_pairs") // 256
+    one = e.g2_prepare(Q[0]); allq = e.g2_prepare(Q)
+    e.profile(True)
+    for prep, want in ((one, oracle.pairing_batch(P, np.tile(Q[0], (n, 1)))), (allq, oracle.pairing_batch(P, Q))):
+        e.profile_reset()
+        got = e.pairing_prepared_native_batch(P, prep)
+        assert e.kernel_stats("pairing_wave")[1] == 1 and e.kernel_stats("miller_native")[1] == 0
+        assert np.array_equal(got, want)
+        with e.options(wave_pairing_max=0):
+            e.profile_reset()
+            got2 = e.pairing_prepared_native_batch(P, prep)
+            assert e.kernel_stats("pairing_wave")[1] == 0 and e.kernel_stats("miller_native")[1] == 1
+        assert np.array_equal(got2, want)
+    # just above the route's limit: the native kernels, by default
+    big = 12 * cus + 1
+    Pb = np.tile(P, (big // n + 1, 1))[:big]
+    e.profile_reset()
+    gb = e.pairing_prepared_native_batch(Pb, one)
+    assert e.kernel_stats("miller_native")[1] == 1 and e.kernel_stats("pairing_wave")[1] == 0
+    assert np.array_equal(gb[:n], oracle.pairing_batch(P, np.tile(Q[0], (n, 1)))) and np.array_equal(gb[n:2 * n], gb[:n])
+    one.close(); allq.close(); e.close()

@@ -44,15 +44,23 @@ def soak(te, oracle, sizes=SIZES, log=print):
         # some sizes ONE shared table against the general path on a tiled Q
         prep = e.g2_prepare_dev(q.data_ptr(), n, te._stream())
         nat = te.empty(n, 48)
-        e.pairing_prepared_native_dev(p.data_ptr(), prep, nat.data_ptr(), n, stream=te._stream())
-        torch.cuda.synchronize()
+        with e.options(wave_pairing_max=0):                                                     # the native kernels at EVERY size (small calls are routed to the wave kernels by default)
+            e.pairing_prepared_native_dev(p.data_ptr(), prep, nat.data_ptr(), n, stream=te._stream())
+            torch.cuda.synchronize()
         outs["native_per_q"] = nat
+        if n <= 4097:                                                                           # ... and the default route on both sides of its limit
+            natd = te.empty(n, 48)
+            e.pairing_prepared_native_dev(p.data_ptr(), prep, natd.data_ptr(), n, stream=te._stream())
+            torch.cuda.synchronize()
+            outs["native_default_route"] = natd
         prep.close()
         if n in (1, 33, 257, 1025, 16385, 65537):
             qs = Q[7:8].contiguous()                                                            # one point for all (were it one of the infinite ones, both sides would be one)
             prep1 = e.g2_prepare_dev(qs.data_ptr(), 1, te._stream())
             nat1 = te.empty(n, 48)
-            e.pairing_prepared_native_dev(p.data_ptr(), prep1, nat1.data_ptr(), n, stream=te._stream())
+            with e.options(wave_pairing_max=0):
+                e.pairing_prepared_native_dev(p.data_ptr(), prep1, nat1.data_ptr(), n, stream=te._stream())
+                torch.cuda.synchronize()
             with e.options(**PATHS["lane_pair"]):
                 want1 = te.pairing_batch(p, qs.expand(n, 24).contiguous())
             torch.cuda.synchronize()
