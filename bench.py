@@ -428,6 +428,34 @@ def run_product(eng, dev, dist, P, Q, steps, warmup):
     return elapsed, {k: v[0] / ks for k, v in st.items()}, tr
 
 
+def run_product_prepared(eng, dev, dist, P, Q, steps, warmup):
+    """the multi-pairing product of the pairs (P[i], Q[i]) with every Q[i] prepared natively beforehand (not timed: a verifier's G2 points are fixed)"""
+    n = P.shape[0]
+    prep = eng.e.g2_prepare_dev(Q.data_ptr(), n, eng._stream())
+    part = eng.empty(1, 48)
+
+    def step():
+        eng.e.miller_product_prepared_native_dev(P.data_ptr(), prep, n, part.data_ptr(), stream=eng._stream())
+        eng.e.final_exp_batch_dev(part.data_ptr(), part.data_ptr(), 1, eng._stream())
+    elapsed = timed_steps(dist, dev, step, steps, warmup)
+    ks = min(steps, 3)
+    st = kernel_times(eng, dev, step, ("miller_native", "miller_native_shared") + PRODUCT_KERNELS, ks)
+    prep.close()
+    return elapsed, {k: v[0] / ks for k, v in st.items()}
+
+
+def bench_product_prepared(args, eng, dev, world, rank):
+    """side metric: configs[3] with the G2 side prepared natively, --batch pairs (default 2^18) per GPU -> one Gt per GPU (no exchange timed)"""
+    import torch.distributed as dist
+    from bn_amd import distributed as D
+    n = args.batch or PRODUCT_TOTAL
+    P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
+    elapsed, kms = run_product_prepared(eng, dev, dist, P, Q, args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps(_line("BN254 pairs/sec folded into one multi-pairing product over prepared G2 points (bit-exact vs ref)", "pairs/s", world * n * args.steps / elapsed,
+                               world, args, elapsed, "weak", f"product of {n} pairs -> 1 Gt per GPU, one native table (33.8 KB) per pair", {"kernel_ms_per_step": kms})), flush=True)
+
+
 def bench_product(args, eng, dev, world, rank):
     """side metric: BASELINE.json configs[3] - multi-pairing product of 2^18 pairs -> ONE Gt, sharded 2^18/N per GPU; the only
     workload with an exchange step: one RCCL all-gather of 384 B per rank, then world-1 Fq12 products and a single final
@@ -536,6 +564,12 @@ def side_object(eng, dev, dist, P16, Q16):
                          ("product_2_15", PRODUCT_TOTAL // 8, "the per-GPU shard of configs[3] at 8 GPUs: 2^15 pairs -> 1 Gt (Miller loops, one-launch product tree, one final exponentiation)")):
         elapsed, kms, ktr = run_product(eng, dev, dist, P[:m], Q[:m], 3, 1)
         side[tag] = {"config": what, "value": m * 3 / elapsed, "unit": "pairs/s", "ms_per_step": elapsed / 3 * 1e3, "kernel_ms_per_step": kms, "kernel_traffic": ktr}
+    # configs[3] with the G2 side PREPARED (what a verifier with fixed G2 points evaluates): one native table per pair, four pairs per accumulator
+    elapsed, kms = run_product_prepared(eng, dev, dist, P, Q, 3, 1)
+    side["product_prepared_2_18"] = {"config": "BASELINE.json configs[3] on ONE GPU over 2^18 natively prepared G2 points (bn254_miller_product_prepared_native_dev): 33.8 KB of table per pair "
+                                               "streamed from HBM, four pairs share one Miller accumulator, one final exponentiation", "value": PRODUCT_TOTAL * 3 / elapsed, "unit": "pairs/s",
+                                     "ms_per_step": elapsed / 3 * 1e3, "kernel_ms_per_step": kms, "table_GBps": PRODUCT_TOTAL * 33792 / (max(kms.get("miller_native_shared", 0.0), 1e-9) * 1e-3) / 1e9,
+                                     "vs_fused_product": side["product_2_18"]["ms_per_step"] / (elapsed / 3 * 1e3)}
     out1 = eng.empty(1, 48)
     step = lambda: eng.pairing_batch(P16[:1], Q16[:1], out1)
     elapsed = timed_steps(dist, dev, step, 20, 3)
@@ -652,7 +686,7 @@ def main():
     ap.add_argument("--no-host-api", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="skip the sampled power leg (1.2 s more of the headline step after the timed region)")
     ap.add_argument("--no-side", action="store_true", help="skip the `side` object (configs[3], configs[4], single-pairing latency) of the default line")
-    ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product"], default="pairing",
+    ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product", "product_prepared"], default="pairing",
                     help="pairing: the headline metric (default); the others are side metrics with their own line")
     ap.add_argument("--prepared-mode", choices=["native", "native_per_q", "reference"], default="native",
                     help="--workload prepared: the device-native table of bn254_g2_prepare (default) or the reference-image coefficients")
@@ -712,6 +746,8 @@ def main():
             return bench_gtpow(args, eng, dev, world, rank)
         if args.workload == "prepared":
             return bench_prepared(args, eng, dev, world, rank)
+        if args.workload == "product_prepared":
+            return bench_product_prepared(args, eng, dev, world, rank)
         if args.workload == "product":
             return bench_product(args, eng, dev, world, rank)
 

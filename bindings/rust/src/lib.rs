@@ -30,6 +30,7 @@ extern "C" {
     fn bn254_g2_prepared_count(prep: *const c_void) -> usize;
     fn bn254_g2_prepared_bytes(prep: *const c_void) -> usize;
     fn bn254_pairing_prepared_native_batch(ctx: *mut c_void, p: *const G1, prep: *const c_void, out: *mut Gt, n: usize) -> c_int;
+    fn bn254_pairing_product_prepared_native(ctx: *mut c_void, p: *const G1, prep: *const c_void, n: usize, out: *mut Gt) -> c_int;
     // wire format of the crate's Encodable / Decodable impls (src/groups/mod.rs:143-205, src/fields/fp.rs:24-36), fixed-size records and the stream
     fn bn254_fr_encode_batch(ctx: *mut c_void, k: *const Fr, out: *mut u8, n: usize) -> c_int;
     fn bn254_fr_decode_batch(ctx: *mut c_void, bytes: *const u8, out: *mut Fr, status: *mut i32, n: usize) -> c_int;
@@ -227,6 +228,13 @@ impl PreparedG2 {
         assert!(self.len() == 1 || p.len() <= self.len());
         let mut out = vec![Gt::one(); p.len()];
         check(unsafe { bn254_pairing_prepared_native_batch(std::ptr::null_mut(), p.as_ptr(), self.0, out.as_mut_ptr(), p.len()) })?;
+        Ok(out)
+    }
+    /// `fold(Gt::one(), |acc, i| acc * bn::pairing(p[i], q[i]))` (shootout/main.rs:11-16) with ONE final exponentiation
+    pub fn pairing_product(&self, p: &[G1]) -> Result<Gt, GpuError> {
+        assert!(self.len() == 1 || p.len() <= self.len());
+        let mut out = Gt::one();
+        check(unsafe { bn254_pairing_product_prepared_native(std::ptr::null_mut(), p.as_ptr(), self.0, p.len(), &mut out) })?;
         Ok(out)
     }
 }

@@ -57,6 +57,8 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_pairing_prepared_native_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_miller_prepared_native_dev": [_VP, _VP, _VP, _SZ, _VP, _SZ, _VP],
     "bn254_pairing_prepared_native_batch_dev": [_VP, _VP, _VP, _SZ, _VP, _SZ, _VP],
+    "bn254_pairing_product_prepared_native": [_VP, _VP, _VP, _SZ, _VP],
+    "bn254_miller_product_prepared_native_dev": [_VP, _VP, _VP, _SZ, _SZ, _VP, _VP],
     "bn254_gt_mul_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_gt_pow_batch": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_gt_inverse_batch": [_VP, _VP, _VP, _SZ],

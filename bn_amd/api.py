@@ -201,5 +201,10 @@ class PreparedG2:
         P = np.stack([p.limbs for p in ps]) if not isinstance(ps, np.ndarray) else ps
         return self._e.pairing_prepared_native_batch(P, self._h)
 
+    def pairing_product(self, ps):
+        """== fold(Gt::one(), acc * pairing(ps[i], q[i])) (shootout/main.rs:11-16) with ONE final exponentiation"""
+        P = np.stack([p.limbs for p in ps]) if not isinstance(ps, np.ndarray) else ps
+        return Gt(self._e.pairing_product_prepared_native(P, self._h))
+
     def close(self):
         self._h.close()

@@ -620,6 +620,40 @@ int bn254_pairing_prepared_native_batch_dev(bn254_ctx *ctx, const void *d_p, con
     rc = bn_launch_miller_native(ctx, d_p, prep, q_first, d_out, n, s); if (rc) return rc;
     return bn_launch_final_exp(ctx, d_out, d_out, n, s, nullptr);
 }
+// local part of a multi-pairing over prepared points: prod_i miller(p[i], point q_first + i), un-exponentiated.  The shared-accumulator kernels
+// (pairing.hpp miller_loop_native_shared) from two machine rounds of pairs on, like the fused path (miller_shared_m); a small call takes the
+// general path on the points kept with the handle.
+int bn254_miller_product_prepared_native_dev(bn254_ctx *ctx, const void *d_p, const bn254_g2_prepared *prep, size_t q_first, size_t n, void *d_partial, void *stream) {
+    int rc = bn_get_ctx(ctx); if (rc) return rc;
+    if (!d_partial || (n && !d_p) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    if (n == 0) return bn254_gt_product_dev(ctx, nullptr, 0, d_partial, stream);
+    BN_PREP_CHECK();
+    const size_t small = prep->small_max < bn_wave_pairing_max(ctx) ? prep->small_max : bn_wave_pairing_max(ctx);
+    if (n <= small) return bn254_miller_product_dev(ctx, d_p, (const char *)prep->q + (prep->nq == 1 ? 0 : q_first) * sizeof(bn_g2), n, d_partial, stream);
+    BnDeviceGuard dev_guard;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    BnScratchGuard g(ctx, s); if (g.rc) return g.rc;
+    const int m = miller_shared_m(ctx, n);
+    const size_t nv = (n + (size_t)m - 1) / (size_t)m;             // Miller values that reach the product tree
+    const size_t fbytes = nv * 384;
+    rc = ctx->ws.reserve(fbytes + bn_product_tmp_bytes(ctx, nv)); if (rc) return rc;
+    if (m == 1) {
+        rc = bn_launch_miller_native(ctx, d_p, prep, q_first, ctx->ws.p, n, s); if (rc) return rc;
+    } else {
+        const int shared = prep->nq == 1;
+        const size_t step = bn_sub_launch(ctx, nv);                // sub-launches of at most one round of LANE PAIRS, each with m pairs
+        for (size_t lo = 0; lo < nv; lo += step) {
+            const size_t groups = nv - lo < step ? nv - lo : step, first = lo * (size_t)m;
+            const size_t cnt = n - first < groups * (size_t)m ? n - first : groups * (size_t)m;
+            BnScope sc(ctx, s, "miller_native_shared");
+            rc = bn254_launch_miller_native_shared_B((const char *)d_p + first * sizeof(bn_g1), prep->table, prep->inf, prep->nq, shared ? 0 : q_first + first, shared,
+                                                     (char *)ctx->ws.p + lo * sizeof(bn_gt), cnt, m, s);
+            if (rc) return rc;
+        }
+    }
+    return bn_launch_product(ctx, ctx->ws.p, nv, d_partial, (char *)ctx->ws.p + fbytes, s);
+}
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream) {
     BN_DEV_PROLOGUE(!d_a || !d_b || !d_out, BN_N_MAX);
     return bn_for_parts(n, BN_LAUNCH_MAX, [&](size_t lo, size_t cnt) -> int {
@@ -745,10 +779,12 @@ int bn254_g2_prepare(bn254_ctx *ctx, const bn_g2 *q, size_t nq, bn254_g2_prepare
     return BN254_OK;
 }
 int bn254_g2_prepared_export(bn254_ctx *ctx, const bn254_g2_prepared *prep, void *host_table, size_t bytes) {
-    if (!prep || !host_table || bytes != prep->bytes) return BN254_E_BAD_ARG;
+    if (!prep || !host_table || bytes != prep->nq * (size_t)BN254_PREPARED_NATIVE_BYTES) return BN254_E_BAD_ARG;
     BN_HOST_PROLOGUE();
     if (prep->device != ctx->device) return BN254_E_BAD_ARG;
-    HIP_TRY(hipMemcpyAsync(host_table, prep->table, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    // the device table ends with the identity column pair (bn254_kernels_b.hip): every row of 2 nq + 2 columns gives up its first 2 nq
+    const size_t row = 2 * prep->nq * 16, rows = bytes / row;
+    HIP_TRY(hipMemcpy2DAsync(host_table, row, prep->table, row + 32, row, rows, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;
 }
@@ -761,6 +797,18 @@ int bn254_pairing_prepared_native_batch(bn254_ctx *ctx, const bn_g1 *p, const bn
     HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
     rc = bn254_pairing_prepared_native_batch_dev(ctx, dp.p, prep, 0, dout.p, n, ctx->stream); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, dout.p, n * sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return BN254_OK;
+}
+int bn254_pairing_product_prepared_native(bn254_ctx *ctx, const bn_g1 *p, const bn254_g2_prepared *prep, size_t n, bn_gt *out) {
+    if (!out || !prep || (n && !p) || n > 0x7fffffffu / 96) return BN254_E_BAD_ARG;
+    BN_HOST_PROLOGUE();
+    BnBuf &dp = ctx->stage[0], &dpart = ctx->stage[2];
+    if ((rc = dp.reserve(n * sizeof(bn_g1))) || (rc = dpart.reserve(sizeof(bn_gt)))) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(bn_g1), hipMemcpyHostToDevice, ctx->stream));
+    rc = bn254_miller_product_prepared_native_dev(ctx, dp.p, prep, 0, n, dpart.p, ctx->stream); if (rc) return rc;
+    rc = bn254_final_exp_batch_dev(ctx, dpart.p, dpart.p, 1, ctx->stream); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dpart.p, sizeof(bn_gt), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return BN254_OK;
 }

@@ -416,6 +416,90 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_W
     if (live) f12_store(f, f_out + 96u * pair);
 }
 
+// Every native table ends with the IDENTITY column pair (column 2 nq, 2 nq + 1): A = 1, B = xi B = 0 in all 88 lines, so that a lane pair reading
+// it with sigma = 1, tau = 0 multiplies its accumulator by exactly one - how the shared-accumulator loop below treats a point at infinity.
+__global__ void __launch_bounds__(BLOCK) bn254_native_identity_B(uint4 *table, uint32_t stride) {
+    for (uint32_t r = threadIdx.x; r < (uint32_t)(NATIVE_LINES * NATIVE_GROUPS); r += BLOCK) {
+        const uint32_t g = r % NATIVE_GROUPS;
+        uint4 even = make_uint4(0, 0, 0, 0);                                       // A own = ONE on the even lane (9 limbs: groups 0, 1, 2), zero elsewhere
+        if (g == 0) even = make_uint4(k::ONE[0], k::ONE[1], k::ONE[2], k::ONE[3]);
+        if (g == 1) even = make_uint4(k::ONE[4], k::ONE[5], k::ONE[6], k::ONE[7]);
+        if (g == 2) even = make_uint4(k::ONE[8], 0, 0, 0);
+        table[(size_t)r * stride + stride - 2] = even;
+        table[(size_t)r * stride + stride - 1] = make_uint4(0, 0, 0, 0);
+    }
+}
+// ---- the multi-pairing over native tables (pairing.hpp miller_loop_native_shared): M pairs per lane pair on ONE accumulator, pair i of lane pair
+// t is pairing M t + i of the launch and reads the table of point q_lo + M t + i (shared: of point 0).  Per pair in LDS: sigma, tau = 18 dwords
+// per lane ([pair][dword][lane]; 18 KB per workgroup at M = 4, eight workgroups per CU = 147 of the 160 KB).  There is no per-step point state.
+template <int M>
+struct NativeSharedMem {
+    const uint4 *base;
+    uint32_t col0, ident, stride, infmask;   // column of pair 0, the identity column (both incl. the lane's parity; shared: col0 for every pair)
+    uint32_t *lds;
+    int line, cur, col_step;
+    mutable Fe xbu, xbv;
+    __device__ __forceinline__ uint32_t col() const { return ((infmask >> cur) & 1u) ? ident : col0 + (uint32_t)(cur * col_step); }
+    __device__ __forceinline__ Fe ld_lds(int slot) const {
+        Fe v;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v.l[i] = lds[((cur * 2 + slot) * 9 + i) * BLOCK];
+        return v;
+    }
+    __device__ __forceinline__ void st_lds(int pair, int slot, const Fe &v) const {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) lds[((pair * 2 + slot) * 9 + i) * BLOCK] = v.l[i];
+    }
+    __device__ __forceinline__ void set_line(int l, int i) { line = l; cur = i; }
+    __device__ __forceinline__ Fq2BPrep<Fe> x0() const {
+        const NativeTableMem t = {const_cast<uint4 *>(base), col(), stride};
+        Fe v[3];
+        t.ld_n<3, 0>(line, v);
+        xbu = v[1]; xbv = v[2];
+        return f2b_prepare(F2{fe_mul(v[0], ld_lds(0))});
+    }
+    __device__ __forceinline__ Fq2BPrep<Fe> xb() const { return {xbu, xbv}; }
+    __device__ __forceinline__ Fq2BPrep<Fe> b() const {
+        const NativeTableMem t = {const_cast<uint4 *>(base), col(), stride};
+        Fe v[2];
+        t.ld_n<2, 7>(line, v);
+        return {v[0], v[1]};
+    }
+    __device__ __forceinline__ Fe tau() const { return ld_lds(1); }
+    __device__ __forceinline__ Fe tau9() const { return p_native_tau9(ld_lds(1)); }
+    __device__ __forceinline__ Fe taum() const { return p_native_taum(ld_lds(1)); }
+};
+template <int M>
+__device__ __forceinline__ void miller_native_shared_body(const uint32_t *g1, const uint4 *table, uint32_t stride, uint32_t q_lo, int shared, const uint32_t *q_inf, uint32_t *f_out, uint32_t n) {
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lp = t >> 1, groups = (n + M - 1) / M;
+    const bool live = lp < groups;
+    const uint32_t first = (live ? lp : groups - 1) * M, parity = threadIdx.x & 1u;
+    __shared__ uint32_t park[M * 18 * BLOCK];
+    NativeSharedMem<M> src = {table, shared ? parity : 2u * (q_lo + first) + parity, stride - 2u + parity, stride, 0u, park + threadIdx.x, 0, 0, shared ? 0 : 2, {}, {}};
+#pragma unroll 1
+    for (int i = 0; i < M; ++i) {
+        uint32_t pair = first + (uint32_t)i;
+        const bool beyond = pair >= n;
+        if (beyond) pair = n - 1;
+        const uint32_t *w1 = g1 + 24u * pair;
+        const bool inf = beyond || words_all_zero(w1 + 16, 8) || q_inf[shared ? 0u : q_lo + pair] != 0u;                 // groups/mod.rs:766
+        if (inf) src.infmask |= 1u << i;
+        const PNative<Fe> pn = p_native(f2_scalar_load((const F2 *)nullptr, w1), f2_scalar_load((const F2 *)nullptr, w1 + 8), f2_scalar_load((const F2 *)nullptr, w1 + 16));
+        Fe one, zero;
+        p_native_identity(one, zero);
+        src.st_lds(i, 0, fe_select(inf, pn.sigma, one)); src.st_lds(i, 1, fe_select(inf, pn.tau, zero));
+    }
+    Fq12<F2> f = miller_loop_native_shared<M, F2>(src);
+    if (live) f12_store(f, f_out + 96u * lp);
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_native_shared2_B(const uint32_t *g1, const uint4 *table, uint32_t stride, uint32_t q_lo, int shared, const uint32_t *q_inf, uint32_t *f_out, uint32_t n) {
+    miller_native_shared_body<2>(g1, table, stride, q_lo, shared, q_inf, f_out, n);
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_miller_native_shared4_B(const uint32_t *g1, const uint4 *table, uint32_t stride, uint32_t q_lo, int shared, const uint32_t *q_inf, uint32_t *f_out, uint32_t n) {
+    miller_native_shared_body<4>(g1, table, stride, q_lo, shared, q_inf, f_out, n);
+}
+
 // out[i] = a[i] * b[i]   (Gt * Gt, lib.rs:175-179 -> fq12.rs:295-307)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BN_WAVES, BN_WAVES))) bn254_gt_mul_B(const uint32_t *a, const uint32_t *b, uint32_t *out, uint32_t n) {
     uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
@@ -553,19 +637,29 @@ int bn254_launch_miller_prepared_B(const void *p, const void *coeffs, int shared
                        (uint32_t)(shared ? 0 : NCOEFF * COEFF_WORDS), (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
-size_t bn254_native_table_bytes_B(size_t nq) { return nq * (size_t)NATIVE_LINES * NATIVE_GROUPS * 2 * sizeof(uint4); }
+// nq points + the identity column pair the table ends with
+size_t bn254_native_table_bytes_B(size_t nq) { return (nq + 1) * (size_t)NATIVE_LINES * NATIVE_GROUPS * 2 * sizeof(uint4); }
 int bn254_native_lines_B(void) { return NATIVE_LINES; }
 // table: bn254_native_table_bytes_B(nq) bytes for nq points, q_inf: nq words
 int bn254_launch_g2_prepare_native_B(const void *q, void *table, void *q_inf, size_t nq, hipStream_t s) {
     unsigned grid = (unsigned)((2 * nq + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_g2_prepare_native_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)q, (uint4 *)table, (uint32_t)(2 * nq), (uint32_t *)q_inf, (uint32_t)nq);
+    hipLaunchKernelGGL(bn254_g2_prepare_native_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)q, (uint4 *)table, (uint32_t)(2 * nq + 2), (uint32_t *)q_inf, (uint32_t)nq);
+    hipLaunchKernelGGL(bn254_native_identity_B, dim3(1), dim3(BLOCK), 0, s, (uint4 *)table, (uint32_t)(2 * nq + 2));
     return (int)hipGetLastError();
 }
 // nq: points in the table (its stride); shared: every p[i] against point 0, else p[i] against point q_lo + i
 int bn254_launch_miller_native_B(const void *p, const void *table, const void *q_inf, size_t nq, size_t q_lo, int shared, void *f, size_t n, hipStream_t s) {
     unsigned grid = (unsigned)((2 * n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(bn254_miller_native_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint4 *)table, (uint32_t)(2 * nq), (uint32_t)q_lo, shared ? 1 : 0,
+    hipLaunchKernelGGL(bn254_miller_native_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint4 *)table, (uint32_t)(2 * nq + 2), (uint32_t)q_lo, shared ? 1 : 0,
                        (const uint32_t *)q_inf, (uint32_t *)f, (uint32_t)n);
+    return (int)hipGetLastError();
+}
+// m pairs per lane pair on one accumulator (m = 2 or 4): ceil(n / m) Miller values out, value t = prod_{i < m} miller(p[m t + i], point q_lo + m t + i)
+int bn254_launch_miller_native_shared_B(const void *p, const void *table, const void *q_inf, size_t nq, size_t q_lo, int shared, void *f, size_t n, int m, hipStream_t s) {
+    const size_t groups = (n + m - 1) / m;
+    unsigned grid = (unsigned)((2 * groups + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(m == 4 ? bn254_miller_native_shared4_B : bn254_miller_native_shared2_B, dim3(grid), dim3(BLOCK), 0, s, (const uint32_t *)p, (const uint4 *)table,
+                       (uint32_t)(2 * nq + 2), (uint32_t)q_lo, shared ? 1 : 0, (const uint32_t *)q_inf, (uint32_t *)f, (uint32_t)n);
     return (int)hipGetLastError();
 }
 int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s) {

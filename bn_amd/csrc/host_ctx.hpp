@@ -180,6 +180,7 @@ size_t bn254_native_table_bytes_B(size_t nq);
 int bn254_native_lines_B(void);
 int bn254_launch_g2_prepare_native_B(const void *q, void *table, void *q_inf, size_t nq, hipStream_t s);
 int bn254_launch_miller_native_B(const void *p, const void *table, const void *q_inf, size_t nq, size_t q_lo, int shared, void *f, size_t n, hipStream_t s);
+int bn254_launch_miller_native_shared_B(const void *p, const void *table, const void *q_inf, size_t nq, size_t q_lo, int shared, void *f, size_t n, int m, hipStream_t s);
 int bn254_launch_gt_mul_B(const void *a, const void *b, void *out, size_t n, hipStream_t s);
 size_t bn254_gt_pow_table_bytes_B(size_t n);
 int bn254_launch_gt_pow_B(const void *a, const void *k, void *out, size_t n, void *table, int mode, hipStream_t s);

@@ -322,14 +322,16 @@ BN_FN void precompute_native(const G2Aff<F2> &q_in, Store &st) {
 }
 // what a pairing needs of P in native mode, from its Jacobian coordinates (x = X / Z^2, y = Y / Z^3): ONE inversion
 template <class T> struct PNative { T sigma, tau, tau9, taum; };
+template <class T> BN_FN T p_native_tau9(const T &tau) { return fe_lc3<9, 0, 0>(tau, tau, tau); }
+template <class T> BN_FN T p_native_taum(const T &tau) { return lane_pick(fe_lc3<-1, 0, 0>(tau, tau, tau), tau); }
 template <class T>
 BN_FN PNative<T> p_native(const T &x, const T &y, const T &z) {
     const T inv = fe_inverse(fe_mul(x, z));                          // 1 / (X Z)
     PNative<T> p;
     p.sigma = fe_mul(fe_mul(fe_sqr(z), z), inv);                     // Z^2 / X = 1 / x_P
     p.tau = fe_mul(y, inv);                                          // Y / (Z X) = y_P / x_P
-    p.tau9 = fe_lc3<9, 0, 0>(p.tau, p.tau, p.tau);                   // xi z tau = own (9 tau) + partner (-+ tau)
-    p.taum = lane_pick(fe_lc3<-1, 0, 0>(p.tau, p.tau, p.tau), p.tau);
+    p.tau9 = p_native_tau9(p.tau);                                   // xi z tau = own (9 tau) + partner (-+ tau)
+    p.taum = p_native_taum(p.tau);
     return p;
 }
 // `src.set_line(i)` selects line i; the rest of its interface is f12_mul_by_line_native's
@@ -349,6 +351,42 @@ BN_FN Fq12<F2> miller_loop_native(Src &src) {
             BN_COMPILER_FENCE();                                                        // the line is fetched AFTER the squaring
             src.set_line(idx++);
             f = f12_mul_by_line_native(f, src);
+        }
+    }
+    return f;
+}
+
+// The multi-pairing over prepared points: prod_i e(p_i, Q_i) needs ONE final exponentiation, so M pairs on a lane pair share the accumulator
+// f (one f^2 per step instead of M: the idea of miller_loop_shared) - and over native tables a pair has NO per-step point state at all: what it
+// keeps is sigma and tau (LDS; 9 tau and -+tau are re-derived per line, two fused reductions against a line's ~3.8 k instructions, because 36
+// dwords x 4 pairs per lane do not fit the LDS of two waves per SIMD) and the number of its table column.  A pair with a point at infinity
+// contributes the factor 1 (groups/mod.rs:766) WITHOUT a select in the loop: it reads the IDENTITY column every native table ends with
+// (A = 1, B = xi B = 0: bn254_kernels_b.hip) with sigma = 1, tau = 0, and its "line" A sigma + tau v w + B v^2 is exactly one.
+//   src.set_line(line, i): select line `line` of pair i;  the rest of src's interface is f12_mul_by_line_native's
+template <class T> BN_FN void p_native_identity(T &sigma, T &tau) {
+    sigma = lane_bcast((const T *)nullptr, fe_one());
+    tau = lane_bcast((const T *)nullptr, fe_zero());
+}
+template <int M, class F2, class Src>
+BN_FN Fq12<F2> miller_loop_native_shared(Src &src) {
+    Fq12<F2> f = f12_one<F2>();
+    constexpr int ND = k::ATE_NAF_LEN - 1;
+    int idx = 0;
+#pragma unroll 1
+    for (int j = 0; j < ND + 2; ++j) {
+        const bool tail = j >= ND;
+        const int digit = tail ? 1 : k::ATE_NAF[ND - 1 - j];
+#pragma unroll 1
+        for (int pass = tail ? 1 : 0; pass < (digit != 0 ? 2 : 1); ++pass) {
+            BN_MILLER_HOOK(2 * j + pass, 2 * (ND + 2));
+            if (pass == 0 && j != 0) f = f12_sqr(f);                                    // ONE squaring for all M pairs
+#pragma unroll 1
+            for (int i = 0; i < M; ++i) {
+                BN_COMPILER_FENCE();
+                src.set_line(idx, i);
+                f = f12_mul_by_line_native(f, src);
+            }
+            ++idx;
         }
     }
     return f;

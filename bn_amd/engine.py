@@ -179,6 +179,16 @@ class Engine:
         _native.check(self._lib.bn254_pairing_prepared_native_batch(self._h, _p(p), prepared._h, _p(out), p.shape[0]))
         return out
 
+    def pairing_product_prepared_native(self, p, prepared):
+        """fold(Gt::one(), acc * pairing(p[i], Q[i])) over prepared points (one-point handle: against that point) -> (48,) uint64"""
+        p = _arr(p, G1_WORDS) if len(p) else np.zeros((0, G1_WORDS), np.uint64)
+        out = np.empty(GT_WORDS, np.uint64)
+        _native.check(self._lib.bn254_pairing_product_prepared_native(self._h, _p(p), prepared._h, p.shape[0], _p(out)))
+        return out
+
+    def miller_product_prepared_native_dev(self, d_p, prepared, n, d_partial, q_first=0, stream=0):
+        _native.check(self._lib.bn254_miller_product_prepared_native_dev(self._h, d_p, prepared._h, q_first, n, d_partial, stream))
+
     def miller_prepared_native_dev(self, d_p, prepared, d_f, n, q_first=0, stream=0):
         _native.check(self._lib.bn254_miller_prepared_native_dev(self._h, d_p, prepared._h, q_first, d_f, n, stream))
 

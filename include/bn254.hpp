@@ -112,6 +112,12 @@ public:
         return out;
     }
     Gt pairing(const G1 &p) const { Gt r; check(bn254_pairing_prepared_native_batch(nullptr, &p.v, h_, &r.v, 1)); return r; }
+    // == fold(Gt::one(), acc * bn::pairing(p[i], q[i]))   (shootout/main.rs:11-16): ONE final exponentiation, shared Miller accumulators
+    Gt pairing_product(const std::vector<G1> &p) const {
+        Gt r;
+        check(bn254_pairing_product_prepared_native(nullptr, reinterpret_cast<const bn_g1 *>(p.data()), h_, p.size(), &r.v));
+        return r;
+    }
 };
 
 // tunables of the default context (BN254_OPT_* of bn254_hip.h; value < 0 restores the default derived from the device)

@@ -172,7 +172,7 @@ int bn254_pairing_prepared_batch(bn254_ctx *ctx, const bn_g1 *p, const bn_ell_co
    number of threads / streams may use it concurrently; destroy it after the last call that uses it has completed. */
 typedef struct bn254_g2_prepared bn254_g2_prepared;
 #define BN254_PREPARED_NATIVE_LINES 88
-#define BN254_PREPARED_NATIVE_BYTES 33792    /* device bytes per prepared point: 88 lines x 2 lanes x 12 x 16 B */
+#define BN254_PREPARED_NATIVE_BYTES 33792    /* device bytes per prepared point: 88 lines x 2 lanes x 12 x 16 B (a handle holds one more record: the identity) */
 int bn254_g2_prepare(bn254_ctx *ctx, const bn_g2 *q, size_t nq, bn254_g2_prepared **out);
 void bn254_g2_prepared_destroy(bn254_g2_prepared *prep);
 size_t bn254_g2_prepared_count(const bn254_g2_prepared *prep);           /* points in the handle */
@@ -180,6 +180,12 @@ size_t bn254_g2_prepared_bytes(const bn254_g2_prepared *prep);           /* devi
 /* copies the table to the host ([line][16-byte group][2 x point + lane] x 4 u32; for tests and inspection): bytes = BN254_PREPARED_NATIVE_BYTES x count */
 int bn254_g2_prepared_export(bn254_ctx *ctx, const bn254_g2_prepared *prep, void *host_table, size_t bytes);
 int bn254_pairing_prepared_native_batch(bn254_ctx *ctx, const bn_g1 *p, const bn254_g2_prepared *prep, bn_gt *out, size_t n);
+/* the multi-pairing over prepared points: out[0] = fold(Gt::one(), acc * pairing(p[i], point i)) over n pairs (shootout/main.rs:11-16 with the
+   G2 side prepared; n <= count, or any n against a handle of ONE point) - what a verifier with fixed G2 points evaluates.  ONE final
+   exponentiation for the whole product, and from two machine rounds of pairs on (2 x 256 x CUs) two resp. four pairs share one Miller
+   accumulator per lane pair: over native tables a pair has no per-step point state, so the shared loop is the line products plus a quarter of
+   the squarings.  n == 0 gives Gt::one(); a point at infinity on either side contributes one (groups/mod.rs:766). */
+int bn254_pairing_product_prepared_native(bn254_ctx *ctx, const bn_g1 *p, const bn254_g2_prepared *prep, size_t n, bn_gt *out);
 int bn254_gt_mul_batch(bn254_ctx *ctx, const bn_gt *a, const bn_gt *b, bn_gt *out, size_t n);
 /* Gt::pow (lib.rs:171).  a[i] are Gt VALUES - what the reference's type holds: Gt::one, pairing() and products, powers, inverses of
    such (the Fq12 inside Gt is private and Gt has no decoder), all of order r.  On those the device exponentiates through the
@@ -282,6 +288,9 @@ int bn254_miller_prepared_dev(bn254_ctx *ctx, const void *d_p, const void *d_coe
 int bn254_g2_prepare_dev(bn254_ctx *ctx, const void *d_q, size_t nq, bn254_g2_prepared **out, void *stream);
 int bn254_miller_prepared_native_dev(bn254_ctx *ctx, const void *d_p, const bn254_g2_prepared *prep, size_t q_first, void *d_f, size_t n, void *stream);
 int bn254_pairing_prepared_native_batch_dev(bn254_ctx *ctx, const void *d_p, const bn254_g2_prepared *prep, size_t q_first, void *d_out, size_t n, void *stream);
+/* local part of a multi-pairing over prepared points: un-exponentiated product of the Miller values of p[i] against point q_first + i -> one
+   Fq12 (the counterpart of bn254_miller_product_dev; bn254_gt_product_final_exp_dev or bn254_final_exp_batch_dev finishes it) */
+int bn254_miller_product_prepared_native_dev(bn254_ctx *ctx, const void *d_p, const bn254_g2_prepared *prep, size_t q_first, size_t n, void *d_partial, void *stream);
 int bn254_gt_mul_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
 int bn254_gt_pow_batch_dev(bn254_ctx *ctx, const void *d_a, const void *d_k, void *d_out, size_t n, void *stream);
 int bn254_gt_inverse_batch_dev(bn254_ctx *ctx, const void *d_a, void *d_out, size_t n, void *stream);
@@ -303,7 +312,7 @@ int bn254_tile_dev(bn254_ctx *ctx, const void *d_record, size_t record_bytes, si
    accumulated duration and launch count per kernel since the last reset (this is what bench.py's roofline uses). */
 int bn254_profile_enable(bn254_ctx *ctx, int on);
 int bn254_profile_reset(bn254_ctx *ctx);
-/* kernel: "miller", "miller_shared", "miller_wave", "miller_quad", "pairing_wave", "final_exp", "final_exp_wave", "final_exp_quad", "exp_by_neg_z", "gt_product", "gt_tail", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "g2_prepare_native", "miller_native", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
+/* kernel: "miller", "miller_shared", "miller_wave", "miller_quad", "pairing_wave", "final_exp", "final_exp_wave", "final_exp_quad", "exp_by_neg_z", "gt_product", "gt_tail", "g1_mul", "g2_mul", "gt_mul", "gt_pow", "g2_precompute", "miller_prepared", "g2_prepare_native", "miller_native", "miller_native_shared", "wire_encode", "wire_decode", "gt_inverse", "g1_add", "g2_add".
    Synchronises and consumes the recorded events (totals accumulate until bn254_profile_reset). */
 int bn254_kernel_stats(bn254_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 /* issue-rate ceiling of v_mad_u64_u32 (the 32x32+64 multiply-accumulate every field product is built from) at

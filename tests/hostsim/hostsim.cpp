@@ -292,6 +292,41 @@ EXPORT void hsb_native_pairing(const uint32_t *g1, const uint32_t *table, int mi
     if (inf) f = f12_one<F2B>();
     f12_store(f, o);
 }
+// the multi-pairing over native tables (pairing.hpp miller_loop_native_shared): m pairs on one simulated lane pair share the accumulator; a pair
+// with a point at infinity (flags[i] != 0, or z_P = 0) reads the identity record with sigma = 1, tau = 0.  tables: m x [88][2][48] words.
+struct NativeSharedSim {
+    const uint32_t *t[8];
+    FeP sigma[8], tau_[8];
+    uint32_t ident[2][48];
+    int line = 0, cur = 0;
+    void set_line(int l, int i) { line = l; cur = i; }
+    FeP ld(int off) const {
+        const uint32_t *base = t[cur];
+        if (!base) return {{NativeTableSim::get(ident[0] + off), NativeTableSim::get(ident[1] + off)}};
+        return {{NativeTableSim::get(base + (line * 2 + 0) * 48 + off), NativeTableSim::get(base + (line * 2 + 1) * 48 + off)}};
+    }
+    Fq2BPrep<FeP> x0() const { return f2b_prepare(F2B{fe_mul(ld(0), sigma[cur])}); }
+    Fq2BPrep<FeP> xb() const { return {ld(9), ld(18)}; }
+    Fq2BPrep<FeP> b() const { return {ld(28), ld(37)}; }
+    FeP tau() const { return tau_[cur]; }
+    FeP tau9() const { return p_native_tau9(tau_[cur]); }             // re-derived per line, like the kernel (LDS holds sigma, tau only)
+    FeP taum() const { return p_native_taum(tau_[cur]); }
+};
+EXPORT void hsb_native_product(int m, const uint32_t *g1, const uint32_t *tables, const uint32_t *q_inf, uint32_t *o) {
+    static NativeSharedSim src;
+    for (int j = 0; j < 48; ++j) src.ident[0][j] = src.ident[1][j] = 0;
+    for (int j = 0; j < 9; ++j) src.ident[0][j] = k::ONE[j];                        // A = 1 + 0 i: even lane ONE, odd lane 0; B = xi B = 0
+    for (int i = 0; i < m; ++i) {
+        const uint32_t *w = g1 + 24 * i;
+        const bool inf = words_all_zero(w + 16, 8) || q_inf[i] != 0;
+        src.t[i] = inf ? nullptr : tables + (size_t)i * NATIVE_LINES * 2 * 48;
+        const PNative<FeP> pn = p_native(f2_scalar_load((F2B *)0, w), f2_scalar_load((F2B *)0, w + 8), f2_scalar_load((F2B *)0, w + 16));
+        src.sigma[i] = pn.sigma; src.tau_[i] = pn.tau;
+        if (inf) p_native_identity(src.sigma[i], src.tau_[i]);
+    }
+    Fq12<F2B> f = m == 1 ? miller_loop_native_shared<1, F2B>(src) : m == 2 ? miller_loop_native_shared<2, F2B>(src) : m == 3 ? miller_loop_native_shared<3, F2B>(src) : miller_loop_native_shared<4, F2B>(src);
+    f12_store(final_exponentiation(f), o);
+}
 // bn254_miller_prepared_B alone (the reference-image coefficients already computed): what that kernel executes per pairing
 EXPORT void hsb_prepared_miller(const uint32_t *g1, const uint32_t *coeffs, uint32_t *o) {
     FeP zi = fe_inverse(f2_scalar_load((F2B *)0, g1 + 16)), zi2 = fe_sqr(zi);

@@ -189,7 +189,7 @@ def test_option_and_exchange_discriminants():
     import ctypes as C
     lib = _native.lib()
     lib.bn254_native_table_bytes_B.restype = C.c_size_t; lib.bn254_native_table_bytes_B.argtypes = [C.c_size_t]
-    assert lib.bn254_native_lines_B() == sizes["PREPARED_NATIVE_LINES"] and lib.bn254_native_table_bytes_B(3) == 3 * sizes["PREPARED_NATIVE_BYTES"]
+    assert lib.bn254_native_lines_B() == sizes["PREPARED_NATIVE_LINES"] and lib.bn254_native_table_bytes_B(3) == (3 + 1) * sizes["PREPARED_NATIVE_BYTES"]
     # the binding's own EllCoeffs mirrors bn_ell_coeffs: three arrays of 8 u64, in the header's order
     m = re.search(r"pub struct EllCoeffs \{([^}]*)\}", txt)
     assert m and re.findall(r"pub (\w+): \[u64; 8\]", m.group(1)) == re.search(r"typedef struct \{ uint64_t ([^;]*); \} bn_ell_coeffs", HEADER.read_text()).group(1).replace("[8]", "").split(", ")

@@ -62,7 +62,7 @@ def test_hot_loops_are_spill_free(kernel):
 # `tools/isa_mix.py --blocks KERNEL` before raising one.  (The one-lane test double lives in tests/testdouble/, not in this library.)
 SPILL_CEILING = {
     "bn254_miller_B": 3, "bn254_miller_naf_B": 0, "bn254_final_exp_B": 7, "bn254_miller_shared2_B": 19, "bn254_miller_shared4_B": 19,
-    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 0, "bn254_g2_prepare_native_B": 0, "bn254_miller_native_B": 0, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 11, "bn254_gt_inverse_B": 4,
+    "bn254_g2_precompute_B": 0, "bn254_miller_prepared_B": 0, "bn254_g2_prepare_native_B": 0, "bn254_miller_native_B": 0, "bn254_miller_native_shared2_B": 0, "bn254_miller_native_shared4_B": 0, "bn254_native_identity_B": 0, "bn254_gt_mul_B": 0, "bn254_gt_pow_B": 11, "bn254_gt_inverse_B": 4,
     "bn254_exp_by_neg_z_B": 4, "bn254_miller_naf_Q": 0, "bn254_final_exp_Q": 0,
     "bn254_g1_mul_M": 7, "bn254_g1_mul_chain_M": 0,      # (round 6: 7, all in the loop's preheader - the digit streams and the GLV halves are set up there -
                                                          #  and the epilogue; the window loop itself: test_scalar_multiplication_loops_do_not_store_to_scratch)

@@ -156,7 +156,7 @@ def test_full_size_shared_and_per_pairing(oracle):
     P, Q = D.synthetic_points(te, 0, n)
     # one table per pairing (2.2 GB of tables)
     prep = e.g2_prepare_dev(Q.data_ptr(), n, te._stream())
-    assert prep.count == n and prep.device_bytes == n * (33792 + 4 + 192)
+    assert prep.count == n and prep.device_bytes == (n + 1) * 33792 + n * (4 + 192)       # the tables, the identity record, flags, the points
     out = te.empty(n, 48)
     e.pairing_prepared_native_dev(P.data_ptr(), prep, out.data_ptr(), n, stream=te._stream())
     ref = D.pairing_batch_sharded(te, P, Q)
@@ -267,3 +267,94 @@ def test_small_calls_are_routed_to_the_wave_kernels(oracle):
     assert e.kernel_stats("miller_native")[1] == 1 and e.kernel_stats("pairing_wave")[1] == 0
     assert np.array_equal(gb[:n], oracle.pairing_batch(P, np.tile(Q[0], (n, 1)))) and np.array_equal(gb[n:2 * n], gb[:n])
     one.close(); allq.close(); e.close()
+
+
+def test_product_over_native_tables_matches_fold(oracle, goldens):
+    """the multi-pairing over prepared points (bn254_pairing_product_prepared_native): fold(Gt::one(), acc * pairing(p[i], q[i])) of
+    shootout/main.rs:11-16 with the G2 side prepared - plain native kernels (M = 1), two and four pairs per accumulator (the shared-accumulator
+    kernels, reached at test sizes through round_pairs / miller_shared), ragged n (not a multiple of M), points at infinity on either side
+    (the identity record), the empty product, the small-call route, q_first through the device entry point; and the committed goldens"""
+    import torch
+    import bn_amd
+    from bn_amd import _native
+    from bn_amd import distributed as D
+    rng = np.random.default_rng(606)
+    n = 203
+    P = _g1(oracle, _scalars(rng, n)); Q = _g2(oracle, _scalars(rng, n))
+    P[0] = oracle.g1_zero(); Q[5] = oracle.g2_zero(); P[6] = oracle.g1_zero(); Q[6] = oracle.g2_zero(); P[n - 1] = oracle.g1_zero(); P[9] = oracle.g1_one()
+    e = bn_amd.Engine(0)
+    prep = e.g2_prepare(Q)
+    want = oracle.pairing_product(P, Q)
+    assert np.array_equal(e.pairing_product_prepared_native(P, prep), want)                        # default: the small-call route (wave kernels)
+    assert np.array_equal(e.pairing_product_prepared_native(P[:0], prep), oracle.fq12_one())        # empty product
+    e.profile(True)
+    for opts, kernel in ((dict(wave_pairing_max=0), "miller_native"), (dict(wave_pairing_max=0, round_pairs=64, miller_shared=2), "miller_native_shared"),
+                         (dict(wave_pairing_max=0, round_pairs=32), "miller_native_shared"), (dict(wave_pairing_max=0, round_pairs=16, miller_shared=4), "miller_native_shared")):
+        with e.options(**opts):
+            for cnt in (n, n - 1, n - 2, n - 3, 5, 1):
+                e.profile_reset()
+                got = e.pairing_product_prepared_native(P[:cnt], prep)
+                assert np.array_equal(got, oracle.pairing_product(P[:cnt], Q[:cnt])), (opts, cnt)
+                if cnt >= 200:
+                    assert e.kernel_stats(kernel)[1] >= 1 and e.kernel_stats("pairing_wave")[1] == 0, (opts, cnt)
+    # more pairs than prepared points: rejected
+    with pytest.raises(_native.Bn254Error):
+        e.pairing_product_prepared_native(np.concatenate([P, P[:1]]), prep)
+    # q_first through the device entry point, four pairs per accumulator
+    dev = torch.device("cuda", 0)
+    te = D.TorchEngine(e, dev)
+    dp = torch.from_numpy(P[50:180].view(np.int64)).to(dev)
+    part = te.empty(1, 48)
+    with e.options(wave_pairing_max=0, round_pairs=16):
+        e.miller_product_prepared_native_dev(dp.data_ptr(), prep, 130, part.data_ptr(), q_first=50, stream=te._stream())
+        e.final_exp_batch_dev(part.data_ptr(), part.data_ptr(), 1, stream=te._stream())
+        torch.cuda.synchronize()
+    assert np.array_equal(part.cpu().numpy().view(np.uint64)[0], oracle.pairing_product(P[50:180], Q[50:180]))
+    # ONE prepared point against many P: prod e(p_i, Q) = e(sum p_i, Q)
+    one = e.g2_prepare(Q[1])
+    with e.options(wave_pairing_max=0, round_pairs=32):
+        got = e.pairing_product_prepared_native(P[:101], one)
+    assert np.array_equal(got, oracle.pairing_product(P[:101], np.tile(Q[1], (101, 1))))
+    one.close(); prep.close()
+    # committed goldens: the product of all 96 golden pairings, through tables of their own g2
+    g1, g2, gt = goldens["g1"], goldens["g2"], goldens["gt"]
+    want_g = gt[0]
+    for v in gt[1:]:
+        want_g = oracle.fq12_mul(want_g, v)
+    pg = e.g2_prepare(g2)
+    with e.options(wave_pairing_max=0, round_pairs=16):
+        assert np.array_equal(e.pairing_product_prepared_native(g1, pg), want_g)
+    pg.close(); e.close()
+
+
+def test_full_size_product_over_native_tables(oracle):
+    """BASELINE configs[3] shape on one GPU with the G2 side prepared: 2^18 pairs, one table each (8.9 GB), four pairs per accumulator - equal to the
+    fused multi-pairing of the same inputs (an independent device path) and, on a 512-pair prefix, to the oracle's fold; 2^17 pairs (two pairs
+    per accumulator) likewise"""
+    import torch
+    import bn_amd
+    from bn_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    n = 1 << 18
+    e = bn_amd.Engine(0)
+    te = D.TorchEngine(e, dev)
+    P, Q = D.synthetic_points(te, 0, n)
+    prep = e.g2_prepare_dev(Q.data_ptr(), n, te._stream())
+    e.profile(True)
+    part = te.empty(1, 48)
+    for cnt, m in ((n, 4), (n // 2, 2)):
+        e.profile_reset()
+        e.miller_product_prepared_native_dev(P.data_ptr(), prep, cnt, part.data_ptr(), stream=te._stream())
+        e.final_exp_batch_dev(part.data_ptr(), part.data_ptr(), 1, stream=te._stream())
+        torch.cuda.synchronize()
+        assert e.kernel_stats("miller_native_shared")[1] == (cnt // m) >> 16
+        ref = D.pairing_product_sharded(te, P[:cnt].contiguous(), Q[:cnt].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(part[0], ref.reshape(-1))
+    with e.options(wave_pairing_max=0, round_pairs=64):
+        e.miller_product_prepared_native_dev(P.data_ptr(), prep, 512, part.data_ptr(), stream=te._stream())
+        e.final_exp_batch_dev(part.data_ptr(), part.data_ptr(), 1, stream=te._stream())
+        torch.cuda.synchronize()
+    Pn = P[:512].cpu().numpy().view(np.uint64); Qn = Q[:512].cpu().numpy().view(np.uint64)
+    assert np.array_equal(part.cpu().numpy().view(np.uint64)[0], oracle.pairing_product(Pn, Qn))
+    prep.close(); e.close()

@@ -243,6 +243,38 @@ def test_native_prepared_mode(oracle, hs, kats):
         assert np.array_equal(out, oracle.pairing(Pi, Q))
 
 
+def test_native_prepared_product(oracle, hs):
+    """the multi-pairing over native tables (pairing.hpp miller_loop_native_shared: M pairs of one lane pair share the accumulator; sigma, tau
+    per pair, 9 tau / -+tau re-derived per line; infinity = the identity record with sigma = 1, tau = 0), every bound enforced: M = 1 ... 4
+    against the oracle's fold of pairing() values (shootout/main.rs:11-16), with P or Q at infinity in any slot"""
+    import ctypes as C
+    U32 = C.POINTER(C.c_uint32)
+    lib = hs.lib
+    rng = np.random.default_rng(41)
+    Ps = [oracle.g1_mul(oracle.g1_one(), _fr(oracle, rng)) for _ in range(4)]
+    Qs = [oracle.g2_mul(oracle.g2_one(), _fr(oracle, rng)) for _ in range(4)]
+    tabs = np.zeros((4, 88, 2, 48), np.uint32)
+    for i, Q in enumerate(Qs):
+        lib.hsb_native_precompute(Q.ctypes.data_as(U32), tabs[i].ctypes.data_as(U32))
+    vals = [oracle.pairing(P, Q) for P, Q in zip(Ps, Qs)]
+    one = oracle.pairing(oracle.g1_zero(), Qs[0])
+
+    def run(m, p_inf=(), q_inf=()):
+        g1 = np.stack([oracle.g1_zero() if i in p_inf else Ps[i] for i in range(m)])
+        flags = np.array([1 if i in q_inf else 0 for i in range(m)], np.uint32)
+        out = np.zeros(48, np.uint64)
+        lib.hsb_native_product(C.c_int(m), np.ascontiguousarray(g1).ctypes.data_as(U32), tabs.ctypes.data_as(U32), flags.ctypes.data_as(U32), out.ctypes.data_as(U32))
+        want = one
+        for i in range(m):
+            if i not in p_inf and i not in q_inf:
+                want = oracle.fq12_mul(want, vals[i])
+        assert np.array_equal(out, want), (m, p_inf, q_inf)
+
+    for m in (1, 2, 3, 4):
+        run(m)
+    run(4, p_inf=(0,)); run(4, q_inf=(3,)); run(4, p_inf=(1,), q_inf=(2,)); run(2, p_inf=(0, 1)); run(3, p_inf=(2,), q_inf=(0, 1))
+
+
 def test_gt_pow_windowed_chain(oracle, hs):
     """Gt::pow as bn254_gt_pow_B computes it (4-bit windows, general squarings), every limb/value bound enforced: pairing values, an
     element outside the cyclotomic subgroup (a raw Miller value) and edge exponents against the oracle's bit-serial pow"""
