@@ -428,10 +428,11 @@ def run_product(eng, dev, dist, P, Q, steps, warmup):
     return elapsed, {k: v[0] / ks for k, v in st.items()}, tr
 
 
-def run_product_prepared(eng, dev, dist, P, Q, steps, warmup):
-    """the multi-pairing product of the pairs (P[i], Q[i]) with every Q[i] prepared natively beforehand (not timed: a verifier's G2 points are fixed)"""
+def run_product_prepared(eng, dev, dist, P, Q, steps, warmup, one_q=False, power=False):
+    """the multi-pairing product of the pairs (P[i], Q[i]) with every Q[i] prepared natively beforehand (not timed: a verifier's G2 points are fixed);
+    one_q: every P against ONE prepared point (the table then comes out of the caches: what streaming the tables costs)"""
     n = P.shape[0]
-    prep = eng.e.g2_prepare_dev(Q.data_ptr(), n, eng._stream())
+    prep = eng.e.g2_prepare_dev(Q.data_ptr(), 1 if one_q else n, eng._stream())
     part = eng.empty(1, 48)
 
     def step():
@@ -440,8 +441,12 @@ def run_product_prepared(eng, dev, dist, P, Q, steps, warmup):
     elapsed = timed_steps(dist, dev, step, steps, warmup)
     ks = min(steps, 3)
     st = kernel_times(eng, dev, step, ("miller_native", "miller_native_shared") + PRODUCT_KERNELS, ks)
+    kms = {k: v[0] / ks for k, v in st.items()}
+    if power:
+        pw = PowerSampler(eng.torch, dev).run(eng.torch, dev, step, n, min_seconds=1.2, est_ms_per_step=elapsed / steps * 1e3)
+        kms["power"] = {k: pw.get(k) for k in ("power_W", "sclk_MHz", "power_cap_W", "energy_uJ_per_unit", "units_per_s_during_leg")}
     prep.close()
-    return elapsed, {k: v[0] / ks for k, v in st.items()}
+    return elapsed, kms
 
 
 def bench_product_prepared(args, eng, dev, world, rank):
@@ -450,10 +455,10 @@ def bench_product_prepared(args, eng, dev, world, rank):
     from bn_amd import distributed as D
     n = args.batch or PRODUCT_TOTAL
     P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
-    elapsed, kms = run_product_prepared(eng, dev, dist, P, Q, args.steps, args.warmup)
+    elapsed, kms = run_product_prepared(eng, dev, dist, P, Q, args.steps, args.warmup, one_q=args.prepared_mode == "native", power=True)
     if rank == 0:
         print(json.dumps(_line("BN254 pairs/sec folded into one multi-pairing product over prepared G2 points (bit-exact vs ref)", "pairs/s", world * n * args.steps / elapsed,
-                               world, args, elapsed, "weak", f"product of {n} pairs -> 1 Gt per GPU, one native table (33.8 KB) per pair", {"kernel_ms_per_step": kms})), flush=True)
+                               world, args, elapsed, "weak", f"product of {n} pairs -> 1 Gt per GPU, " + ("ONE native table for all pairs" if args.prepared_mode == "native" else "one native table (33.8 KB) per pair"), {"kernel_ms_per_step": kms})), flush=True)
 
 
 def bench_product(args, eng, dev, world, rank):
@@ -519,7 +524,7 @@ def bench_prepared(args, eng, dev, world, rank):
     from bn_amd import distributed as D
     n = args.batch or BATCH
     P, Q = D.synthetic_points(eng, rank * n, (rank + 1) * n)
-    mode = args.prepared_mode
+    mode = args.prepared_mode or "native"
     elapsed, rf, kms = run_prepared(eng, dev, dist, P, Q, n, mode, args.steps, args.warmup)
     if rank == 0:
         what = {"native": "against ONE prepared Q: one device-native table (88 lines x 384 B, bn254_g2_prepare) read by all lanes",
@@ -688,7 +693,7 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the `side` object (configs[3], configs[4], single-pairing latency) of the default line")
     ap.add_argument("--workload", choices=["pairing", "g1mul", "g2mul", "gtpow", "prepared", "product", "product_prepared"], default="pairing",
                     help="pairing: the headline metric (default); the others are side metrics with their own line")
-    ap.add_argument("--prepared-mode", choices=["native", "native_per_q", "reference"], default="native",
+    ap.add_argument("--prepared-mode", choices=["native", "native_per_q", "reference"], default=None,
                     help="--workload prepared: the device-native table of bn254_g2_prepare (default) or the reference-image coefficients")
     ap.add_argument("--mode", choices=["dist", "multi_c"], default="dist",
                     help="dist (default, what the driver runs): one process per GPU over torch.distributed/RCCL, inputs resident in HBM; "
