@@ -54,6 +54,7 @@ extern "C" {
     fn bn254_multi_prepared_destroy(prep: *mut c_void);
     fn bn254_multi_prepared_count(prep: *const c_void) -> usize;
     fn bn254_pairing_prepared_native_batch_multi(m: *mut c_void, p: *const G1, prep: *const c_void, out: *mut Gt, n: usize) -> c_int;
+    fn bn254_pairing_product_prepared_native_multi(m: *mut c_void, p: *const G1, prep: *const c_void, n: usize, out: *mut Gt) -> c_int;
     fn bn254_pairing_batch_multi(m: *mut c_void, p: *const G1, q: *const G2, out: *mut Gt, n: usize) -> c_int;
     fn bn254_pairing_product_multi(m: *mut c_void, p: *const G1, q: *const G2, n: usize, out: *mut Gt) -> c_int;
 }
@@ -393,6 +394,12 @@ impl<'a> MultiPreparedG2<'a> {
     pub fn pairing_batch(&self, p: &[G1]) -> Result<Vec<Gt>, GpuError> {
         let mut out = vec![Gt::one(); p.len()];
         check(unsafe { bn254_pairing_prepared_native_batch_multi(self.gpus.0, p.as_ptr(), self.h, out.as_mut_ptr(), p.len()) })?;
+        Ok(out)
+    }
+    /// the fold of shootout/main.rs:11-16 over the prepared points, sharded: one 384-byte exchange, ONE final exponentiation
+    pub fn pairing_product(&self, p: &[G1]) -> Result<Gt, GpuError> {
+        let mut out = Gt::one();
+        check(unsafe { bn254_pairing_product_prepared_native_multi(self.gpus.0, p.as_ptr(), self.h, p.len(), &mut out) })?;
         Ok(out)
     }
 }

@@ -76,6 +76,7 @@ SIGNATURES = {   # name -> argtypes  (every function returns int unless noted)
     "bn254_multi_prepared_destroy": [_VP],
     "bn254_multi_prepared_count": [_VP],
     "bn254_pairing_prepared_native_batch_multi": [_VP, _VP, _VP, _VP, _SZ],
+    "bn254_pairing_product_prepared_native_multi": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_pairing_batch_multi": [_VP, _VP, _VP, _VP, _SZ],
     "bn254_pairing_product_multi": [_VP, _VP, _VP, _SZ, _VP],
     "bn254_synthetic_scalars_dev": [_VP, C.c_uint64, C.c_uint64, _SZ, C.c_int, _VP, _VP],

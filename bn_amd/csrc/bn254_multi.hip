@@ -411,8 +411,11 @@ int bn254_pairing_prepared_native_batch_multi(bn254_multi *m, const bn_g1 *p, co
     return bn_no_throw([&] { return pairing_prepared_native_batch_multi(m, p, prep, out, n); });
 }
 
-static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
-    if (!m || !out || (n && (!p || !q))) return BN254_E_BAD_ARG;
+// q != NULL: the fused multi-pairing of (p[i], q[i]);  prep != NULL: the same over natively prepared points (one point on every rank, or the set
+// sharded by the rule of the pairs - then n == count)
+static int product_multi_impl(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, const bn254_multi_prepared *prep, size_t n, bn_gt *out) {
+    if (!m || !out || (n && (!p || (!q && !prep)))) return BN254_E_BAD_ARG;
+    if (prep && (prep->owner != m || (prep->nq != 1 && n != prep->nq))) return BN254_E_BAD_ARG;
     std::lock_guard<std::mutex> lk(m->mu);
     const size_t G = m->ctx.size();
     std::vector<int> rcs(G, BN254_OK);
@@ -424,12 +427,14 @@ static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q,
         HIP_TRY(hipSetDevice(c->device));
         BnBuf &dp = c->stage[0], &dq = c->stage[1];
         int rc;
-        if ((rc = dp.reserve(cnt * sizeof(bn_g1))) || (rc = dq.reserve(cnt * sizeof(bn_g2)))) return rc;
+        if ((rc = dp.reserve(cnt * sizeof(bn_g1))) || (!prep && (rc = dq.reserve(cnt * sizeof(bn_g2))))) return rc;
         if (cnt) {
             HIP_TRY(hipMemcpyAsync(dp.p, p + lo, cnt * sizeof(bn_g1), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(dq.p, q + lo, cnt * sizeof(bn_g2), hipMemcpyHostToDevice, c->stream));
+            if (!prep) HIP_TRY(hipMemcpyAsync(dq.p, q + lo, cnt * sizeof(bn_g2), hipMemcpyHostToDevice, c->stream));
         }
-        if ((rc = bn254_miller_product_dev(c, dp.p, dq.p, cnt, m->d_partial[g].p, c->stream))) return rc;
+        if (prep) rc = bn254_miller_product_prepared_native_dev(c, dp.p, prep->h[g], 0, cnt, m->d_partial[g].p, c->stream);
+        else rc = bn254_miller_product_dev(c, dp.p, dq.p, cnt, m->d_partial[g].p, c->stream);
+        if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream));
         return BN254_OK;
     };
@@ -474,6 +479,15 @@ static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q,
     HIP_TRY(hipMemcpyAsync(out, m->d_partial[0].p, sizeof(bn_gt), hipMemcpyDeviceToHost, c0->stream));
     HIP_TRY(hipStreamSynchronize(c0->stream));
     return BN254_OK;
+}
+static int pairing_product_multi(bn254_multi *m, const bn_g1 *p, const bn_g2 *q, size_t n, bn_gt *out) {
+    if (n && !q) return BN254_E_BAD_ARG;
+    return product_multi_impl(m, p, q, nullptr, n, out);
+}
+int bn254_pairing_product_prepared_native_multi(bn254_multi *m, const bn_g1 *p, const bn254_multi_prepared *prep, size_t n, bn_gt *out) {
+    if (!prep) return BN254_E_BAD_ARG;
+    BnDeviceGuard dev_guard;
+    return bn_no_throw([&] { return product_multi_impl(m, p, nullptr, prep, n, out); });
 }
 
 }  // extern "C"

@@ -47,6 +47,15 @@ class TorchEngine:
         self.e.miller_product_dev(p.data_ptr(), q.data_ptr(), p.shape[0], out.data_ptr(), self._stream())
         return out
 
+    def g2_prepare(self, q):
+        """native tables of this rank's G2 points (bn254_g2_prepare_dev): a PreparedG2 handle on this rank's GPU"""
+        return self.e.g2_prepare_dev(q.data_ptr(), q.shape[0], self._stream())
+
+    def miller_product_prepared(self, p, prepared):
+        out = self.empty(GT_WORDS)
+        self.e.miller_product_prepared_native_dev(p.data_ptr(), prepared, p.shape[0], out.data_ptr(), stream=self._stream())
+        return out
+
     def gt_product(self, vals):
         out = self.empty(GT_WORDS)
         vals = vals.contiguous()
@@ -104,6 +113,16 @@ def pairing_product_sharded(eng, p_local, q_local, group=None):
     parts = all_gather_partials(partial, group)             # RCCL all-gather of 384 B per rank
     if hasattr(eng, "product_final_exp"):
         return eng.product_final_exp(parts)                 # world-1 multiplications + ONE final exponentiation, one launch
+    return eng.final_exp(eng.gt_product(parts))
+
+
+def pairing_product_prepared_sharded(eng, p_local, prepared_local, group=None):
+    """the same over natively prepared points: `prepared_local` = eng.g2_prepare(this rank's shard of the G2 points), made once and re-used;
+    the exchange and the tail are those of pairing_product_sharded"""
+    partial = eng.miller_product_prepared(p_local, prepared_local)
+    parts = all_gather_partials(partial, group)
+    if hasattr(eng, "product_final_exp"):
+        return eng.product_final_exp(parts)
     return eng.final_exp(eng.gt_product(parts))
 
 

@@ -460,6 +460,13 @@ class MultiEngine:
         _native.check(self._lib.bn254_pairing_prepared_native_batch_multi(self._h, _p(p), prepared._h, _p(out), p.shape[0]))
         return out
 
+    def pairing_product_prepared_native(self, p, prepared):
+        """the multi-pairing over the prepared points, sharded: one 384-byte exchange, ONE final exponentiation"""
+        p = _arr(p, G1_WORDS) if len(p) else np.zeros((0, G1_WORDS), np.uint64)
+        out = np.empty(GT_WORDS, np.uint64)
+        _native.check(self._lib.bn254_pairing_product_prepared_native_multi(self._h, _p(p), prepared._h, p.shape[0], _p(out)))
+        return out
+
 
 class MultiPreparedG2:
     """handle of bn254_g2_prepare_multi: per-rank native tables"""

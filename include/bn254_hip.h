@@ -236,6 +236,9 @@ int bn254_g2_prepare_multi(bn254_multi *m, const bn_g2 *q, size_t nq, bn254_mult
 void bn254_multi_prepared_destroy(bn254_multi_prepared *prep);
 size_t bn254_multi_prepared_count(const bn254_multi_prepared *prep);
 int bn254_pairing_prepared_native_batch_multi(bn254_multi *m, const bn_g1 *p, const bn254_multi_prepared *prep, bn_gt *out, size_t n);
+/* bn254_pairing_product_multi over prepared points (bn254_pairing_product_prepared_native sharded): every rank folds its shard over its own tables,
+   then the ONE 384-byte exchange and the single final exponentiation on rank 0.  n == count for a sharded set, any n against one point. */
+int bn254_pairing_product_prepared_native_multi(bn254_multi *m, const bn_g1 *p, const bn254_multi_prepared *prep, size_t n, bn_gt *out);
 
 /* wire format of the crate's Encodable/Decodable impls for G1/G2 (groups/mod.rs:143-205, fields/fp.rs:24-36, fields/fq2.rs:31-53,
    arith.rs:100-159), as fixed-size batch records: [tag][x][y] with tag 4 and big-endian canonical coordinates (Fq2 = the 512-bit

@@ -204,6 +204,13 @@ def test_multi_device_entry_points_of_the_native_mode(oracle):
         assert np.array_equal(m.pairing_prepared_native_batch(P, allq), want)
         with pytest.raises(_native.Bn254Error):
             m.pairing_prepared_native_batch(P[:50], allq)                  # a sharded set pairs with exactly as many points
+        # the multi-pairing over the prepared points: shards fold locally (shared-accumulator kernels at this size via round_pairs), one exchange
+        m.set_option("round_pairs", 8)
+        assert np.array_equal(m.pairing_product_prepared_native(P, allq), oracle.pairing_product(P, Q))
+        assert np.array_equal(m.pairing_product_prepared_native(P[:77], one), oracle.pairing_product(P[:77], np.tile(Q[1], (77, 1))))
+        assert np.array_equal(m.pairing_product_prepared_native(P[:0], one), oracle.fq12_one())
+        with pytest.raises(_native.Bn254Error):
+            m.pairing_product_prepared_native(P[:50], allq)
         one.close(); allq.close(); m.close()
 
 
@@ -355,6 +362,10 @@ def test_full_size_product_over_native_tables(oracle):
         e.miller_product_prepared_native_dev(P.data_ptr(), prep, 512, part.data_ptr(), stream=te._stream())
         e.final_exp_batch_dev(part.data_ptr(), part.data_ptr(), 1, stream=te._stream())
         torch.cuda.synchronize()
+    # the one-process-per-GPU path (bn_amd/distributed.py) at world 1: same bytes
+    got = D.pairing_product_prepared_sharded(te, P, prep)
+    torch.cuda.synchronize()
+    assert torch.equal(got.reshape(-1), D.pairing_product_sharded(te, P, Q).reshape(-1))
     Pn = P[:512].cpu().numpy().view(np.uint64); Qn = Q[:512].cpu().numpy().view(np.uint64)
     assert np.array_equal(part.cpu().numpy().view(np.uint64)[0], oracle.pairing_product(Pn, Qn))
     prep.close(); e.close()

@@ -150,6 +150,8 @@ class OracleEngine:                       # test double: same five methods as To
         for v in self._np(vals): acc = o.fq12_mul(acc, v)
         return self._t(acc)
     def final_exp(self, f): return self._t(o.fq12_final_exponentiation(self._np(f)))
+    def g2_prepare(self, q): return q                       # the double's "prepared handle" is the points themselves
+    def miller_product_prepared(self, p, prepared): return self.miller_product(p, prepared)
 n = %(n)d
 data = np.load(%(data)r)
 lo, hi = D.shard_range(n, rank, world)
@@ -157,6 +159,8 @@ eng = OracleEngine()
 P = torch.from_numpy(data["P"][lo:hi].view(np.int64)); Q = torch.from_numpy(data["Q"][lo:hi].view(np.int64))
 gt = D.pairing_product_sharded(eng, P, Q)
 loc = D.pairing_batch_sharded(eng, P, Q)
+gtp = D.pairing_product_prepared_sharded(eng, P, eng.g2_prepare(Q))          # the same exchange and tail over prepared points
+assert torch.equal(gtp, gt)
 np.save(%(out)r + f".{rank}.npy", np.concatenate([gt.numpy().view(np.uint64).reshape(1, 48), loc.numpy().view(np.uint64).reshape(-1, 48)]))
 dist.barrier(); dist.destroy_process_group()
 '''
