@@ -442,6 +442,15 @@ def run_product_prepared(eng, dev, dist, P, Q, steps, warmup, one_q=False, power
     ks = min(steps, 3)
     st = kernel_times(eng, dev, step, ("miller_native", "miller_native_shared") + PRODUCT_KERNELS, ks)
     kms = {k: v[0] / ks for k, v in st.items()}
+    if "miller_native_shared" in st:
+        # the Miller kernel priced over the chain it EXECUTES per pair (four / two pairs per accumulator: profiles/executed_chain_lengths.json)
+        m = 4 if n >= 4 * eng.e.get_option("round_pairs") else 2
+        key = f"miller_native_shared{m}"
+        rf = roofline(eng, {key: st["miller_native_shared"]}, n, FQMUL_OWN[key] * MAC32_PER_FQMUL, steps=ks, ref_mac32_per_unit=11952 * MAC32_PER_FQMUL)
+        kk = rf["kernels"][key]
+        kms["roofline"] = dict({k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "frac_executed", "frac_executed_of_occupancy_peak", "frac_vs_reference_chain", "avg_launch_ms", "traffic", "traffic_source")},
+                               **{k: kk.get(k) for k in ("algorithmic_bytes", "traffic_ratio", "hbm_GBps")},
+                               pairs_per_accumulator=m, table_GBps=(0 if one_q else n * 33792 / (kk["ms_per_step"] * 1e-3) / 1e9))
     if power:
         pw = PowerSampler(eng.torch, dev).run(eng.torch, dev, step, n, min_seconds=1.2, est_ms_per_step=elapsed / steps * 1e3)
         kms["power"] = {k: pw.get(k) for k in ("power_W", "sclk_MHz", "power_cap_W", "energy_uJ_per_unit", "units_per_s_during_leg")}
@@ -573,7 +582,7 @@ def side_object(eng, dev, dist, P16, Q16):
     elapsed, kms = run_product_prepared(eng, dev, dist, P, Q, 3, 1)
     side["product_prepared_2_18"] = {"config": "BASELINE.json configs[3] on ONE GPU over 2^18 natively prepared G2 points (bn254_miller_product_prepared_native_dev): 33.8 KB of table per pair "
                                                "streamed from HBM, four pairs share one Miller accumulator, one final exponentiation", "value": PRODUCT_TOTAL * 3 / elapsed, "unit": "pairs/s",
-                                     "ms_per_step": elapsed / 3 * 1e3, "kernel_ms_per_step": kms, "table_GBps": PRODUCT_TOTAL * 33792 / (max(kms.get("miller_native_shared", 0.0), 1e-9) * 1e-3) / 1e9,
+                                     "ms_per_step": elapsed / 3 * 1e3, "kernel_ms_per_step": {k: v for k, v in kms.items() if k != "roofline"}, "roofline": kms.get("roofline"),
                                      "vs_fused_product": side["product_2_18"]["ms_per_step"] / (elapsed / 3 * 1e3)}
     out1 = eng.empty(1, 48)
     step = lambda: eng.pairing_batch(P16[:1], Q16[:1], out1)

@@ -312,7 +312,8 @@ struct NativeSharedSim {
     FeP tau9() const { return p_native_tau9(tau_[cur]); }             // re-derived per line, like the kernel (LDS holds sigma, tau only)
     FeP taum() const { return p_native_taum(tau_[cur]); }
 };
-EXPORT void hsb_native_product(int m, const uint32_t *g1, const uint32_t *tables, const uint32_t *q_inf, uint32_t *o) {
+// miller_only != 0: the un-exponentiated value (what the kernel alone executes)
+EXPORT void hsb_native_product(int m, const uint32_t *g1, const uint32_t *tables, const uint32_t *q_inf, int miller_only, uint32_t *o) {
     static NativeSharedSim src;
     for (int j = 0; j < 48; ++j) src.ident[0][j] = src.ident[1][j] = 0;
     for (int j = 0; j < 9; ++j) src.ident[0][j] = k::ONE[j];                        // A = 1 + 0 i: even lane ONE, odd lane 0; B = xi B = 0
@@ -325,7 +326,7 @@ EXPORT void hsb_native_product(int m, const uint32_t *g1, const uint32_t *tables
         if (inf) p_native_identity(src.sigma[i], src.tau_[i]);
     }
     Fq12<F2B> f = m == 1 ? miller_loop_native_shared<1, F2B>(src) : m == 2 ? miller_loop_native_shared<2, F2B>(src) : m == 3 ? miller_loop_native_shared<3, F2B>(src) : miller_loop_native_shared<4, F2B>(src);
-    f12_store(final_exponentiation(f), o);
+    f12_store(miller_only ? f : final_exponentiation(f), o);
 }
 // bn254_miller_prepared_B alone (the reference-image coefficients already computed): what that kernel executes per pairing
 EXPORT void hsb_prepared_miller(const uint32_t *g1, const uint32_t *coeffs, uint32_t *o) {

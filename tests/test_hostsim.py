@@ -263,7 +263,7 @@ def test_native_prepared_product(oracle, hs):
         g1 = np.stack([oracle.g1_zero() if i in p_inf else Ps[i] for i in range(m)])
         flags = np.array([1 if i in q_inf else 0 for i in range(m)], np.uint32)
         out = np.zeros(48, np.uint64)
-        lib.hsb_native_product(C.c_int(m), np.ascontiguousarray(g1).ctypes.data_as(U32), tabs.ctypes.data_as(U32), flags.ctypes.data_as(U32), out.ctypes.data_as(U32))
+        lib.hsb_native_product(C.c_int(m), np.ascontiguousarray(g1).ctypes.data_as(U32), tabs.ctypes.data_as(U32), flags.ctypes.data_as(U32), C.c_int(0), out.ctypes.data_as(U32))
         want = one
         for i in range(m):
             if i not in p_inf and i not in q_inf:
@@ -421,6 +421,11 @@ def executed_chain_lengths(oracle, hs):
     count_raw("miller_native", 2, hs.lib.hsb_native_pairing, P.ctypes.data_as(U32), tab.ctypes.data_as(U32), C.c_int(1), o.ctypes.data_as(U32))
     hs.lib.hsb_prepared_pairing(P.ctypes.data_as(U32), Q.ctypes.data_as(U32), coeffs.ctypes.data_as(U32), o.ctypes.data_as(U32))
     count_raw("miller_prepared", 2, hs.lib.hsb_prepared_miller, P.ctypes.data_as(U32), coeffs.ctypes.data_as(U32), o.ctypes.data_as(U32))
+    # the multi-pairing over native tables: PER PAIR of a lane pair that carries four (resp. two) pairs on one accumulator
+    P4 = np.ascontiguousarray(np.tile(P, (4, 1))); tab4 = np.ascontiguousarray(np.tile(tab, 4)); flags = np.zeros(4, np.uint32)
+    for m in (4, 2):
+        count_raw(f"miller_native_shared{m}", 2, hs.lib.hsb_native_product, C.c_int(m), P4.ctypes.data_as(U32), tab4.ctypes.data_as(U32), flags.ctypes.data_as(U32), C.c_int(1), o.ctypes.data_as(U32))
+        prods[f"miller_native_shared{m}"] //= m; macs[f"miller_native_shared{m}"] //= m
     return prods, macs
 
 

@@ -10,7 +10,7 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l)
-        print('value %.5g ms/step %.4f kernels %s' % (d['value'], d['ms_per_step'], {k: (round(v,4) if not isinstance(v,dict) else {a:(round(b,1) if b else b) for a,b in v.items()}) for k,v in d["kernel_ms_per_step"].items()})); break
+        print('value %.5g ms/step %.4f kernels %s' % (d['value'], d['ms_per_step'], {k: (round(v,4) if not isinstance(v,dict) else {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items() if a in ("power_W","sclk_MHz","frac","frac_executed","table_GBps")}) for k,v in d["kernel_ms_per_step"].items()})); break
 else: print('no line')" >> $out/${tag}_ab.txt
 done; done; done
 sort $out/${tag}_ab.txt

@@ -12,7 +12,7 @@ for s in ${@:-smoke tests bench prof sq latency}; do
     newtests) timeout 1200 python -m pytest tests/test_gpu_prepared_native.py -x -q > $out/${tag}_newtests.log 2>&1; echo "newtests rc=$?" | tee -a $out/${tag}_summary.txt; tail -4 $out/${tag}_newtests.log | tee -a $out/${tag}_summary.txt ;;
     bench) timeout 900 python bench.py --steps 20 --warmup 3 > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?" | tee -a $out/${tag}_summary.txt; python tools/brief_line.py < $out/${tag}_bench.json | tee -a $out/${tag}_summary.txt
            timeout 900 python bench.py > $out/${tag}_bench_default_flags.json 2>> $out/${tag}_bench.err; python tools/brief_line.py < $out/${tag}_bench_default_flags.json | tee -a $out/${tag}_summary.txt
-           for w in g1mul g2mul gtpow product prepared; do timeout 300 python bench.py --workload $w --steps 10 --warmup 2 >> $out/${tag}_side.json 2>> $out/${tag}_bench.err; done
+           for w in g1mul g2mul gtpow product prepared product_prepared; do timeout 300 python bench.py --workload $w --steps 10 --warmup 2 >> $out/${tag}_side.json 2>> $out/${tag}_bench.err; done
            timeout 300 python bench.py --workload prepared --prepared-mode reference --steps 10 --warmup 2 >> $out/${tag}_side.json 2>> $out/${tag}_bench.err
            timeout 300 python bench.py --workload prepared --prepared-mode native_per_q --steps 10 --warmup 2 >> $out/${tag}_side.json 2>> $out/${tag}_bench.err
            python -c "
@@ -30,7 +30,7 @@ for l in open('$out/${tag}_side.json'):
           grep -h "^{" $out/${tag}_statsprep.log > $out/${tag}_prepared_line_under_rocprof.json
           for c in FETCH_SIZE WRITE_SIZE; do
             timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_pairing_$c -- python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-api --no-side --no-power > $out/${tag}_pmc_pairing_$c.log 2>&1
-            for w in g1mul g2mul gtpow product prepared; do
+            for w in g1mul g2mul gtpow product prepared product_prepared; do
               timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_${w}_$c -- python $repo/bench.py --workload $w --steps 2 --warmup 1 > $out/${tag}_pmc_${w}_$c.log 2>&1
             done
             timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_prepq_$c -- python $repo/bench.py --workload prepared --prepared-mode native_per_q --steps 2 --warmup 1 > $out/${tag}_pmc_prepq_$c.log 2>&1

@@ -21,6 +21,9 @@ KERNELS = {
     "bn254_miller_prepared_B": ("miller_prepared", lambda g: g // 2, 96 + 384),
     # one SHARED native table (33 792 B per Q, read by every lane): its algorithmic share per pairing is the table once per launch
     "bn254_miller_native_B": ("miller_native", lambda g: g // 2, 96 + 384 + 33792 / 65536),
+    # the multi-pairing over native tables, one table per pair: 96 B of P and 33 792 B of table in, a quarter / half of an Fq12 out
+    "bn254_miller_native_shared4_B": ("miller_native_shared4", lambda g: g // 2 * 4, 96 + 33792 + 384 / 4),
+    "bn254_miller_native_shared2_B": ("miller_native_shared2", lambda g: g // 2 * 2, 96 + 33792 + 384 / 2),
     "bn254_gt_pow_B": ("gt_pow", lambda g: g // 2, 384 + 32 + 384),
     "bn254_gt_mul_B": ("gt_mul", lambda g: g // 2, 3 * 384),
     "bn254_g1_mul_M": ("g1_mul", lambda g: g, 96 + 32 + 96),
