@@ -794,7 +794,7 @@ def test_bench_multi_c_mode(workload):
 
 def test_cpp_host_drives_multi_device_entry_points(oracle, tmp_path):
     """a compiled host program (g++, no Python in the loop) on include/bn254.hpp: bn::pairing, Gt::inverse, bn::MultiGpu with two
-    ranks on device 0 - pairing_batch and pairing_product equal the oracle's fold of shootout/main.rs:11-16 - and bn::PreparedG2"""
+    ranks on device 0 - pairing_batch and pairing_product equal the oracle's fold of shootout/main.rs:11-16 - and bn::PreparedG2 (batch and product)"""
     import pathlib, subprocess
     root = pathlib.Path(__file__).resolve().parents[1]
     src = tmp_path / "host.cpp"
@@ -819,6 +819,7 @@ int main() {
     for (auto &g : vk.pairing_batch(p)) dump(g);
     PreparedG2 all(q);
     for (auto &g : all.pairing_batch(p)) dump(g);
+    dump(all.pairing_product(p));                          // the multi-pairing over the prepared points
     return 0;
 }
 ''')
@@ -840,6 +841,8 @@ int main() {
     more = [np.array([int(x) for x in l.split()], np.uint64) for l in lines[8:18]]
     assert np.array_equal(np.stack(more[:5]), oracle.pairing_batch(P, np.tile(Q[1], (5, 1))))          # bn::PreparedG2 of one point
     assert np.array_equal(np.stack(more[5:]), want)                                                    # ... and of one point per pairing
+    last = np.array([int(x) for x in lines[18].split()], np.uint64)
+    assert np.array_equal(last, oracle.pairing_product(P, Q))                                          # PreparedG2::pairing_product
 
 
 def test_config3_whole_2_20_on_one_gpu(oracle):
