@@ -341,8 +341,11 @@ int bn_launch_pairing(bn254_ctx *c, const void *p, const void *q, void *out, siz
     return bn_launch_final_exp(c, out, out, n, s, table);
 }
 
-// The normalising kernels keep every lane's window table (640 B) in a buffer: sub-launches of 2^18 lanes (168 MB) reuse one.
-constexpr size_t BN_MUL_LANES_PER_LAUNCH = (size_t)1 << 18;
+// The normalising kernels keep every lane's window table (640 B) in a buffer the sub-launches reuse.  Sub-launches of 2^20 lanes (671 MB; rounds
+// 2-5: 2^18): these kernels run three resident waves per SIMD under plain oldest-first arbitration, a launch ends with every SIMD draining its last
+// wave alone, and that tail is paid once per launch - 2^20 G1 multiplications in ONE launch of 16 waves per SIMD: 91.1 against 86.7 M/s in four
+// launches on the same box, G2 +2 % (profiles/r06_ab_mul_launch_size.txt).
+constexpr size_t BN_MUL_LANES_PER_LAUNCH = (size_t)1 << 20;
 int bn_mul_dev(bn254_ctx *ctx, int g, const void *d_p, const void *d_k, void *d_out, size_t n, hipStream_t s, int normalize, BnBuf *table) {
     const size_t ps = g == 1 ? sizeof(bn_g1) : sizeof(bn_g2);
     const size_t step = normalize ? BN_MUL_LANES_PER_LAUNCH / (g == 1 ? 1 : 2) : BN_LAUNCH_MAX;
