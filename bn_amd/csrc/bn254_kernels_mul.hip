@@ -9,7 +9,9 @@
 // whole chain (in the call-based build of bn254_hip.hip every doubling went through private memory: 6 / 27 GB of HBM traffic
 // per 2^16 G1 / G2 multiplications).  Only the 16-entry window table is a per-lane array in private memory.
 #define BN_INLINE_ALL 1       // fe.hpp: leaves and Fq6/Fq12-sized steps force-inlined
-#define BN_MUL_WAVES 3        // resident waves per SIMD the G1 kernels are compiled for (160 VGPRs, no spills; 2: -1 %, 4: spills)
+#ifndef BN_MUL_WAVES
+#define BN_MUL_WAVES 3        // resident waves per SIMD the G1 kernels are compiled for (168 VGPRs, 7 spilled; 2: equal since round 6's single launch, 4: 72 spilled, -2.5 %: profiles/r06_ab_mul_launch_size.txt)
+#endif
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "curve.hpp"
