@@ -31,7 +31,7 @@ def test_cross_path_soak(oracle, te):
     import soak_paths
     lines = []
     checked, bad = soak_paths.soak(te, oracle, log=lines.append)
-    assert checked >= 350, checked            # 40 sizes x (three mappings + default + native prepared tables) + products + oracle slices
+    assert checked >= 450, checked            # 40 sizes x (three mappings + default + native prepared tables) + products (fused and over native tables, M = 1 / 2 / 4) + oracle slices
     assert bad == 0, [l for l in lines if "MISMATCH" in l]
 
 

@@ -48,6 +48,16 @@ def soak(te, oracle, sizes=SIZES, log=print):
             e.pairing_prepared_native_dev(p.data_ptr(), prep, nat.data_ptr(), n, stream=te._stream())
             torch.cuda.synchronize()
         outs["native_per_q"] = nat
+        # the multi-pairing over the same tables: plain native kernels, two and four pairs per accumulator (forced at every size; the fused
+        # product of the lane-pair kernels is the reference of the `_product` comparisons below)
+        if n <= 40000:
+            for m in (1, 2, 4):
+                part = te.empty(1, 48)
+                with e.options(wave_pairing_max=0, miller_shared=m, round_pairs=max(1, min(1 << 16, n // (2 * m)))):
+                    e.miller_product_prepared_native_dev(p.data_ptr(), prep, n, part.data_ptr(), stream=te._stream())
+                    e.final_exp_batch_dev(part.data_ptr(), part.data_ptr(), 1, te._stream())
+                    torch.cuda.synchronize()
+                outs[f"native_m{m}_product"] = part.reshape(-1).clone()
         if n <= 4097:                                                                           # ... and the default route on both sides of its limit
             natd = te.empty(n, 48)
             e.pairing_prepared_native_dev(p.data_ptr(), prep, natd.data_ptr(), n, stream=te._stream())
