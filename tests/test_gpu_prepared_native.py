@@ -322,6 +322,7 @@ def test_product_over_native_tables_matches_fold(oracle, goldens):
     with e.options(wave_pairing_max=0, round_pairs=32):
         got = e.pairing_product_prepared_native(P[:101], one)
     assert np.array_equal(got, oracle.pairing_product(P[:101], np.tile(Q[1], (101, 1))))
+    assert np.array_equal(e.pairing_product_prepared_native(P[:101], one), got)                     # ... and through the small-call route (the point repeated)
     one.close(); prep.close()
     # committed goldens: the product of all 96 golden pairings, through tables of their own g2
     g1, g2, gt = goldens["g1"], goldens["g2"], goldens["gt"]
