@@ -9,11 +9,19 @@
 // whole chain (in the call-based build of bn254_hip.hip every doubling went through private memory: 6 / 27 GB of HBM traffic
 // per 2^16 G1 / G2 multiplications).  Only the 16-entry window table is a per-lane array in private memory.
 #define BN_INLINE_ALL 1       // fe.hpp: leaves and Fq6/Fq12-sized steps force-inlined
-#ifndef BN_MUL_WAVES
 #define BN_MUL_WAVES 3        // resident waves per SIMD the G1 kernels are compiled for (168 VGPRs, 7 spilled; 2: equal since round 6's single launch, 4: 72 spilled, -2.5 %: profiles/r06_ab_mul_launch_size.txt)
-#endif
 #include <hip/hip_runtime.h>
 #include <type_traits>
+// The G2 kernel runs two resident waves per SIMD like the lane-pair pairing kernels, and the same ONE hand-over of the issue priority keeps both
+// alive to the end (bn254_kernels_b.hip bn_fair_handover; the hardware's oldest-first arbitration lets the older wave leave early and the younger
+// one finish alone): 2^16 / 2^17 / 2^18 G2 multiplications per call 33.5 / 35.1 / 36.1 -> 35.7 / 36.6 / 36.9 M/s (profiles/r06_ab_mul_launch_size.txt).
+// Called from the window loop of scalar_mul_gls only (curve.hpp BN_MUL_HOOK); the G1 kernels run three waves per SIMD and keep the default.
+__device__ __forceinline__ void bn_mul_fair_handover(int step, int total) {
+    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1;      // HW_ID.wave_id
+    if (slot == 0) { if (step * 1000 < 769 * total) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+    else { if (step * 1000 < 231 * total) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+}
+#define BN_MUL_HOOK(step, total) bn_mul_fair_handover(step, total)
 #include "curve.hpp"
 #include "io.hpp"
 

@@ -619,6 +619,7 @@ BN_FN Jac<Fq2Field<F2>> scalar_mul_gls(const Jac<Fq2Field<F2>> &p, const uint32_
         }
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
+            BN_MUL_HOOK((GLS_WINDOWS - 1 - w) * 4 + j, GLS_WINDOWS * 4);
             const int d = BoothStream<3, GLS_WINDOWS>::digit_of(j == 0 ? ds[0].s[2] : j == 1 ? ds[1].s[2] : j == 2 ? ds[2].s[2] : ds[3].s[2]);
             const int ad = d < 0 ? -d : d;
             const bool negate = ((d < 0) != g.neg[j]) != (j >= 2);            // psi^2, psi^3 carry a minus sign on y
@@ -686,6 +687,7 @@ BN_FN Fq12<F2> gt_pow_gls_loop(const uint32_t *k_raw, Tbl &tbl) {
         }
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
+            BN_EXP_HOOK((GLS_WINDOWS - 1 - w) * 4 + j, GLS_WINDOWS * 4);           // the two resident waves' hand-over (bn254_kernels_b.hip; a no-op elsewhere)
             // (the digit STREAM of scalar_mul_gls is neutral here - 18.0 M pows/s either way - and costs the register allocation of the product
             //  blocks 11 more spilled VGPRs: profiles/r06_ab_gtpow_mapped_table.txt)
             const int d = booth_digit<3>(g.m[j], w);
