@@ -22,6 +22,18 @@ __device__ __forceinline__ void bn_mul_fair_handover(int step, int total) {
     else { if (step * 1000 < 231 * total) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
 }
 #define BN_MUL_HOOK(step, total) bn_mul_fair_handover(step, total)
+// The G1 kernel (three resident waves per SIMD, oldest first) ends a launch with every SIMD draining its last waves one after the other.  In the
+// LAST resident round of a multi-round launch (the last 3 x 4 x 256 workgroups: MI355X; elsewhere the policy is merely mis-sized) a wave lowers
+// its own priority as it advances, so the three share the SIMD by progress and finish together: +0.9 ... +1.6 % at 2^20 per launch
+// (profiles/r06_ab_mul_launch_size.txt).  Single-round launches keep the default (waves of one age in lockstep are slower).
+constexpr unsigned BN_G1_RESIDENT_WAVES = BN_MUL_WAVES * 4 * 256;
+__device__ __forceinline__ void bn_g1_tail_policy(int step, int total) {
+    if (gridDim.x >= 2 * BN_G1_RESIDENT_WAVES && blockIdx.x + BN_G1_RESIDENT_WAVES >= gridDim.x) {
+        const int q = step * 4 / total;
+        if (q == 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2); else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+}
+#define BN_G1_HOOK(step, total) bn_g1_tail_policy(step, total)
 #include "curve.hpp"
 #include "io.hpp"
 

@@ -528,6 +528,7 @@ BN_FN Jac<FqField> scalar_mul_glv(const Jac<FqField> &p, const uint32_t *k_raw, 
         }
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
+            BN_G1_HOOK((GLV_WINDOWS - 1 - w) * 2 + half, GLV_WINDOWS * 2);
             const int d = half ? d2.digit() : d1.digit();
             const int ad = d < 0 ? -d : d;
             const bool negate = (d < 0) != (half ? g.neg2 : g.neg1);

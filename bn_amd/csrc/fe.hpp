@@ -67,6 +67,9 @@
 #ifndef BN_MUL_HOOK
 #define BN_MUL_HOOK(step, total) ((void)0)
 #endif
+#ifndef BN_G1_HOOK
+#define BN_G1_HOOK(step, total) ((void)0)
+#endif
 #include "bn254_constants.hpp"
 // GPU builds run the multiplier leaves and the 64-bit chains of the fused reductions as inline-asm instruction chains (fe_asm.hpp: same
 // arithmetic, fixed instruction order); the host simulation runs the C++ bodies, which also carry the bound checks

@@ -148,7 +148,7 @@ def test_only_plain_dpp_moves_and_the_flag_that_guarantees_them():
 
 
 def test_the_measurement_switch_builds(tmp_path):
-    """The library has three compile-time switches left (round 4: 45): BN_INLINE_ALL (every kernel unit defines it), BN_MILLER_HOOK / BN_EXP_HOOK / BN_MUL_HOOK (the
+    """The library has three compile-time switches left (round 4: 45): BN_INLINE_ALL (every kernel unit defines it), BN_MILLER_HOOK / BN_EXP_HOOK / BN_MUL_HOOK / BN_G1_HOOK (the
     hooks of the hand-over policy of bn254_kernels_b.hip resp. of the G2 kernel of bn254_kernels_mul.hip: defined there, each with its own default) and BN_AB_ALIAS_SCRATCH - the zero-traffic twin of the table-carrying kernels
     (same instruction stream on a cache-resident footprint, WRONG results: a timing experiment only, profiles/r04a_ab_traffic_cost.txt,
     r05_ab_shared_miller_state_traffic.txt).  The first two are exercised by every build; this test builds the third in both units that
@@ -161,7 +161,7 @@ def test_the_measurement_switch_builds(tmp_path):
         if f.name in ("fe_asm.hpp", "wave_tables.hpp", "bn254_constants.hpp"):
             continue
         switches |= set(re.findall(r"^#\s*if(?:n?def|\s+!?defined\()\s*(BN_\w+)", f.read_text(), re.M))
-    assert switches == {"BN_HOSTSIM", "BN_BOUNDS", "BN_INLINE_ALL", "BN_MILLER_HOOK", "BN_EXP_HOOK", "BN_MUL_HOOK", "BN_AB_ALIAS_SCRATCH"}, switches
+    assert switches == {"BN_HOSTSIM", "BN_BOUNDS", "BN_INLINE_ALL", "BN_MILLER_HOOK", "BN_EXP_HOOK", "BN_MUL_HOOK", "BN_G1_HOOK", "BN_AB_ALIAS_SCRATCH"}, switches
     procs = [subprocess.Popen([_native.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value"] + _native.DEVICE_FLAGS +
                               ["-DBN_AB_ALIAS_SCRATCH", "--cuda-device-only", "-c", str(csrc / (u + ".hip")), "-o", str(tmp_path / (u + ".o"))],
                               stderr=subprocess.PIPE, text=True) for u in ("bn254_kernels_mul", "bn254_kernels_b")]
